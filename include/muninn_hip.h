@@ -1,0 +1,138 @@
+/*
+ * muninn_hip.h — C-ABI of libmuninn_hip.so, the MI355X (gfx950) implementation of sqlite-muninn's
+ * compute hot path.  Plain pointers and sizes only; no C++/torch types cross this boundary.
+ *
+ * Each entry point names the reference interface it replaces (file:line in the reference repo).
+ * The SQLite glue (hnsw_vtab.c, node2vec.c, graph_community.c) binds to these instead of to
+ * hnsw_algo.c / vec_math.c; INTEGRATION.md shows the binding.
+ *
+ * Threading contract (as the reference's, SURVEY §8b "Threading"): one host thread per index at a
+ * time; several indexes per process are fine (each owns a HIP stream).
+ *
+ * Error convention follows src/hnsw_algo.h:55-79: create → NULL on failure; insert/delete → 0 / -1;
+ * search → result count.  mn_last_error() returns a thread-local message for the last failure.
+ * There is NO CPU fallback: if no gfx950 device is usable every compute entry point fails.
+ */
+#ifndef MUNINN_HIP_H
+#define MUNINN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MN_ABI_VERSION 1
+
+/* src/vec_math.h:13 — values are persisted in "{table}_config" (src/hnsw_vtab.c:189) */
+typedef enum { MN_METRIC_L2 = 0, MN_METRIC_COSINE = 1, MN_METRIC_INNER_PRODUCT = 2 } mn_metric;
+
+/* Summation order of the distance inner loop:
+ *   MN_ORDER_SSE  — bit-exact to the reference's x86 build (src/vec_math.c:78-143)
+ *   MN_ORDER_WAVE — wavefront-native order (coalesced float4 per lane + xor butterfly); within
+ *                   ~1e-7 relative of the reference, faster */
+typedef enum { MN_ORDER_SSE = 0, MN_ORDER_WAVE = 1 } mn_order;
+
+/* Build schedule for mn_hnsw_insert_batch */
+typedef enum {
+    MN_BUILD_SEQUENTIAL = 0, /* one node at a time: graph bit-identical to hnsw_insert called in a loop */
+    MN_BUILD_BATCHED = 1     /* batch-synchronous: nodes of one call are searched against the graph frozen
+                                at call start, then linked in order */
+} mn_build_mode;
+
+/* src/hnsw_algo.h:30-33 */
+typedef struct {
+    int64_t id;
+    float distance;
+} mn_search_result;
+
+typedef struct mn_index mn_index; /* replaces HnswIndex (src/hnsw_algo.h:36-53); device-resident */
+
+/* ---- library ---- */
+int mn_abi_version(void);
+const char *mn_last_error(void);
+/* number of usable gfx950 devices (0 → every compute call fails) */
+int mn_device_count(void);
+
+/* ---- vec_math.c replacements (a1-a4) ---- */
+/* src/vec_math.c:192-204: "l2" | "cosine" | "inner_product" → 0, else -1 */
+int mn_vec_parse_metric(const char *name, int *out_metric);
+/* vec_get_distance_func(metric)(query, rows[i], dim) for i < n  (src/vec_math.c:78-143,180-190).
+ * Host pointers; rows is [n][dim] row-major.  Returns 0 / -1. */
+int mn_vec_dist_batch(int metric, int order, const float *query, const float *rows, int64_t n, int dim, float *out);
+
+/* ---- hnsw_algo.c replacements (a5-a12) ---- */
+/* hnsw_create (src/hnsw_algo.c:181-208).  M_max0 = 2M, rng seed 42.  device = HIP ordinal. */
+mn_index *mn_hnsw_create(int dim, int metric, int M, int ef_construction);
+mn_index *mn_hnsw_create_on(int dim, int metric, int M, int ef_construction, int device);
+/* hnsw_destroy (:210-220) */
+void mn_hnsw_destroy(mn_index *idx);
+/* hnsw_seed_rng (:222-224) */
+void mn_hnsw_seed_rng(mn_index *idx, unsigned seed);
+/* distance summation order for this index; must be set before the first insert (default SSE) */
+int mn_hnsw_set_order(mn_index *idx, int order);
+
+/* hnsw_insert (:520-666): vector is copied.  0, or -1 on duplicate id / failure. */
+int mn_hnsw_insert(mn_index *idx, int64_t id, const float *vector);
+/* n inserts in one call.  mode MN_BUILD_SEQUENTIAL ≡ n × mn_hnsw_insert; MN_BUILD_BATCHED is the
+ * batch-synchronous schedule.  vectors is host [n][dim].  Returns 0 / -1 (nothing inserted on -1). */
+int mn_hnsw_insert_batch(mn_index *idx, const int64_t *ids, const float *vectors, int64_t n, int mode);
+/* Bulk build helper: splits [n] into batches growing with the index (batch ≤ max(1, count/grow_div),
+ * capped at max_batch) and calls the batched schedule on each.  grow_div ≤ 0 → 16, max_batch ≤ 0 → 8192. */
+int mn_hnsw_build(mn_index *idx, const int64_t *ids, const float *vectors, int64_t n, int grow_div, int max_batch);
+
+/* hnsw_search (:670-704): ef = max(ef, k); results ascending by distance; returns count ≤ k */
+int mn_hnsw_search(mn_index *idx, const float *query, int k, int ef_search, mn_search_result *results);
+/* nq independent hnsw_search calls in one launch.  queries host [nq][dim]; out_ids/out_dists host
+ * [nq][k] (unused tail: id -1, distance 0); out_counts host [nq].  Returns 0 / -1. */
+int mn_hnsw_search_batch(mn_index *idx, const float *queries, int64_t nq, int k, int ef_search, int64_t *out_ids,
+                         float *out_dists, int *out_counts);
+/* Same with every buffer already resident in device memory (HBM) on idx's device; asynchronous on the
+ * index's stream — call mn_hnsw_sync before reading.  */
+int mn_hnsw_search_batch_dev(mn_index *idx, const float *d_queries, int64_t nq, int k, int ef_search,
+                             int64_t *d_out_ids, float *d_out_dists, int *d_out_counts);
+int mn_hnsw_sync(mn_index *idx);
+
+/* hnsw_delete (:717-805): soft delete + neighbour reconnection.  0 / -1. */
+int mn_hnsw_delete(mn_index *idx, int64_t id);
+
+/* hnsw_get_vector / hnsw_get_node (:226-236): copies dim floats out (index lives in HBM).
+ * Returns 0, or -1 if absent or deleted. */
+int mn_hnsw_get_vector(mn_index *idx, int64_t id, float *out);
+
+/* ---- state the vtab persists / reloads (replaces direct HnswIndex/HnswNode field access in
+ *      src/hnsw_vtab.c:237-341,405-462 and ht_find/node_create/node_add_neighbor, src/hnsw_algo.h:98-104) ---- */
+int mn_hnsw_node_count(mn_index *idx);     /* live nodes (HnswIndex.node_count) */
+int64_t mn_hnsw_entry_point(mn_index *idx); /* -1 if empty */
+int mn_hnsw_max_level(mn_index *idx);
+int mn_hnsw_node_level(mn_index *idx, int64_t id);   /* -1 if absent */
+int mn_hnsw_node_deleted(mn_index *idx, int64_t id); /* -1 if absent */
+/* neighbour ids of `id` at `level` in list order; returns the count (may exceed cap), -1 if absent */
+int mn_hnsw_neighbors(mn_index *idx, int64_t id, int level, int64_t *out, int cap);
+/* load path of load_index_from_shadow (src/hnsw_vtab.c:286-341): nodes first, then edges, then entry */
+int mn_hnsw_load_node(mn_index *idx, int64_t id, const float *vector, int level, int deleted);
+int mn_hnsw_load_neighbors(mn_index *idx, int64_t id, int level, const int64_t *nbrs, int n);
+int mn_hnsw_set_entry(mn_index *idx, int64_t entry_point, int max_level);
+
+/* ---- measurement hooks (bench.py) ---- */
+typedef struct {
+    double last_kernel_ms;   /* HIP-event time of the last dominant kernel launch on the index's stream */
+    int64_t last_n_dist;     /* distance evaluations performed by that launch (device counter) */
+    int64_t last_n_expanded; /* neighbour rows read by that launch */
+    int64_t last_n_overflow; /* queries whose heaps exceeded workspace (must be 0) */
+} mn_launch_stats;
+int mn_hnsw_last_launch(mn_index *idx, mn_launch_stats *out);
+/* device malloc/free/copies so a non-HIP host (ctypes) can stage HBM-resident inputs */
+void *mn_dev_malloc(mn_index *idx, size_t bytes);
+void mn_dev_free(mn_index *idx, void *p);
+int mn_dev_upload(mn_index *idx, void *dst_dev, const void *src_host, size_t bytes);
+int mn_dev_download(mn_index *idx, void *dst_host, const void *src_dev, size_t bytes);
+/* exact brute-force top-k on device (ground truth for recall@k; not on the parity path).
+ * d_queries device [nq][dim]; out host [nq][k] ids. */
+int mn_hnsw_bruteforce_topk(mn_index *idx, const float *d_queries, int64_t nq, int k, int64_t *out_ids);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUNINN_HIP_H */

@@ -85,15 +85,19 @@ static float wave_reduce(float *part) {
     return part[0];
 }
 
+/* rows are stored zero-padded to ld = round_up(dim, 4); a lane folds whole float4s */
 static float dot_wave(const float *a, const float *b, int dim) {
     float part[64];
+    const int ld = (dim + 3) & ~3;
     for (int l = 0; l < 64; l++) {
         float acc = 0.0f;
-        for (int base = 0; base < dim; base += 256)
+        for (int base = 0; base < ld; base += 256)
             for (int j = 0; j < 4; j++) {
                 int e = base + 4 * l + j;
-                if (e < dim)
-                    acc = fmaf(a[e], b[e], acc);
+                if (e < ld) {
+                    float ae = e < dim ? a[e] : 0.0f, be = e < dim ? b[e] : 0.0f;
+                    acc = fmaf(ae, be, acc);
+                }
             }
         part[l] = acc;
     }
@@ -102,13 +106,14 @@ static float dot_wave(const float *a, const float *b, int dim) {
 
 static float l2_wave(const float *a, const float *b, int dim) {
     float part[64];
+    const int ld = (dim + 3) & ~3;
     for (int l = 0; l < 64; l++) {
         float acc = 0.0f;
-        for (int base = 0; base < dim; base += 256)
+        for (int base = 0; base < ld; base += 256)
             for (int j = 0; j < 4; j++) {
                 int e = base + 4 * l + j;
-                if (e < dim) {
-                    float d = a[e] - b[e];
+                if (e < ld) {
+                    float d = e < dim ? a[e] - b[e] : 0.0f;
                     acc = fmaf(d, d, acc);
                 }
             }

@@ -1,0 +1,44 @@
+"""Builds libmuninn_hip.so (gfx950) in-tree with hipcc.  No JIT cache, no torch extension machinery:
+the product is a plain C-ABI shared library (include/muninn_hip.h)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmuninn_hip.so")
+SOURCES = ["mn_kernels.hip", "mn_build.hip", "mn_index.hip", "mn_brute.hip"]
+HEADERS = ["mn_device.hpp", "mn_dist.hpp", os.path.join("..", "..", "include", "muninn_hip.h")]
+# -ffp-contract=off: the reference's distance loops use separate mul/add (src/vec_math.c:85,106);
+# the wave-order kernels call fmaf explicitly where fusion is intended.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
+         "-Wno-unused-function", "-Wno-unused-value"]
+
+
+def _hipcc() -> str:
+    for c in ("hipcc", "/opt/rocm/bin/hipcc"):
+        p = shutil.which(c)
+        if p:
+            return p
+    raise RuntimeError("hipcc not found: cannot build libmuninn_hip.so")
+
+
+def stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False) -> str:
+    if force or stale():
+        cmd = [_hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+        subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True))

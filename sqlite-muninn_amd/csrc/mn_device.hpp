@@ -1,0 +1,95 @@
+// mn_device.hpp — device-side views shared by the kernels and the host shim.  gfx950 only.
+//
+// HBM layout of one index.  Nodes are addressed by SLOT (insertion order,
+// int32); int64 rowids only appear at the API boundary (ids[slot]).
+//   vectors  [cap][ld]   f32, ld = round_up(dim,4), pad = 0          (src/hnsw_algo.h:19 HnswNode.vector)
+//   norms    [cap]       f32 |v|² in the index's summation order (cosine only)
+//   links0   [cap][W0]   int32 neighbour slots at layer 0, list order preserved, -1 padded; W0 = 2M
+//   links_up [rows][WU]  int32, layers ≥ 1; node's layer l lives in row up_off[slot] + (l-1); WU = M
+//   up_off   [cap]       int32 first pool row of the node, -1 when level == 0
+//   levels   [cap] int8, deleted [cap] u8, ids [cap] int64
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MN_WAVE 64
+constexpr int MN_ORDER_SSE_V = 0;  // muninn_hip.h mn_order
+constexpr int MN_ORDER_WAVE_V = 1;
+
+struct MnDevIndex {
+    const float *vectors;
+    const float *norms;
+    int *links0;
+    int *links_up;
+    const int *up_off;
+    const signed char *levels;
+    const unsigned char *deleted;
+    const long long *ids;
+    int dim, ld, metric, order;
+    int W0, WU;
+    int n_slots;
+    int n_pool_rows;
+};
+
+// One launch of the beam-search kernel (search or build flavour).
+struct MnSearchArgs {
+    // queries: either dense host-uploaded vectors [nq][dim] or rows of the index (build)
+    const float *queries;
+    const int *query_slots; // build: slot of each batch node
+    long long nq;
+    int k;  // search: results wanted per query
+    int ef; // beam width
+    int entry_slot, max_level;
+    // search outputs
+    long long *out_ids; // [nq][k]
+    float *out_dists;   // [nq][k]
+    int *out_counts;    // [nq]
+    // build outputs: per (query, level) the first min(found, M_max) results
+    int *sel;          // [nq][nlev][W0]
+    int *nsel;         // [nq][nlev]
+    int nlev;          // max_level + 1 at batch start
+    const int *up_bm_index; // build: per query, index of its upper-layer bitmap block or -1
+    // workspace
+    unsigned *bitmap0;       // [nq][bm0_words]
+    long long bm0_words;
+    unsigned *bitmap_up;     // [n_upper_q][max_level][bmu_words]
+    long long bmu_words;
+    uint2 *cand_ovf;         // [nq][cand_gcap]
+    int cand_gcap;
+    uint2 *res_ovf;          // [nq][res_gcap]
+    int res_gcap;
+    unsigned long long *counters; // [0] n_dist [1] n_expanded [2] overflowed queries
+};
+
+// LDS budget per wavefront (items are 8 B: f32 distance bits, int32 slot)
+#define MN_CAND_LDS 512
+#define MN_RES_LDS 256
+
+// host-callable launchers (mn_kernels.hip)
+void mn_launch_norms(const MnDevIndex &ix, int first_slot, int n, float *norms_out, hipStream_t st);
+void mn_launch_dist_batch(int metric, int order, const float *d_query, const float *d_rows, long long n, int dim, int ld,
+                          float *d_out, hipStream_t st);
+size_t mn_search_lds_bytes(int ld);
+int mn_launch_search(const MnDevIndex &ix, const MnSearchArgs &a, bool build, hipStream_t st);
+void mn_launch_bruteforce(const MnDevIndex &ix, const float *d_queries, long long nq, int k, long long *d_out_ids,
+                          float *d_scratch, hipStream_t st);
+
+// link kernels for the batched build (mn_build.hip)
+struct MnLinkArgs {
+    int level, M_max;
+    int nq, nlev;
+    const int *query_slots; // [nq] slot of batch node j
+    const int *sel;         // [nq][nlev][W0]
+    const int *nsel;        // [nq][nlev]
+    // scratch (all device)
+    int *t_target;  // [max_tuples]
+    int *t_src;     // [max_tuples] batch index j
+    int *counters;  // [0] n_tuples [1] n_touched [2] cursor   (zeroed per level)
+    int *count;     // [n_slots] zero on entry, zero again on exit
+    int *fill;      // [n_slots]
+    int *binoff;    // [n_slots]
+    int *touched;   // [max_tuples]
+    int *bins;      // [max_tuples]
+    int *newrows;   // [max_tuples][W0]
+};
+void mn_launch_link(const MnDevIndex &ix, const MnLinkArgs &a, int max_tuples, hipStream_t st);

@@ -1,0 +1,1002 @@
+// mn_index.hip — host side of libmuninn_hip.so: the C-ABI of include/muninn_hip.h over a
+// device-resident HNSW index.  No CPU compute path exists here: distances, searches and link
+// updates are HIP kernels (mn_kernels.hip, mn_build.hip); the host only keeps the id→slot table,
+// per-node metadata, the level RNG (src/hnsw_algo.c:19-30,240-248) and the cold delete path.
+#include "../../include/muninn_hip.h"
+#include "mn_device.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+
+static void set_err(const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+#define HIPCHK(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t e__ = (expr);                                                          \
+        if (e__ != hipSuccess) {                                                          \
+            set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return -1;                                                                    \
+        }                                                                                 \
+    } while (0)
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0; // elements
+    int reserve(size_t n, bool keep, hipStream_t st, int fill_byte = -1) {
+        if (n <= cap)
+            return 0;
+        size_t nc = cap ? cap : 1024;
+        while (nc < n)
+            nc = nc + nc / 2 + 1024;
+        T *np = nullptr;
+        HIPCHK(hipMalloc(&np, nc * sizeof(T)));
+        if (fill_byte >= 0)
+            HIPCHK(hipMemsetAsync(np, fill_byte, nc * sizeof(T), st));
+        if (keep && p && cap)
+            HIPCHK(hipMemcpyAsync(np, p, cap * sizeof(T), hipMemcpyDeviceToDevice, st));
+        if (p) {
+            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(hipFree(p));
+        }
+        p = np;
+        cap = nc;
+        return 0;
+    }
+    void release() {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct mn_index {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int dim = 0, ld = 0, metric = 0, order = MN_ORDER_SSE, M = 0, M_max0 = 0, efc = 0;
+    double level_mult = 0;
+    int64_t entry_id = -1;
+    int max_level = -1;
+    unsigned rng_state = 42;
+    int node_count = 0;
+    // host metadata, slot-indexed
+    std::vector<int64_t> ids;
+    std::vector<signed char> levels;
+    std::vector<unsigned char> deleted;
+    std::vector<int> up_off;
+    int n_slots = 0, n_pool_rows = 0;
+    int meta_uploaded = 0; // slots whose metadata is on the device
+    // reference-compatible open-addressing table id → slot (src/hnsw_algo.c:38-91)
+    std::vector<int> ht;
+    int ht_cap = 256;
+    // device state
+    DevBuf<float> d_vectors, d_norms;
+    DevBuf<int> d_links0, d_links_up, d_up_off;
+    DevBuf<signed char> d_levels;
+    DevBuf<unsigned char> d_deleted;
+    DevBuf<long long> d_ids;
+    // host mirror of the link rows (pulled on demand for delete / inspection / load)
+    std::vector<int> h_links0, h_links_up;
+    bool host_links_valid = true;   // host mirror == device
+    bool dev_links_stale = false;   // host mirror modified, device not yet updated
+    // workspaces
+    DevBuf<unsigned> ws_bm0, ws_bmu;
+    DevBuf<uint2> ws_cand, ws_res;
+    DevBuf<float> ws_q, ws_outd;
+    DevBuf<long long> ws_outi;
+    DevBuf<int> ws_outc, ws_qslots, ws_sel, ws_nsel, ws_upidx;
+    DevBuf<int> lk_target, lk_src, lk_counters, lk_count, lk_fill, lk_binoff, lk_touched, lk_bins, lk_newrows;
+    DevBuf<unsigned long long> ws_counters;
+    mn_launch_stats last = {0, 0, 0, 0};
+};
+
+// ───────────────────────── small host helpers ─────────────────────────
+
+static unsigned xorshift32(unsigned *state) { // src/hnsw_algo.c:19-26
+    unsigned x = *state;
+    x ^= x << 13;
+    x ^= x >> 17;
+    x ^= x << 5;
+    *state = x;
+    return x;
+}
+
+static int random_level(mn_index *x) { // src/hnsw_algo.c:240-248
+    double r = (double)xorshift32(&x->rng_state) / (double)0xFFFFFFFFu;
+    if (r == 0.0)
+        r = 1e-10;
+    int level = (int)(-log(r) * x->level_mult);
+    if (level >= 32)
+        level = 31;
+    return level;
+}
+
+static int ht_hash(int64_t id, int cap) { // src/hnsw_algo.c:38-47
+    uint64_t h = (uint64_t)id;
+    h ^= h >> 33;
+    h *= 0xff51afd7ed558ccdULL;
+    h ^= h >> 33;
+    h *= 0xc4ceb9fe1a85ec53ULL;
+    h ^= h >> 33;
+    return (int)(h & (uint64_t)(cap - 1));
+}
+
+static int ht_find(const mn_index *x, int64_t id) {
+    int s = ht_hash(id, x->ht_cap);
+    for (int i = 0; i < x->ht_cap; i++) {
+        int p = (s + i) & (x->ht_cap - 1);
+        if (x->ht[p] < 0)
+            return -1;
+        if (x->ids[x->ht[p]] == id)
+            return x->ht[p];
+    }
+    return -1;
+}
+
+static int ht_put(std::vector<int> &t, int cap, const std::vector<int64_t> &ids, int slot) {
+    int s = ht_hash(ids[slot], cap);
+    for (int i = 0; i < cap; i++) {
+        int p = (s + i) & (cap - 1);
+        if (t[p] < 0) {
+            t[p] = slot;
+            return 0;
+        }
+        if (ids[t[p]] == ids[slot])
+            return -1;
+    }
+    return -1;
+}
+
+static void ht_grow(mn_index *x) { // src/hnsw_algo.c:76-91: rehash in old-table order
+    int nc = x->ht_cap * 2;
+    std::vector<int> nt((size_t)nc, -1);
+    for (int i = 0; i < x->ht_cap; i++)
+        if (x->ht[i] >= 0)
+            ht_put(nt, nc, x->ids, x->ht[i]);
+    x->ht.swap(nt);
+    x->ht_cap = nc;
+}
+
+static int use_device(mn_index *x) {
+    HIPCHK(hipSetDevice(x->device));
+    return 0;
+}
+
+static MnDevIndex dev_view(mn_index *x) {
+    MnDevIndex v;
+    v.vectors = x->d_vectors.p;
+    v.norms = x->d_norms.p;
+    v.links0 = x->d_links0.p;
+    v.links_up = x->d_links_up.p;
+    v.up_off = x->d_up_off.p;
+    v.levels = x->d_levels.p;
+    v.deleted = x->d_deleted.p;
+    v.ids = x->d_ids.p;
+    v.dim = x->dim;
+    v.ld = x->ld;
+    v.metric = x->metric;
+    v.order = x->order;
+    v.W0 = x->M_max0;
+    v.WU = x->M;
+    v.n_slots = x->n_slots;
+    v.n_pool_rows = x->n_pool_rows;
+    return v;
+}
+
+// append a node to the host tables (node_create + ht_insert); returns slot
+static int host_add_node(mn_index *x, int64_t id, int level, int deleted) {
+    int s = x->n_slots;
+    x->ids.push_back(id);
+    x->levels.push_back((signed char)level);
+    x->deleted.push_back((unsigned char)deleted);
+    if (level > 0) {
+        x->up_off.push_back(x->n_pool_rows);
+        x->n_pool_rows += level;
+    } else {
+        x->up_off.push_back(-1);
+    }
+    x->n_slots++;
+    if (ht_put(x->ht, x->ht_cap, x->ids, s) != 0) {
+        x->ids.pop_back();
+        x->levels.pop_back();
+        x->deleted.pop_back();
+        if (level > 0)
+            x->n_pool_rows -= level;
+        x->up_off.pop_back();
+        x->n_slots--;
+        return -1;
+    }
+    if (x->host_links_valid) {
+        x->h_links0.resize((size_t)x->n_slots * x->M_max0, -1);
+        x->h_links_up.resize((size_t)x->n_pool_rows * x->M, -1);
+    }
+    return s;
+}
+
+// make device buffers large enough for the host tables and upload metadata of new slots
+static int sync_meta(mn_index *x) {
+    hipStream_t st = x->stream;
+    size_t ns = (size_t)x->n_slots;
+    if (x->d_vectors.reserve(ns * x->ld, true, st)) return -1;
+    if (x->d_norms.reserve(ns, true, st)) return -1;
+    if (x->d_links0.reserve(ns * x->M_max0, true, st, 0xFF)) return -1;
+    if (x->d_links_up.reserve((size_t)std::max(1, x->n_pool_rows) * x->M, true, st, 0xFF)) return -1;
+    if (x->d_up_off.reserve(ns, true, st)) return -1;
+    if (x->d_levels.reserve(ns, true, st)) return -1;
+    if (x->d_deleted.reserve(ns, true, st)) return -1;
+    if (x->d_ids.reserve(ns, true, st)) return -1;
+    int a = x->meta_uploaded, n = x->n_slots - a;
+    if (n > 0) {
+        HIPCHK(hipMemcpyAsync(x->d_up_off.p + a, x->up_off.data() + a, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(x->d_levels.p + a, x->levels.data() + a, (size_t)n, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(x->d_deleted.p + a, x->deleted.data() + a, (size_t)n, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(x->d_ids.p + a, x->ids.data() + a, (size_t)n * sizeof(long long), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st)); // host vectors may be reallocated by later appends
+        x->meta_uploaded = x->n_slots;
+    }
+    return 0;
+}
+
+// upload n vectors (host [n][dim]) into slots [first, first+n), zero padded to ld, and their norms
+static int upload_vectors(mn_index *x, int first, const float *vecs, int n) {
+    hipStream_t st = x->stream;
+    if (x->ld == x->dim) {
+        HIPCHK(hipMemcpyAsync(x->d_vectors.p + (size_t)first * x->ld, vecs, (size_t)n * x->dim * sizeof(float),
+                              hipMemcpyHostToDevice, st));
+    } else {
+        HIPCHK(hipMemsetAsync(x->d_vectors.p + (size_t)first * x->ld, 0, (size_t)n * x->ld * sizeof(float), st));
+        HIPCHK(hipMemcpy2DAsync(x->d_vectors.p + (size_t)first * x->ld, (size_t)x->ld * sizeof(float), vecs,
+                                (size_t)x->dim * sizeof(float), (size_t)x->dim * sizeof(float), (size_t)n,
+                                hipMemcpyHostToDevice, st));
+    }
+    if (x->metric == MN_METRIC_COSINE)
+        mn_launch_norms(dev_view(x), first, n, x->d_norms.p, st);
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
+static int pull_links(mn_index *x) {
+    if (x->host_links_valid)
+        return 0;
+    x->h_links0.assign((size_t)x->n_slots * x->M_max0, -1);
+    x->h_links_up.assign((size_t)x->n_pool_rows * x->M, -1);
+    if (x->n_slots)
+        HIPCHK(hipMemcpyAsync(x->h_links0.data(), x->d_links0.p, x->h_links0.size() * sizeof(int), hipMemcpyDeviceToHost,
+                              x->stream));
+    if (x->n_pool_rows)
+        HIPCHK(hipMemcpyAsync(x->h_links_up.data(), x->d_links_up.p, x->h_links_up.size() * sizeof(int),
+                              hipMemcpyDeviceToHost, x->stream));
+    HIPCHK(hipStreamSynchronize(x->stream));
+    x->host_links_valid = true;
+    x->dev_links_stale = false;
+    return 0;
+}
+
+static int push_links(mn_index *x) {
+    if (!x->dev_links_stale)
+        return 0;
+    if (sync_meta(x))
+        return -1;
+    if (x->n_slots)
+        HIPCHK(hipMemcpyAsync(x->d_links0.p, x->h_links0.data(), x->h_links0.size() * sizeof(int), hipMemcpyHostToDevice,
+                              x->stream));
+    if (x->n_pool_rows)
+        HIPCHK(hipMemcpyAsync(x->d_links_up.p, x->h_links_up.data(), x->h_links_up.size() * sizeof(int),
+                              hipMemcpyHostToDevice, x->stream));
+    HIPCHK(hipStreamSynchronize(x->stream));
+    x->dev_links_stale = false;
+    return 0;
+}
+
+static int *h_row(mn_index *x, int slot, int level, int *W) {
+    if (level == 0) {
+        *W = x->M_max0;
+        return x->h_links0.data() + (size_t)slot * x->M_max0;
+    }
+    *W = x->M;
+    return x->h_links_up.data() + ((size_t)x->up_off[slot] + (level - 1)) * x->M;
+}
+
+static int h_row_count(const int *row, int W) {
+    int n = 0;
+    while (n < W && row[n] >= 0)
+        n++;
+    return n;
+}
+
+// ───────────────────────── library ─────────────────────────
+
+extern "C" int mn_abi_version(void) { return MN_ABI_VERSION; }
+extern "C" const char *mn_last_error(void) { return g_err.c_str(); }
+
+extern "C" int mn_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    int ok = 0;
+    for (int i = 0; i < n; i++) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0)
+            ok++;
+    }
+    return ok;
+}
+
+extern "C" int mn_vec_parse_metric(const char *name, int *out) { // src/vec_math.c:192-204
+    if (!name || !out)
+        return -1;
+    if (strcmp(name, "l2") == 0) {
+        *out = MN_METRIC_L2;
+        return 0;
+    }
+    if (strcmp(name, "cosine") == 0) {
+        *out = MN_METRIC_COSINE;
+        return 0;
+    }
+    if (strcmp(name, "inner_product") == 0) {
+        *out = MN_METRIC_INNER_PRODUCT;
+        return 0;
+    }
+    return -1;
+}
+
+extern "C" int mn_vec_dist_batch(int metric, int order, const float *query, const float *rows, int64_t n, int dim,
+                                 float *out) {
+    if (mn_device_count() <= 0) {
+        set_err("mn_vec_dist_batch: no gfx950 device");
+        return -1;
+    }
+    if (n <= 0)
+        return 0;
+    int ld = (dim + 3) & ~3;
+    float *dq = nullptr, *dr = nullptr, *dout = nullptr;
+    HIPCHK(hipMalloc(&dq, (size_t)dim * sizeof(float)));
+    HIPCHK(hipMalloc(&dr, (size_t)n * ld * sizeof(float)));
+    HIPCHK(hipMalloc(&dout, (size_t)n * sizeof(float)));
+    HIPCHK(hipMemcpy(dq, query, (size_t)dim * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(dr, 0, (size_t)n * ld * sizeof(float)));
+    HIPCHK(hipMemcpy2D(dr, (size_t)ld * sizeof(float), rows, (size_t)dim * sizeof(float), (size_t)dim * sizeof(float),
+                       (size_t)n, hipMemcpyHostToDevice));
+    mn_launch_dist_batch(metric, order, dq, dr, n, dim, ld, dout, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, dout, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    (void)hipFree(dq);
+    (void)hipFree(dr);
+    (void)hipFree(dout);
+    return 0;
+}
+
+// ───────────────────────── create / destroy ─────────────────────────
+
+extern "C" mn_index *mn_hnsw_create_on(int dim, int metric, int M, int ef_construction, int device) {
+    if (dim <= 0 || M < 2 || ef_construction < 1 || metric < 0 || metric > 2) {
+        set_err("mn_hnsw_create: bad parameters");
+        return nullptr;
+    }
+    if (2 * M + 1 > 64) {
+        set_err("mn_hnsw_create: M=%d not supported on device (2M+1 must fit one 64-lane wavefront)", M);
+        return nullptr;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        set_err("mn_hnsw_create: HIP device %d not available (no CPU fallback)", device);
+        return nullptr;
+    }
+    mn_index *x = new mn_index();
+    x->device = device;
+    x->dim = dim;
+    x->ld = (dim + 3) & ~3;
+    x->metric = metric;
+    x->M = M;
+    x->M_max0 = 2 * M; // src/hnsw_algo.c:188
+    x->efc = ef_construction;
+    x->level_mult = 1.0 / log((double)M); // :192
+    x->ht.assign(256, -1);                // :197
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&x->ev0) != hipSuccess || hipEventCreate(&x->ev1) != hipSuccess) {
+        set_err("mn_hnsw_create: cannot create HIP stream/events on device %d", device);
+        delete x;
+        return nullptr;
+    }
+    return x;
+}
+
+extern "C" mn_index *mn_hnsw_create(int dim, int metric, int M, int ef_construction) {
+    return mn_hnsw_create_on(dim, metric, M, ef_construction, 0);
+}
+
+extern "C" void mn_hnsw_destroy(mn_index *x) {
+    if (!x)
+        return;
+    (void)hipSetDevice(x->device);
+    if (x->stream)
+        (void)hipStreamSynchronize(x->stream);
+    x->d_vectors.release(); x->d_norms.release(); x->d_links0.release(); x->d_links_up.release();
+    x->d_up_off.release(); x->d_levels.release(); x->d_deleted.release(); x->d_ids.release();
+    x->ws_bm0.release(); x->ws_bmu.release(); x->ws_cand.release(); x->ws_res.release(); x->ws_q.release();
+    x->ws_outd.release(); x->ws_outi.release(); x->ws_outc.release(); x->ws_qslots.release(); x->ws_sel.release();
+    x->ws_nsel.release(); x->ws_upidx.release(); x->lk_target.release(); x->lk_src.release(); x->lk_counters.release();
+    x->lk_count.release(); x->lk_fill.release(); x->lk_binoff.release(); x->lk_touched.release(); x->lk_bins.release();
+    x->lk_newrows.release(); x->ws_counters.release();
+    if (x->ev0) (void)hipEventDestroy(x->ev0);
+    if (x->ev1) (void)hipEventDestroy(x->ev1);
+    if (x->stream) (void)hipStreamDestroy(x->stream);
+    delete x;
+}
+
+extern "C" void mn_hnsw_seed_rng(mn_index *x, unsigned seed) { x->rng_state = seed ? seed : 1; }
+
+extern "C" int mn_hnsw_set_order(mn_index *x, int order) {
+    if (x->n_slots > 0) {
+        set_err("mn_hnsw_set_order: index not empty");
+        return -1;
+    }
+    if (order != MN_ORDER_SSE && order != MN_ORDER_WAVE)
+        return -1;
+    x->order = order;
+    return 0;
+}
+
+// ───────────────────────── search ─────────────────────────
+
+static int prepare_search_ws(mn_index *x, int64_t nq, int ef, MnSearchArgs &a) {
+    hipStream_t st = x->stream;
+    a.bm0_words = ((int64_t)x->n_slots + 31) / 32;
+    a.cand_gcap = 16 * ef + 1024;
+    a.res_gcap = ef > MN_RES_LDS ? ef : 8;
+    if (x->ws_bm0.reserve((size_t)nq * a.bm0_words, false, st)) return -1;
+    if (x->ws_cand.reserve((size_t)nq * a.cand_gcap, false, st)) return -1;
+    if (x->ws_res.reserve((size_t)nq * a.res_gcap, false, st)) return -1;
+    if (x->ws_counters.reserve(4, false, st)) return -1;
+    HIPCHK(hipMemsetAsync(x->ws_bm0.p, 0, (size_t)nq * a.bm0_words * sizeof(unsigned), st));
+    HIPCHK(hipMemsetAsync(x->ws_counters.p, 0, 4 * sizeof(unsigned long long), st));
+    a.bitmap0 = x->ws_bm0.p;
+    a.cand_ovf = x->ws_cand.p;
+    a.res_ovf = x->ws_res.p;
+    a.counters = x->ws_counters.p;
+    a.bitmap_up = nullptr;
+    a.bmu_words = 0;
+    return 0;
+}
+
+static int fetch_counters(mn_index *x) {
+    unsigned long long c[4];
+    HIPCHK(hipMemcpyAsync(c, x->ws_counters.p, sizeof(c), hipMemcpyDeviceToHost, x->stream));
+    HIPCHK(hipStreamSynchronize(x->stream));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, x->ev0, x->ev1) == hipSuccess)
+        x->last.last_kernel_ms = ms;
+    x->last.last_n_dist = (int64_t)c[0];
+    x->last.last_n_expanded = (int64_t)c[1];
+    x->last.last_n_overflow = (int64_t)c[2];
+    return 0;
+}
+
+extern "C" int mn_hnsw_search_batch_dev(mn_index *x, const float *d_queries, int64_t nq, int k, int ef, int64_t *d_ids,
+                                        float *d_dists, int *d_counts) {
+    if (use_device(x))
+        return -1;
+    if (nq <= 0)
+        return 0;
+    if (k <= 0) {
+        set_err("mn_hnsw_search: k must be > 0");
+        return -1;
+    }
+    if (ef < k) // src/hnsw_algo.c:673
+        ef = k;
+    hipStream_t st = x->stream;
+    if (x->entry_id == -1 || x->node_count == 0) { // :671
+        HIPCHK(hipMemsetAsync(d_counts, 0, (size_t)nq * sizeof(int), st));
+        HIPCHK(hipMemsetAsync(d_ids, 0xFF, (size_t)nq * k * sizeof(int64_t), st));
+        HIPCHK(hipMemsetAsync(d_dists, 0, (size_t)nq * k * sizeof(float), st));
+        return 0;
+    }
+    if (push_links(x) || sync_meta(x))
+        return -1;
+    MnSearchArgs a;
+    memset(&a, 0, sizeof(a));
+    if (prepare_search_ws(x, nq, ef, a))
+        return -1;
+    a.queries = d_queries;
+    a.nq = nq;
+    a.k = k;
+    a.ef = ef;
+    a.entry_slot = ht_find(x, x->entry_id);
+    a.max_level = x->max_level;
+    a.out_ids = (long long *)d_ids;
+    a.out_dists = d_dists;
+    a.out_counts = d_counts;
+    HIPCHK(hipEventRecord(x->ev0, st));
+    mn_launch_search(dev_view(x), a, false, st);
+    HIPCHK(hipEventRecord(x->ev1, st));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mn_hnsw_sync(mn_index *x) {
+    if (use_device(x))
+        return -1;
+    HIPCHK(hipStreamSynchronize(x->stream));
+    return 0;
+}
+
+extern "C" int mn_hnsw_search_batch(mn_index *x, const float *queries, int64_t nq, int k, int ef, int64_t *out_ids,
+                                    float *out_dists, int *out_counts) {
+    if (use_device(x))
+        return -1;
+    if (nq <= 0)
+        return 0;
+    hipStream_t st = x->stream;
+    if (x->ws_q.reserve((size_t)nq * x->dim, false, st)) return -1;
+    if (x->ws_outi.reserve((size_t)nq * k, false, st)) return -1;
+    if (x->ws_outd.reserve((size_t)nq * k, false, st)) return -1;
+    if (x->ws_outc.reserve((size_t)nq, false, st)) return -1;
+    HIPCHK(hipMemcpyAsync(x->ws_q.p, queries, (size_t)nq * x->dim * sizeof(float), hipMemcpyHostToDevice, st));
+    if (mn_hnsw_search_batch_dev(x, x->ws_q.p, nq, k, ef, (int64_t *)x->ws_outi.p, x->ws_outd.p, x->ws_outc.p))
+        return -1;
+    HIPCHK(hipMemcpyAsync(out_ids, x->ws_outi.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out_dists, x->ws_outd.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out_counts, x->ws_outc.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (x->entry_id != -1 && x->node_count > 0) {
+        if (fetch_counters(x))
+            return -1;
+        if (x->last.last_n_overflow) {
+            set_err("mn_hnsw_search: %lld queries exceeded heap workspace", (long long)x->last.last_n_overflow);
+            return -1;
+        }
+    }
+    return 0;
+}
+
+extern "C" int mn_hnsw_search(mn_index *x, const float *query, int k, int ef, mn_search_result *results) {
+    if (k <= 0)
+        return 0;
+    std::vector<int64_t> ids((size_t)k);
+    std::vector<float> ds((size_t)k);
+    int cnt = 0;
+    if (mn_hnsw_search_batch(x, query, 1, k, ef, ids.data(), ds.data(), &cnt))
+        return 0; // src/hnsw_algo.h:70: count, 0 on failure
+    for (int i = 0; i < cnt; i++) {
+        results[i].id = ids[i];
+        results[i].distance = ds[i];
+    }
+    return cnt;
+}
+
+// ───────────────────────── insert ─────────────────────────
+
+// searched + linked against the graph frozen at call start; slots[] are already appended & uploaded
+static int run_batch(mn_index *x, const std::vector<int> &slots) {
+    hipStream_t st = x->stream;
+    const int nq = (int)slots.size();
+    if (nq == 0)
+        return 0;
+    const int fz_max = x->max_level;
+    const int nlev = fz_max + 1;
+    MnSearchArgs a;
+    memset(&a, 0, sizeof(a));
+    if (prepare_search_ws(x, nq, x->efc, a))
+        return -1;
+    // upper-layer bitmaps for batch nodes with level >= 1
+    std::vector<int> upidx((size_t)nq, -1);
+    int n_upper = 0;
+    for (int j = 0; j < nq; j++)
+        if (x->levels[slots[j]] >= 1 && fz_max >= 1)
+            upidx[j] = n_upper++;
+    a.bmu_words = ((int64_t)std::max(1, x->n_pool_rows) + 31) / 32;
+    if (n_upper) {
+        size_t words = (size_t)n_upper * fz_max * a.bmu_words;
+        if (x->ws_bmu.reserve(words, false, st)) return -1;
+        HIPCHK(hipMemsetAsync(x->ws_bmu.p, 0, words * sizeof(unsigned), st));
+    }
+    a.bitmap_up = x->ws_bmu.p;
+    if (x->ws_qslots.reserve((size_t)nq, false, st)) return -1;
+    if (x->ws_upidx.reserve((size_t)nq, false, st)) return -1;
+    if (x->ws_sel.reserve((size_t)nq * nlev * x->M_max0, false, st)) return -1;
+    if (x->ws_nsel.reserve((size_t)nq * nlev, false, st)) return -1;
+    HIPCHK(hipMemcpyAsync(x->ws_qslots.p, slots.data(), (size_t)nq * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(x->ws_upidx.p, upidx.data(), (size_t)nq * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(x->ws_nsel.p, 0, (size_t)nq * nlev * sizeof(int), st));
+    a.query_slots = x->ws_qslots.p;
+    a.up_bm_index = x->ws_upidx.p;
+    a.nq = nq;
+    a.ef = x->efc;
+    a.entry_slot = ht_find(x, x->entry_id);
+    a.max_level = fz_max;
+    a.sel = x->ws_sel.p;
+    a.nsel = x->ws_nsel.p;
+    a.nlev = nlev;
+    MnDevIndex v = dev_view(x);
+    HIPCHK(hipEventRecord(x->ev0, st));
+    mn_launch_search(v, a, true, st);
+    HIPCHK(hipEventRecord(x->ev1, st));
+    // link, layer by layer
+    const int max_tuples = nq * x->M_max0;
+    if (x->lk_target.reserve((size_t)max_tuples, false, st)) return -1;
+    if (x->lk_src.reserve((size_t)max_tuples, false, st)) return -1;
+    if (x->lk_counters.reserve(4, false, st)) return -1;
+    if (x->lk_count.reserve((size_t)x->d_ids.cap, false, st, 0)) return -1;
+    if (x->lk_fill.reserve((size_t)x->d_ids.cap, false, st)) return -1;
+    if (x->lk_binoff.reserve((size_t)x->d_ids.cap, false, st)) return -1;
+    if (x->lk_touched.reserve((size_t)max_tuples, false, st)) return -1;
+    if (x->lk_bins.reserve((size_t)max_tuples, false, st)) return -1;
+    if (x->lk_newrows.reserve((size_t)max_tuples * x->M_max0, false, st)) return -1;
+    MnLinkArgs la;
+    memset(&la, 0, sizeof(la));
+    la.nq = nq;
+    la.nlev = nlev;
+    la.query_slots = x->ws_qslots.p;
+    la.sel = x->ws_sel.p;
+    la.nsel = x->ws_nsel.p;
+    la.t_target = x->lk_target.p;
+    la.t_src = x->lk_src.p;
+    la.counters = x->lk_counters.p;
+    la.count = x->lk_count.p;
+    la.fill = x->lk_fill.p;
+    la.binoff = x->lk_binoff.p;
+    la.touched = x->lk_touched.p;
+    la.bins = x->lk_bins.p;
+    la.newrows = x->lk_newrows.p;
+    for (int l = 0; l < nlev; l++) {
+        la.level = l;
+        la.M_max = l == 0 ? x->M_max0 : x->M;
+        int mt = l == 0 ? max_tuples : nq * x->M;
+        mn_launch_link(v, la, mt, st);
+    }
+    HIPCHK(hipGetLastError());
+    if (fetch_counters(x))
+        return -1;
+    if (x->last.last_n_overflow) {
+        set_err("mn_hnsw_insert: %lld searches exceeded heap workspace", (long long)x->last.last_n_overflow);
+        return -1;
+    }
+    x->host_links_valid = false;
+    // entry point / max level in batch order (src/hnsw_algo.c:660-663)
+    for (int j = 0; j < nq; j++) {
+        int lv = x->levels[slots[j]];
+        if (lv > x->max_level) {
+            x->entry_id = x->ids[slots[j]];
+            x->max_level = lv;
+        }
+    }
+    return 0;
+}
+
+static int insert_impl(mn_index *x, const int64_t *ids, const float *vectors, int64_t n, int mode) {
+    if (use_device(x))
+        return -1;
+    if (n <= 0)
+        return 0;
+    // duplicates against the index and inside the call (src/hnsw_algo.c:522)
+    {
+        std::vector<int64_t> sorted(ids, ids + n);
+        std::sort(sorted.begin(), sorted.end());
+        for (int64_t i = 1; i < n; i++)
+            if (sorted[i] == sorted[i - 1]) {
+                set_err("mn_hnsw_insert: duplicate id %lld in batch", (long long)sorted[i]);
+                return -1;
+            }
+        for (int64_t i = 0; i < n; i++)
+            if (ht_find(x, ids[i]) >= 0) {
+                set_err("mn_hnsw_insert: duplicate id %lld", (long long)ids[i]);
+                return -1;
+            }
+    }
+    if (push_links(x))
+        return -1;
+    const int first = x->n_slots;
+    std::vector<int> slots((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        if (x->node_count * 10 > x->ht_cap * 7) // :527
+            ht_grow(x);
+        int level = random_level(x); // :532
+        slots[i] = host_add_node(x, ids[i], level, 0);
+        x->node_count++;
+    }
+    if (sync_meta(x))
+        return -1;
+    if (upload_vectors(x, first, vectors, (int)n))
+        return -1;
+    size_t pos = 0;
+    if (x->entry_id == -1) { // :544-548 first node just becomes the entry point
+        x->entry_id = ids[0];
+        x->max_level = x->levels[slots[0]];
+        pos = 1;
+    }
+    if (mode == MN_BUILD_SEQUENTIAL) {
+        for (; pos < (size_t)n; pos++) {
+            std::vector<int> one(1, slots[pos]);
+            if (run_batch(x, one))
+                return -1;
+        }
+        return 0;
+    }
+    std::vector<int> rest(slots.begin() + pos, slots.end());
+    return run_batch(x, rest);
+}
+
+extern "C" int mn_hnsw_insert(mn_index *x, int64_t id, const float *vector) {
+    return insert_impl(x, &id, vector, 1, MN_BUILD_SEQUENTIAL);
+}
+
+extern "C" int mn_hnsw_insert_batch(mn_index *x, const int64_t *ids, const float *vectors, int64_t n, int mode) {
+    return insert_impl(x, ids, vectors, n, mode);
+}
+
+extern "C" int mn_hnsw_build(mn_index *x, const int64_t *ids, const float *vectors, int64_t n, int grow_div,
+                             int max_batch) {
+    if (grow_div <= 0)
+        grow_div = 16;
+    if (max_batch <= 0)
+        max_batch = 8192;
+    int64_t pos = 0;
+    while (pos < n) {
+        int64_t b = std::max<int64_t>(1, x->node_count / grow_div);
+        b = std::min<int64_t>(b, max_batch);
+        b = std::min<int64_t>(b, n - pos);
+        if (insert_impl(x, ids + pos, vectors + (size_t)pos * x->dim, b, MN_BUILD_BATCHED))
+            return -1;
+        pos += b;
+    }
+    return 0;
+}
+
+// ───────────────────────── delete (cold path, host-side list surgery on the mirror) ─────────────────────────
+
+static int h_add(mn_index *x, int slot, int level, int nbr) { // node_add_neighbor, src/hnsw_algo.c:142-163
+    if (level > x->levels[slot])
+        return -1;
+    int W;
+    int *row = h_row(x, slot, level, &W);
+    int n = h_row_count(row, W);
+    for (int i = 0; i < n; i++)
+        if (row[i] == nbr)
+            return 0;
+    if (n >= W)
+        return -2; // the reference would grow the list; fixed-width device rows cannot
+    row[n] = nbr;
+    return 0;
+}
+
+static void h_remove(mn_index *x, int slot, int level, int nbr) { // :166-177 swap with last
+    if (level > x->levels[slot])
+        return;
+    int W;
+    int *row = h_row(x, slot, level, &W);
+    int n = h_row_count(row, W);
+    for (int i = 0; i < n; i++)
+        if (row[i] == nbr) {
+            row[i] = row[n - 1];
+            row[n - 1] = -1;
+            return;
+        }
+}
+
+extern "C" int mn_hnsw_delete(mn_index *x, int64_t id) { // src/hnsw_algo.c:717-805
+    if (use_device(x))
+        return -1;
+    int s = ht_find(x, id);
+    if (s < 0 || x->deleted[s])
+        return -1;
+    if (pull_links(x))
+        return -1;
+    // dry run for overflow so a refused delete leaves the index untouched
+    std::vector<int> save0 = x->h_links0, saveu = x->h_links_up;
+    x->deleted[s] = 1;
+    x->node_count--;
+    int min_conn = x->M / 2;
+    bool overflow = false;
+    for (int l = 0; l <= x->levels[s] && !overflow; l++) {
+        int W;
+        int *row = h_row(x, s, l, &W);
+        int nc = h_row_count(row, W);
+        std::vector<int> former(row, row + nc);
+        for (int i = 0; i < nc; i++)
+            if (!x->deleted[former[i]])
+                h_remove(x, former[i], l, s);
+        for (int i = 0; i < nc && !overflow; i++) {
+            int orphan = former[i];
+            if (x->deleted[orphan] || l > x->levels[orphan])
+                continue;
+            int Wo;
+            int *orow = h_row(x, orphan, l, &Wo);
+            if (h_row_count(orow, Wo) >= min_conn)
+                continue;
+            for (int j = 0; j < nc && h_row_count(orow, Wo) < min_conn; j++) {
+                if (i == j)
+                    continue;
+                int cand = former[j];
+                if (x->deleted[cand] || l > x->levels[cand])
+                    continue;
+                bool already = false;
+                for (int k = 0; k < h_row_count(orow, Wo); k++)
+                    if (orow[k] == cand) {
+                        already = true;
+                        break;
+                    }
+                if (!already) {
+                    if (h_add(x, orphan, l, cand) == -2 || h_add(x, cand, l, orphan) == -2) {
+                        overflow = true;
+                        break;
+                    }
+                }
+            }
+        }
+    }
+    if (overflow) {
+        x->h_links0.swap(save0);
+        x->h_links_up.swap(saveu);
+        x->deleted[s] = 0;
+        x->node_count++;
+        set_err("mn_hnsw_delete: reconnection would exceed the fixed neighbour-row width (unsupported)");
+        return -1;
+    }
+    if (x->entry_id == id) { // :790-802 scan in hash-table order, strict >
+        x->entry_id = -1;
+        x->max_level = -1;
+        for (int i = 0; i < x->ht_cap; i++) {
+            int t = x->ht[i];
+            if (t >= 0 && !x->deleted[t] && x->levels[t] > x->max_level) {
+                x->max_level = x->levels[t];
+                x->entry_id = x->ids[t];
+            }
+        }
+    }
+    x->dev_links_stale = true;
+    if (s < x->meta_uploaded)
+        HIPCHK(hipMemcpy(x->d_deleted.p + s, &x->deleted[s], 1, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// ───────────────────────── inspection / load ─────────────────────────
+
+extern "C" int mn_hnsw_get_vector(mn_index *x, int64_t id, float *out) {
+    if (use_device(x))
+        return -1;
+    int s = ht_find(x, id);
+    if (s < 0 || x->deleted[s])
+        return -1;
+    HIPCHK(hipMemcpy(out, x->d_vectors.p + (size_t)s * x->ld, (size_t)x->dim * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int mn_hnsw_node_count(mn_index *x) { return x->node_count; }
+extern "C" int64_t mn_hnsw_entry_point(mn_index *x) { return x->entry_id; }
+extern "C" int mn_hnsw_max_level(mn_index *x) { return x->max_level; }
+extern "C" int mn_hnsw_node_level(mn_index *x, int64_t id) {
+    int s = ht_find(x, id);
+    return s < 0 ? -1 : x->levels[s];
+}
+extern "C" int mn_hnsw_node_deleted(mn_index *x, int64_t id) {
+    int s = ht_find(x, id);
+    return s < 0 ? -1 : x->deleted[s];
+}
+
+extern "C" int mn_hnsw_neighbors(mn_index *x, int64_t id, int level, int64_t *out, int cap) {
+    if (use_device(x))
+        return -1;
+    int s = ht_find(x, id);
+    if (s < 0 || level > x->levels[s])
+        return -1;
+    if (pull_links(x))
+        return -1;
+    int W;
+    int *row = h_row(x, s, level, &W);
+    int n = h_row_count(row, W);
+    for (int i = 0; i < n && i < cap; i++)
+        out[i] = x->ids[row[i]];
+    return n;
+}
+
+extern "C" int mn_hnsw_load_node(mn_index *x, int64_t id, const float *vector, int level, int deleted) {
+    if (use_device(x))
+        return -1;
+    if (level < 0 || level >= 32)
+        return -1;
+    if (pull_links(x))
+        return -1;
+    if (x->node_count * 10 > x->ht_cap * 7) // src/hnsw_vtab.c:304-306
+        ht_grow(x);
+    int s = host_add_node(x, id, level, deleted);
+    if (s < 0)
+        return -1;
+    if (!deleted)
+        x->node_count++;
+    if (sync_meta(x))
+        return -1;
+    return upload_vectors(x, s, vector, 1);
+}
+
+extern "C" int mn_hnsw_load_neighbors(mn_index *x, int64_t id, int level, const int64_t *nbrs, int n) {
+    if (use_device(x))
+        return -1;
+    int s = ht_find(x, id);
+    if (s < 0 || level > x->levels[s])
+        return -1;
+    if (pull_links(x))
+        return -1;
+    for (int i = 0; i < n; i++) {
+        int t = ht_find(x, nbrs[i]);
+        if (t < 0)
+            continue;
+        if (h_add(x, s, level, t) == -2) {
+            set_err("mn_hnsw_load_neighbors: more than %d neighbours at level %d", level == 0 ? x->M_max0 : x->M, level);
+            return -1;
+        }
+    }
+    x->dev_links_stale = true;
+    return 0;
+}
+
+extern "C" int mn_hnsw_set_entry(mn_index *x, int64_t entry, int max_level) {
+    x->entry_id = entry;
+    x->max_level = max_level;
+    return 0;
+}
+
+// ───────────────────────── measurement hooks ─────────────────────────
+
+extern "C" int mn_hnsw_last_launch(mn_index *x, mn_launch_stats *out) {
+    if (use_device(x))
+        return -1;
+    if (fetch_counters(x))
+        return -1;
+    *out = x->last;
+    return 0;
+}
+
+extern "C" void *mn_dev_malloc(mn_index *x, size_t bytes) {
+    void *p = nullptr;
+    if (hipSetDevice(x->device) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) {
+        set_err("mn_dev_malloc(%zu) failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+extern "C" void mn_dev_free(mn_index *x, void *p) {
+    (void)hipSetDevice(x->device);
+    (void)hipFree(p);
+}
+extern "C" int mn_dev_upload(mn_index *x, void *dst, const void *src, size_t bytes) {
+    if (use_device(x))
+        return -1;
+    HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+extern "C" int mn_dev_download(mn_index *x, void *dst, const void *src, size_t bytes) {
+    if (use_device(x))
+        return -1;
+    HIPCHK(hipStreamSynchronize(x->stream));
+    HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int mn_hnsw_bruteforce_topk(mn_index *x, const float *d_queries, int64_t nq, int k, int64_t *out_ids) {
+    if (use_device(x))
+        return -1;
+    if (sync_meta(x))
+        return -1;
+    hipStream_t st = x->stream;
+    if (x->ws_outi.reserve((size_t)nq * k, false, st)) return -1;
+    mn_launch_bruteforce(dev_view(x), d_queries, nq, k, x->ws_outi.p, nullptr, st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_ids, x->ws_outi.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+}

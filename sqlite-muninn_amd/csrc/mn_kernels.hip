@@ -1,0 +1,555 @@
+// mn_kernels.hip — hand-written gfx950 kernels for sqlite-muninn's HNSW hot path.
+//
+//   k_norms        |v|² per row in the index's summation order (cosine)
+//   k_dist_batch   vec_*_distance(query, rows[i])                       src/vec_math.c:78-143
+//   k_beam         greedy descent + ef-bounded beam search, one 64-lane wavefront per query
+//                  (search flavour: hnsw_search src/hnsw_algo.c:670-704; build flavour: the search
+//                  half of hnsw_insert :550-579 for every node of a batch)
+//
+// Execution model: one wavefront owns one query.  The candidate min-heap and the result max-heap
+// (negated distances) are the reference's 1-based binary heaps (src/priority_queue.c:18-80) held in
+// LDS with a global-memory spill, driven wave-uniformly so that pop order among equal distances —
+// and therefore the returned id set — is the reference's.  The visited set (src/hnsw_algo.c:299-338,
+// a plain set) is a per-query bitmap in HBM probed with returning atomicOr (L2-coherent, one round
+// trip for the whole neighbour row).  Candidate vectors are read straight from HBM into registers:
+//   MN_ORDER_WAVE  each row as coalesced float4 per lane (1 KiB per wave-instruction), 8 rows in
+//                  flight, fmaf chain per lane + xor butterfly
+//   MN_ORDER_SSE   16 rows at a time, lane (r,j) walks accumulator j of row r in the reference's
+//                  exact order (separate mul/add, ((t0+t1)+t2)+t3, scalar tail)
+// Build with -ffp-contract=off; the WAVE path uses explicit fmaf, the SSE path explicit *_rn ops.
+#include "mn_device.hpp"
+
+#include "mn_dist.hpp"
+
+// ───────────────────────── k_norms ─────────────────────────
+
+template <int ORDER>
+__global__ void __launch_bounds__(64) k_norms(MnDevIndex ix, int first_slot, int n, float *norms_out) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x;
+    int slot = first_slot + blockIdx.x;
+    if (blockIdx.x >= n)
+        return;
+    const float *row = ix.vectors + (size_t)slot * ix.ld;
+    for (int i = lane; i < ix.ld; i += 64)
+        lds[i] = row[i];
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    float v = lds_self_norm<ORDER>(lds, ix.dim, ix.ld, lane);
+    if (lane == 0)
+        norms_out[slot] = v;
+}
+
+void mn_launch_norms(const MnDevIndex &ix, int first_slot, int n, float *norms_out, hipStream_t st) {
+    if (n <= 0)
+        return;
+    size_t lds = (size_t)ix.ld * sizeof(float);
+    if (ix.order == MN_ORDER_SSE_V)
+        hipLaunchKernelGGL(k_norms<MN_ORDER_SSE_V>, dim3(n), dim3(64), lds, st, ix, first_slot, n, norms_out);
+    else
+        hipLaunchKernelGGL(k_norms<MN_ORDER_WAVE_V>, dim3(n), dim3(64), lds, st, ix, first_slot, n, norms_out);
+}
+
+// ───────────────────────── k_dist_batch ─────────────────────────
+// One wavefront handles up to 64 consecutive rows (WAVE: 8 in flight; SSE: 16 at a time).
+
+template <int ORDER, int NCH>
+__global__ void __launch_bounds__(64)
+    k_dist_batch(int metric, const float *query, const float *rows, long long n, int dim, int ld, float *out) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < ld; i += 64)
+        lds[i] = i < dim ? query[i] : 0.0f;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    MnDevIndex ix = {};
+    ix.vectors = rows;
+    ix.dim = dim;
+    ix.ld = ld;
+    ix.metric = metric;
+    float qnorm = 0.0f;
+    if (metric == 1)
+        qnorm = lds_self_norm<ORDER>(lds, dim, ld, lane);
+    long long base = (long long)blockIdx.x * 64;
+    int cnt = (int)((n - base) < 64 ? (n - base) : 64);
+    if (cnt <= 0)
+        return;
+    // rows are addressed as slots relative to `rows`; slots fit int32 per block via rebasing
+    ix.vectors = rows + (size_t)base * ld;
+    int myslot = lane < cnt ? lane : 0;
+    float d;
+    if (metric == 0) {
+        d = rows_accumulate<ORDER, NCH, true>(ix, lds, myslot, cnt, lane);
+    } else {
+        float dot = rows_accumulate<ORDER, NCH, false>(ix, lds, myslot, cnt, lane);
+        if (metric == 2) {
+            d = -dot;
+        } else {
+            // |row|² in the same order: recompute per row (no cached norms for loose rows)
+            float nb = 0.0f;
+            for (int t = 0; t < cnt; t++) {
+                const float *row = ix.vectors + (size_t)t * ld;
+                // stage row into the upper half of LDS, then self-norm
+                float *tmp = lds + ld;
+                for (int i = lane; i < ld; i += 64)
+                    tmp[i] = row[i];
+                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_wave_barrier();
+                float v = lds_self_norm<ORDER>(tmp, dim, ld, lane);
+                __builtin_amdgcn_wave_barrier();
+                if (lane == t)
+                    nb = v;
+            }
+            d = cosine_finish(dot, qnorm, nb);
+        }
+    }
+    if (lane < cnt)
+        out[base + lane] = d;
+}
+
+static int pick_nch(int ld) {
+    int need = (ld + 255) / 256;
+    if (need <= 1) return 1;
+    if (need <= 2) return 2;
+    if (need <= 3) return 3;
+    if (need <= 4) return 4;
+    if (need <= 6) return 6;
+    if (need <= 8) return 8;
+    return 0;
+}
+
+void mn_launch_dist_batch(int metric, int order, const float *d_query, const float *d_rows, long long n, int dim, int ld,
+                          float *d_out, hipStream_t st) {
+    if (n <= 0)
+        return;
+    dim3 grid((unsigned)((n + 63) / 64)), block(64);
+    size_t lds = (size_t)ld * sizeof(float) * 2;
+    if (order == MN_ORDER_SSE_V) {
+        hipLaunchKernelGGL((k_dist_batch<MN_ORDER_SSE_V, 0>), grid, block, lds, st, metric, d_query, d_rows, n, dim, ld, d_out);
+        return;
+    }
+#define MN_DB(N) \
+    case N:      \
+        hipLaunchKernelGGL((k_dist_batch<MN_ORDER_WAVE_V, N>), grid, block, lds, st, metric, d_query, d_rows, n, dim, ld, d_out); \
+        break;
+    switch (pick_nch(ld)) {
+        MN_DB(1) MN_DB(2) MN_DB(3) MN_DB(4) MN_DB(6) MN_DB(8)
+    default:
+        hipLaunchKernelGGL((k_dist_batch<MN_ORDER_WAVE_V, 0>), grid, block, lds, st, metric, d_query, d_rows, n, dim, ld, d_out);
+    }
+#undef MN_DB
+}
+
+// ───────────────────────── wave-uniform binary heap (src/priority_queue.c) ─────────────────────────
+// Item = (distance bits, slot).  1-based; index i < lcap lives in LDS, the rest in global memory
+// (agent-scope relaxed atomics there: L1 is bypassed so lanes of the wave see each other's stores).
+
+struct WHeap {
+    uint2 *l;
+    unsigned long long *g;
+    int lcap, gcap;
+    int size;
+    int ovf;
+};
+
+DEVI uint2 hget(const WHeap &h, int i) {
+    if (i < h.lcap)
+        return h.l[i];
+    unsigned long long v = __hip_atomic_load(&h.g[i - h.lcap], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_uint2((unsigned)(v & 0xffffffffull), (unsigned)(v >> 32));
+}
+// executed by exactly the lanes that should write
+DEVI void hset(const WHeap &h, int i, uint2 v) {
+    if (i < h.lcap)
+        h.l[i] = v;
+    else
+        __hip_atomic_store(&h.g[i - h.lcap], (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// pq_push + sift_up (src/priority_queue.c:18-26,56-70).  The new item climbs while its parent is
+// strictly greater; lane j inspects ancestor j, one ballot finds where it stops.
+DEVI void heap_push(WHeap &h, int slot, float d, int lane) {
+    if (h.size + 1 >= h.lcap + h.gcap) {
+        h.ovf = 1;
+        return;
+    }
+    h.size++;
+    const int idx = h.size;
+    const int depth = 31 - __clz(idx);
+    const bool anc = lane >= 1 && lane <= depth;
+    const int p = anc ? (idx >> lane) : idx;
+    const uint2 x = make_uint2(f2u(d), (unsigned)slot);
+    uint2 it = x;
+    if (anc)
+        it = hget(h, p);
+    unsigned long long stopm = __ballot(anc && (u2f(it.x) <= d));
+    const int stop = stopm ? (__ffsll((long long)stopm) - 1) : depth + 1;
+    if (lane >= 1 && lane < stop)
+        hset(h, idx >> (lane - 1), it);
+    if (lane == 0)
+        hset(h, idx >> (stop - 1), x);
+    __builtin_amdgcn_wave_barrier();
+}
+
+// pq_pop + sift_down (src/priority_queue.c:28-42,72-80): strict <, left child first.  Wave-uniform.
+DEVI uint2 heap_pop(WHeap &h, int lane) {
+    uint2 top = hget(h, 1);
+    top.x = rflu(top.x);
+    top.y = rflu(top.y);
+    uint2 x = hget(h, h.size);
+    x.x = rflu(x.x);
+    x.y = rflu(x.y);
+    h.size--;
+    if (h.size > 0) {
+        int idx = 1;
+        const float xd = u2f(x.x);
+        for (;;) {
+            int left = 2 * idx;
+            if (left > h.size)
+                break;
+            uint2 L, Rt;
+            if (left + 1 < h.lcap) { // both children in LDS, 16-byte aligned pair
+                uint4 c = *reinterpret_cast<const uint4 *>(&h.l[left]);
+                L = make_uint2(c.x, c.y);
+                Rt = make_uint2(c.z, c.w);
+            } else {
+                L = hget(h, left);
+                Rt = (left + 1 <= h.size) ? hget(h, left + 1) : L;
+            }
+            L.x = rflu(L.x);
+            L.y = rflu(L.y);
+            Rt.x = rflu(Rt.x);
+            Rt.y = rflu(Rt.y);
+            int smallest = idx;
+            float sd = xd;
+            uint2 sv = x;
+            if (u2f(L.x) < sd) {
+                smallest = left;
+                sd = u2f(L.x);
+                sv = L;
+            }
+            if (left + 1 <= h.size && u2f(Rt.x) < sd) {
+                smallest = left + 1;
+                sv = Rt;
+            }
+            if (smallest == idx)
+                break;
+            if (lane == 0)
+                hset(h, idx, sv);
+            idx = smallest;
+        }
+        if (lane == 0)
+            hset(h, idx, x);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return top;
+}
+
+// ───────────────────────── beam search ─────────────────────────
+
+struct WaveCtx {
+    const float *q;  // LDS query, zero padded to ld
+    float qnorm;
+    int *scratch;    // LDS, 64 ints
+    unsigned long long n_dist, n_exp;
+};
+
+DEVI const int *link_row(const MnDevIndex &ix, int node, int level, int &W) {
+    if (level == 0) {
+        W = ix.W0;
+        return ix.links0 + (size_t)node * ix.W0;
+    }
+    W = ix.WU;
+    return ix.links_up + ((size_t)ix.up_off[node] + (level - 1)) * ix.WU;
+}
+
+// src/hnsw_algo.c:257-282 incl. its quirk: after `current` is re-pointed the for-loop carries on at
+// index i+1 of the NEW node's list.
+template <int ORDER, int NCH>
+DEVI int greedy_layer(const MnDevIndex &ix, WaveCtx &w, int entry, int level, int lane) {
+    int cur = entry;
+    float cur_d = rows_distance<ORDER, NCH>(ix, w.q, w.qnorm, cur, 1, lane);
+    cur_d = __shfl(cur_d, 0);
+    w.n_dist += 1;
+    int changed = 1;
+    int guard = 0;
+    while (changed && guard < (1 << 20)) {
+        changed = 0;
+        int i0 = 0;
+        for (;;) {
+            guard++;
+            int W;
+            const int *row = link_row(ix, cur, level, W);
+            w.n_exp++;
+            int nb = (lane < W) ? row[lane] : -1;
+            bool valid = lane >= i0 && nb >= 0 && !ix.deleted[nb >= 0 ? nb : 0];
+            unsigned long long m = __ballot(valid);
+            int n = __popcll(m);
+            if (n == 0)
+                break;
+            int rank = __popcll(m & ((1ull << lane) - 1ull));
+            __builtin_amdgcn_wave_barrier();
+            if (valid)
+                w.scratch[rank] = nb;
+            __builtin_amdgcn_wave_barrier();
+            int myslot = lane < n ? w.scratch[lane] : 0;
+            float d = rows_distance<ORDER, NCH>(ix, w.q, w.qnorm, myslot, n, lane);
+            w.n_dist += n;
+            unsigned long long better = __ballot(lane < n && d < cur_d);
+            if (!better)
+                break;
+            int c = __ffsll((long long)better) - 1; // first compact index that improves
+            cur_d = __shfl(d, c);
+            cur = __shfl(myslot, c);
+            // list position of compact index c = position of the (c+1)-th set bit of m
+            int pos_of_me = lane; // lanes with valid hold their own list position
+            __builtin_amdgcn_wave_barrier();
+            if (valid)
+                w.scratch[rank] = pos_of_me;
+            __builtin_amdgcn_wave_barrier();
+            i0 = w.scratch[c] + 1;
+            i0 = rfl(i0);
+            cur = rfl(cur);
+            changed = 1;
+        }
+    }
+    return cur;
+}
+
+// src/hnsw_algo.c:347-448.  Results are left in the result heap; the caller drains it.
+template <int ORDER, int NCH>
+DEVI void beam_layer(const MnDevIndex &ix, WaveCtx &w, WHeap &cand, WHeap &res, unsigned *bitmap, int entry, int level,
+                     int ef, int lane) {
+    cand.size = 0;
+    res.size = 0;
+    if (!ix.deleted[entry]) { // :360-366
+        float d = rows_distance<ORDER, NCH>(ix, w.q, w.qnorm, entry, 1, lane);
+        d = __shfl(d, 0);
+        w.n_dist += 1;
+        heap_push(cand, entry, d, lane);
+        heap_push(res, entry, -d, lane);
+        if (lane == 0) {
+            int vi = level == 0 ? entry : ix.up_off[entry];
+            atomicOr(&bitmap[vi >> 5], 1u << (vi & 31));
+        }
+    }
+    int patience_max = ef / 4; // :372-375
+    if (patience_max < 10)
+        patience_max = 10;
+    int stale = 0;
+    int guard = 0;
+    while (cand.size > 0 && guard < (1 << 24)) {
+        guard++;
+        uint2 c = heap_pop(cand, lane);
+        const float cd = u2f(c.x);
+        if (res.size >= ef) { // :382-386
+            float worst = -u2f(rflu(hget(res, 1).x));
+            if (cd > worst)
+                break;
+        }
+        if (stale >= patience_max && res.size >= ef) // :391
+            break;
+        const int node = (int)c.y;
+        int W;
+        const int *row = link_row(ix, node, level, W);
+        w.n_exp++;
+        int nb = (lane < W) ? row[lane] : -1;
+        bool todo = false;
+        if (nb >= 0) { // :403-409 — mark visited first, then drop deleted
+            int vi = level == 0 ? nb : ix.up_off[nb];
+            unsigned bit = 1u << (vi & 31);
+            unsigned old = atomicOr(&bitmap[vi >> 5], bit);
+            todo = !(old & bit) && !ix.deleted[nb];
+        }
+        unsigned long long m = __ballot(todo);
+        int n = __popcll(m);
+        int improved = 0;
+        if (n > 0) {
+            int rank = __popcll(m & ((1ull << lane) - 1ull));
+            __builtin_amdgcn_wave_barrier();
+            if (todo)
+                w.scratch[rank] = nb;
+            __builtin_amdgcn_wave_barrier();
+            int myslot = lane < n ? w.scratch[lane] : 0;
+            float d = rows_distance<ORDER, NCH>(ix, w.q, w.qnorm, myslot, n, lane);
+            w.n_dist += n;
+            // :413-425, in list order.  Once the result set is full an element can only be accepted
+            // if it beats the worst AT THAT MOMENT, which never exceeds the worst now: pre-filter.
+            unsigned long long am;
+            if (res.size >= ef) {
+                float worst0 = -u2f(rflu(hget(res, 1).x));
+                am = __ballot(lane < n && d < worst0);
+            } else {
+                am = __ballot(lane < n);
+            }
+            while (am) {
+                int i = __ffsll((long long)am) - 1;
+                am &= am - 1;
+                float di = __shfl(d, i);
+                int si = __shfl(myslot, i);
+                di = u2f(rflu(f2u(di)));
+                si = rfl(si);
+                if (res.size < ef) {
+                    heap_push(cand, si, di, lane);
+                    heap_push(res, si, -di, lane);
+                    improved = 1;
+                } else {
+                    float worst = -u2f(rflu(hget(res, 1).x));
+                    if (di < worst) {
+                        heap_push(cand, si, di, lane);
+                        heap_pop(res, lane);
+                        heap_push(res, si, -di, lane);
+                        improved = 1;
+                    }
+                }
+            }
+        }
+        stale = improved ? 0 : stale + 1; // :428-432
+    }
+    if (guard >= (1 << 24))
+        cand.ovf = 1;
+}
+
+template <int ORDER, int NCH, bool BUILD>
+__global__ void __launch_bounds__(64) k_beam(MnDevIndex ix, MnSearchArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const long long qi = blockIdx.x;
+    if (qi >= a.nq)
+        return;
+    // LDS carve: cand heap | result heap | scratch | query
+    uint2 *cand_l = reinterpret_cast<uint2 *>(smem);
+    uint2 *res_l = cand_l + MN_CAND_LDS;
+    int *scratch = reinterpret_cast<int *>(res_l + MN_RES_LDS);
+    float *q = reinterpret_cast<float *>(scratch + 64);
+
+    int qslot = -1;
+    const float *qsrc;
+    if (BUILD) {
+        qslot = a.query_slots[qi];
+        qsrc = ix.vectors + (size_t)qslot * ix.ld;
+    } else {
+        qsrc = a.queries + (size_t)qi * ix.dim;
+    }
+    for (int i = lane; i < ix.ld; i += 64)
+        q[i] = i < ix.dim ? qsrc[i] : 0.0f;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+
+    WaveCtx w;
+    w.q = q;
+    w.scratch = scratch;
+    w.n_dist = 0;
+    w.n_exp = 0;
+    w.qnorm = 0.0f;
+    if (ix.metric == 1)
+        w.qnorm = BUILD ? ix.norms[qslot] : lds_self_norm<ORDER>(q, ix.dim, ix.ld, lane);
+
+    WHeap cand, res;
+    cand.l = cand_l;
+    cand.lcap = MN_CAND_LDS;
+    cand.g = reinterpret_cast<unsigned long long *>(a.cand_ovf + (size_t)qi * a.cand_gcap);
+    cand.gcap = a.cand_gcap;
+    cand.size = 0;
+    cand.ovf = 0;
+    res.l = res_l;
+    res.lcap = MN_RES_LDS;
+    res.g = reinterpret_cast<unsigned long long *>(a.res_ovf + (size_t)qi * a.res_gcap);
+    res.gcap = a.res_gcap;
+    res.size = 0;
+    res.ovf = 0;
+
+    unsigned *bm0 = a.bitmap0 + (size_t)qi * a.bm0_words;
+    int cur = a.entry_slot;
+
+    if (!BUILD) {
+        // hnsw_search, src/hnsw_algo.c:676-703
+        for (int l = a.max_level; l > 0; l--)
+            cur = greedy_layer<ORDER, NCH>(ix, w, cur, l, lane);
+        beam_layer<ORDER, NCH>(ix, w, cand, res, bm0, cur, 0, a.ef, lane);
+        int count = res.size;
+        int outn = count < a.k ? count : a.k;
+        for (int i = count - 1; i >= 0; i--) { // :436-441
+            uint2 it = heap_pop(res, lane);
+            if (i < a.k && lane == 0) {
+                a.out_ids[qi * a.k + i] = ix.ids[it.y];
+                a.out_dists[qi * a.k + i] = -u2f(it.x);
+            }
+        }
+        if (lane == 0) {
+            for (int i = outn; i < a.k; i++) {
+                a.out_ids[qi * a.k + i] = -1;
+                a.out_dists[qi * a.k + i] = 0.0f;
+            }
+            a.out_counts[qi] = outn;
+        }
+    } else {
+        // search half of hnsw_insert, src/hnsw_algo.c:550-579,:650-652, against the frozen graph
+        const int level = ix.levels[qslot];
+        for (int l = a.max_level; l > level; l--)
+            cur = greedy_layer<ORDER, NCH>(ix, w, cur, l, lane);
+        int start = level < a.max_level ? level : a.max_level;
+        for (int l = start; l >= 0; l--) {
+            unsigned *bm = bm0;
+            if (l > 0)
+                bm = a.bitmap_up + ((size_t)a.up_bm_index[qi] * a.max_level + (l - 1)) * a.bmu_words;
+            beam_layer<ORDER, NCH>(ix, w, cand, res, bm, cur, l, a.ef, lane);
+            const int M_max = (l == 0) ? ix.W0 : ix.WU;
+            int count = res.size;
+            int keep = count < M_max ? count : M_max;
+            int *sel = a.sel + ((size_t)qi * a.nlev + l) * ix.W0;
+            int first = cur;
+            for (int i = count - 1; i >= 0; i--) {
+                uint2 it = heap_pop(res, lane);
+                if (i < keep && lane == 0)
+                    sel[i] = (int)it.y;
+                if (i == 0)
+                    first = (int)it.y;
+            }
+            if (lane == 0)
+                a.nsel[qi * a.nlev + l] = keep;
+            if (count > 0)
+                cur = first;
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(&a.counters[0], w.n_dist);
+        atomicAdd(&a.counters[1], w.n_exp);
+        if (cand.ovf || res.ovf)
+            atomicAdd(&a.counters[2], 1ull);
+    }
+}
+
+size_t mn_search_lds_bytes(int ld) {
+    return (size_t)(MN_CAND_LDS + MN_RES_LDS) * sizeof(uint2) + 64 * sizeof(int) + (size_t)ld * sizeof(float);
+}
+
+template <int ORDER, int NCH>
+static void launch_beam(const MnDevIndex &ix, const MnSearchArgs &a, bool build, hipStream_t st) {
+    dim3 grid((unsigned)a.nq), block(64);
+    size_t lds = mn_search_lds_bytes(ix.ld);
+    if (build)
+        hipLaunchKernelGGL((k_beam<ORDER, NCH, true>), grid, block, lds, st, ix, a);
+    else
+        hipLaunchKernelGGL((k_beam<ORDER, NCH, false>), grid, block, lds, st, ix, a);
+}
+
+int mn_launch_search(const MnDevIndex &ix, const MnSearchArgs &a, bool build, hipStream_t st) {
+    if (a.nq <= 0)
+        return 0;
+    if (ix.order == MN_ORDER_SSE_V) {
+        launch_beam<MN_ORDER_SSE_V, 0>(ix, a, build, st);
+        return 0;
+    }
+    switch (pick_nch(ix.ld)) {
+    case 1: launch_beam<MN_ORDER_WAVE_V, 1>(ix, a, build, st); break;
+    case 2: launch_beam<MN_ORDER_WAVE_V, 2>(ix, a, build, st); break;
+    case 3: launch_beam<MN_ORDER_WAVE_V, 3>(ix, a, build, st); break;
+    case 4: launch_beam<MN_ORDER_WAVE_V, 4>(ix, a, build, st); break;
+    case 6: launch_beam<MN_ORDER_WAVE_V, 6>(ix, a, build, st); break;
+    case 8: launch_beam<MN_ORDER_WAVE_V, 8>(ix, a, build, st); break;
+    default: launch_beam<MN_ORDER_WAVE_V, 0>(ix, a, build, st); break;
+    }
+    return 0;
+}

@@ -1,0 +1,172 @@
+"""GPU parity tests (-m gpu): the HIP path through the C-ABI vs the CPU oracle on identical seeded
+inputs.  Bit-exact for ids, slots, levels and neighbour lists; distances bit-exact against the
+oracle running the same summation order, and within 1e-5 relative of the reference order."""
+import numpy as np
+import pytest
+
+from util import gauss, same_bits
+
+pytestmark = pytest.mark.gpu
+
+METRICS = ["l2", "cosine", "inner_product"]
+
+
+@pytest.mark.parametrize("metric", METRICS)
+@pytest.mark.parametrize("dim", [1, 3, 4, 5, 7, 8, 31, 128, 260, 768, 1536, 2500])
+def test_dist_batch_bit_exact(gpu, orc, metric, dim):
+    X = gauss(200, dim, 7)
+    q = gauss(1, dim, 8)[0]
+    X[3] = 0.0  # zero vector → cosine 1.0 (src/vec_math.c:122-125)
+    X[5] = q  # identical
+    for order, oorder in ((gpu.ORDER_SSE, orc.ORDER_SSE), (gpu.ORDER_WAVE, orc.ORDER_WAVE)):
+        got = gpu.vec_dist_batch(metric, q, X, order)
+        want = orc.dist_batch(metric, q, X, oorder)
+        assert same_bits(got, want), (metric, dim, order)
+    # fast order vs the reference order: 1e-5 relative (north_star).  "Relative" is taken against the
+    # natural scale of the quantity: cosine distance is 1 - cos (absolute accuracy of the subtraction,
+    # scale 1); a dot product / squared distance of near-orthogonal or near-identical vectors cancels,
+    # so its scale is |q||x| resp. |q|^2 + |x|^2.
+    ref = orc.dist_batch(metric, q, X, orc.ORDER_SSE)
+    fast = gpu.vec_dist_batch(metric, q, X, gpu.ORDER_WAVE)
+    qn, xn = np.linalg.norm(q), np.linalg.norm(X, axis=1)
+    floor = {"cosine": np.ones_like(xn), "inner_product": qn * xn, "l2": qn * qn + xn * xn}[metric]
+    scale = np.maximum(np.abs(ref), floor + 1e-30)
+    assert np.max(np.abs(fast - ref) / scale) < 1e-5
+
+
+def _oracle_graph(orc, metric, n, dim, M, efc, order, seed=42, deletes=0):
+    X = gauss(n, dim, seed)
+    ids = (np.arange(n, dtype=np.int64) * 7 + 3)
+    o = orc.Oracle(dim, metric, M, efc, order=order)
+    assert o.insert_many(ids, X) == 0
+    if deletes:
+        rng = np.random.default_rng(seed + 1)
+        for d in ids[rng.choice(n, deletes, replace=False)]:
+            o.delete(int(d))
+    return o, ids, X
+
+
+@pytest.mark.parametrize("metric", METRICS)
+@pytest.mark.parametrize("order", ["sse", "wave"])
+@pytest.mark.parametrize("shape", [(2000, 32, 16, 200), (600, 128, 16, 100), (400, 7, 4, 30), (300, 768, 8, 40)])
+def test_search_over_fixed_graph_bit_exact(gpu, orc, metric, order, shape):
+    n, dim, M, efc = shape
+    oo = orc.ORDER_SSE if order == "sse" else orc.ORDER_WAVE
+    go = gpu.ORDER_SSE if order == "sse" else gpu.ORDER_WAVE
+    o, ids, X = _oracle_graph(orc, metric, n, dim, M, efc, oo, deletes=n // 20)
+    g = gpu.HnswIndex(dim, metric, M, efc, order=go)
+    g.load_graph_from(o, ids, X)
+    assert g.node_count == o.node_count
+    Q = gauss(64, dim, 99)
+    for k, ef in ((1, 1), (10, 10), (10, 20), (10, 64), (10, 128), (50, 300)):
+        wi, wd, wc = o.search_many(Q, k, ef)
+        gi, gd, gc = g.search_batch(Q, k, ef)
+        assert np.array_equal(gc, wc), (k, ef)
+        assert np.array_equal(gi, wi), (k, ef)
+        assert same_bits(gd, wd), (k, ef)
+    # single-query entry point (hnsw_search) agrees with the batch
+    i1, d1 = g.search(Q[0], 10, 64)
+    wi, wd = o.search(Q[0], 10, 64)
+    assert np.array_equal(i1, wi) and same_bits(d1, wd)
+    g.close()
+
+
+def test_search_with_duplicate_vectors_ties(gpu, orc):
+    """Equal distances: pop order among ties is decided by the heap's sift rules
+    (src/priority_queue.c:18-42); the device heaps must reproduce it."""
+    dim, n = 16, 600
+    base = gauss(60, dim, 5)
+    X = base[np.random.default_rng(6).integers(0, 60, n)]  # many exact duplicates
+    ids = np.arange(1, n + 1, dtype=np.int64)
+    for metric in METRICS:
+        o = orc.Oracle(dim, metric, 8, 60)
+        o.insert_many(ids, X)
+        g = gpu.HnswIndex(dim, metric, 8, 60)
+        g.load_graph_from(o, ids, X)
+        Q = base[:32] + 0.0
+        for ef in (10, 40, 100):
+            wi, wd, wc = o.search_many(Q, 10, ef)
+            gi, gd, gc = g.search_batch(Q, 10, ef)
+            assert np.array_equal(gi, wi), (metric, ef)
+            assert same_bits(gd, wd)
+        g.close()
+
+
+def test_empty_and_tiny_index(gpu, orc):
+    g = gpu.HnswIndex(4, "l2", 4, 10)
+    ids, ds = g.search(np.zeros(4, np.float32), 5, 10)
+    assert len(ids) == 0  # src/hnsw_algo.c:671
+    assert g.insert(42, np.array([1, 2, 3, 4], np.float32)) == 0
+    assert g.insert(42, np.array([1, 2, 3, 4], np.float32)) == -1  # duplicate (:522)
+    assert g.entry_point == 42 and g.node_count == 1
+    assert np.array_equal(g.get_vector(42), np.array([1, 2, 3, 4], np.float32))
+    ids, ds = g.search(np.array([1, 2, 3, 5], np.float32), 3, 10)
+    assert ids.tolist() == [42] and ds[0] == np.float32(1.0)
+    g.close()
+
+
+@pytest.mark.parametrize("metric", ["l2", "cosine"])
+@pytest.mark.parametrize("order", ["sse", "wave"])
+def test_batched_build_matches_oracle_schedule(gpu, orc, metric, order):
+    """Batch-synchronous build: identical graph to the CPU restatement of the same schedule."""
+    n, dim, M, efc = 3000, 24, 8, 60
+    oo = orc.ORDER_SSE if order == "sse" else orc.ORDER_WAVE
+    go = gpu.ORDER_SSE if order == "sse" else gpu.ORDER_WAVE
+    X = gauss(n, dim, 11)
+    ids = np.arange(100, 100 + n, dtype=np.int64)
+    o = orc.Oracle(dim, metric, M, efc, order=oo)
+    g = gpu.HnswIndex(dim, metric, M, efc, order=go)
+    pos = 0
+    for b in (1, 1, 1, 5, 20, 100, 372, 1000, 1500):
+        assert o.insert_batch(ids[pos:pos + b], X[pos:pos + b]) == 0
+        assert g.insert_batch(ids[pos:pos + b], X[pos:pos + b], gpu.BUILD_BATCHED) == 0
+        pos += b
+    assert pos == n
+    assert g.graph(ids) == o.graph(ids)
+    Q = gauss(50, dim, 12)
+    wi, wd, wc = o.search_many(Q, 10, 64)
+    gi, gd, gc = g.search_batch(Q, 10, 64)
+    assert np.array_equal(gi, wi) and same_bits(gd, wd)
+    g.close()
+
+
+def test_batched_build_with_ties_matches_oracle(gpu, orc):
+    """Duplicate vectors force distance ties inside the MN-RU prune (src/hnsw_algo.c:620-639)."""
+    dim, n = 8, 1200
+    base = gauss(40, dim, 21)
+    X = base[np.random.default_rng(22).integers(0, 40, n)]
+    ids = np.arange(1, n + 1, dtype=np.int64)
+    for metric in ("l2", "cosine"):
+        o = orc.Oracle(dim, metric, 4, 40)
+        g = gpu.HnswIndex(dim, metric, 4, 40)
+        pos = 0
+        for b in (1, 3, 16, 80, 300, 800):
+            o.insert_batch(ids[pos:pos + b], X[pos:pos + b])
+            assert g.insert_batch(ids[pos:pos + b], X[pos:pos + b], gpu.BUILD_BATCHED) == 0
+            pos += b
+        assert g.graph(ids) == o.graph(ids), metric
+        g.close()
+
+
+def test_delete_matches_oracle(gpu, orc):
+    n, dim = 800, 16
+    X = gauss(n, dim, 31)
+    ids = np.arange(1, n + 1, dtype=np.int64)
+    o = orc.Oracle(dim, "l2", 8, 50)
+    o.insert_many(ids, X)
+    g = gpu.HnswIndex(dim, "l2", 8, 50)
+    g.load_graph_from(o, ids, X)
+    rng = np.random.default_rng(32)
+    dels = [int(o.entry_point)] + [int(x) for x in ids[rng.choice(n, 60, replace=False)]]
+    for d in dels:
+        ro = o.delete(d)
+        rg = g.delete(d)
+        assert ro == rg
+    assert g.delete(dels[0]) == -1  # already deleted
+    assert g.graph(ids) == o.graph(ids)
+    assert g.node_count == o.node_count and g.entry_point == o.entry_point
+    Q = gauss(40, dim, 33)
+    wi, wd, wc = o.search_many(Q, 10, 64)
+    gi, gd, gc = g.search_batch(Q, 10, 64)
+    assert np.array_equal(gi, wi) and same_bits(gd, wd)
+    g.close()
