@@ -115,6 +115,15 @@ int mn_hnsw_load_node(mn_index *idx, int64_t id, const float *vector, int level,
 int mn_hnsw_load_neighbors(mn_index *idx, int64_t id, int level, const int64_t *nbrs, int n);
 int mn_hnsw_set_entry(mn_index *idx, int64_t entry_point, int max_level);
 
+/* Bulk export (what a bulk persist_node replacement reads, src/hnsw_vtab.c:237-283; also lets a
+ * checker mirror the device graph).  Slots are insertion order; deleted nodes keep their slot. */
+int mn_hnsw_slot_count(mn_index *idx);
+int mn_hnsw_export_nodes(mn_index *idx, int64_t *ids, int *levels, int *deleted); /* each [slot_count] */
+int mn_hnsw_export_vectors(mn_index *idx, float *out);                             /* [slot_count][dim] */
+/* neighbour rows of every slot at `level` as slot indices, -1 padded: out is [slot_count][width];
+ * rows of nodes whose level < `level` are all -1.  *width = 2M at level 0, M above. */
+int mn_hnsw_export_links(mn_index *idx, int level, int *out, int *width);
+
 /* ---- measurement hooks (bench.py) ---- */
 typedef struct {
     double last_kernel_ms;   /* HIP-event time of the last dominant kernel launch on the index's stream */

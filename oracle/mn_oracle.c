@@ -1150,3 +1150,25 @@ void orc_hnsw_set_entry(orc_index *x, int64_t entry, int max_level) {
     x->entry_id = entry;
     x->max_level = max_level;
 }
+
+int orc_hnsw_load_bulk(orc_index *x, int n, const int64_t *ids, const float *vectors, const int *levels,
+                       const int *deleted) {
+    for (int i = 0; i < n; i++)
+        if (orc_hnsw_load_node(x, ids[i], vectors + (size_t)i * x->dim, levels[i], deleted[i]) != 0)
+            return -1;
+    return 0;
+}
+
+int orc_hnsw_load_links_bulk(orc_index *x, int level, const int *rows, int width) {
+    for (int s = 0; s < x->n_slots; s++) {
+        if (level > x->levels[s])
+            continue;
+        for (int i = 0; i < width; i++) {
+            int t = rows[(size_t)s * width + i];
+            if (t < 0)
+                break;
+            nl_add(x, s, level, t);
+        }
+    }
+    return 0;
+}

@@ -115,6 +115,10 @@ void orc_hnsw_reset_stats(orc_index *idx);
 int orc_hnsw_load_node(orc_index *idx, int64_t id, const float *vector, int level, int deleted);
 int orc_hnsw_load_neighbors(orc_index *idx, int64_t id, int level, const int64_t *nbrs, int n);
 void orc_hnsw_set_entry(orc_index *idx, int64_t entry, int max_level);
+/* bulk variants: nodes in slot order; link rows are slot indices, -1 padded, [n][width] */
+int orc_hnsw_load_bulk(orc_index *idx, int n, const int64_t *ids, const float *vectors, const int *levels,
+                       const int *deleted);
+int orc_hnsw_load_links_bulk(orc_index *idx, int level, const int *rows, int width);
 
 #ifdef __cplusplus
 }

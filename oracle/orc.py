@@ -75,6 +75,8 @@ def lib():
         L.orc_hnsw_load_node.argtypes = [C.c_void_p, C.c_int64, _f32p, C.c_int, C.c_int]
         L.orc_hnsw_load_neighbors.argtypes = [C.c_void_p, C.c_int64, C.c_int, _i64p, C.c_int]
         L.orc_hnsw_set_entry.argtypes = [C.c_void_p, C.c_int64, C.c_int]
+        L.orc_hnsw_load_bulk.argtypes = [C.c_void_p, C.c_int, _i64p, _f32p, _i32p, _i32p]
+        L.orc_hnsw_load_links_bulk.argtypes = [C.c_void_p, C.c_int, _i32p, C.c_int]
         _lib = L
     return _lib
 
@@ -187,6 +189,18 @@ class Oracle(_IndexBase):
 
     def set_entry(self, entry, max_level):
         self.L.orc_hnsw_set_entry(self.h, int(entry), int(max_level))
+
+    def load_from_device(self, g, vectors=None):
+        """Mirror a device index (sqlite_muninn_amd.HnswIndex) through its bulk export."""
+        ids, lv, dl = g.export_nodes()
+        if vectors is None:
+            vectors = g.export_vectors()
+        vectors = np.ascontiguousarray(vectors, np.float32)
+        assert self.L.orc_hnsw_load_bulk(self.h, len(ids), ids, vectors, lv, dl) == 0
+        for l in range(int(lv.max()) + 1 if len(lv) else 0):
+            rows = g.export_links(l)
+            self.L.orc_hnsw_load_links_bulk(self.h, l, rows, rows.shape[1])
+        self.set_entry(g.entry_point, g.max_level)
 
     @property
     def node_count(self):

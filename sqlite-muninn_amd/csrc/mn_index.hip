@@ -476,6 +476,8 @@ static int prepare_search_ws(mn_index *x, int64_t nq, int ef, MnSearchArgs &a) {
 
 static int fetch_counters(mn_index *x) {
     unsigned long long c[4];
+    if (!x->ws_counters.p) // nothing launched yet
+        return 0;
     HIPCHK(hipMemcpyAsync(c, x->ws_counters.p, sizeof(c), hipMemcpyDeviceToHost, x->stream));
     HIPCHK(hipStreamSynchronize(x->stream));
     float ms = 0;
@@ -947,6 +949,51 @@ extern "C" int mn_hnsw_load_neighbors(mn_index *x, int64_t id, int level, const 
 extern "C" int mn_hnsw_set_entry(mn_index *x, int64_t entry, int max_level) {
     x->entry_id = entry;
     x->max_level = max_level;
+    return 0;
+}
+
+// ───────────────────────── bulk export ─────────────────────────
+
+extern "C" int mn_hnsw_slot_count(mn_index *x) { return x->n_slots; }
+
+extern "C" int mn_hnsw_export_nodes(mn_index *x, int64_t *ids, int *levels, int *deleted) {
+    for (int s = 0; s < x->n_slots; s++) {
+        ids[s] = x->ids[s];
+        levels[s] = x->levels[s];
+        deleted[s] = x->deleted[s];
+    }
+    return 0;
+}
+
+extern "C" int mn_hnsw_export_vectors(mn_index *x, float *out) {
+    if (use_device(x))
+        return -1;
+    if (x->n_slots == 0)
+        return 0;
+    HIPCHK(hipStreamSynchronize(x->stream));
+    HIPCHK(hipMemcpy2D(out, (size_t)x->dim * sizeof(float), x->d_vectors.p, (size_t)x->ld * sizeof(float),
+                       (size_t)x->dim * sizeof(float), (size_t)x->n_slots, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int mn_hnsw_export_links(mn_index *x, int level, int *out, int *width) {
+    if (use_device(x))
+        return -1;
+    if (pull_links(x))
+        return -1;
+    const int W = level == 0 ? x->M_max0 : x->M;
+    *width = W;
+    for (int s = 0; s < x->n_slots; s++) {
+        int *dst = out + (size_t)s * W;
+        if (level > x->levels[s]) {
+            for (int i = 0; i < W; i++)
+                dst[i] = -1;
+        } else {
+            int w2;
+            const int *row = h_row(x, s, level, &w2);
+            memcpy(dst, row, (size_t)W * sizeof(int));
+        }
+    }
     return 0;
 }
 

@@ -67,6 +67,10 @@ SYMBOLS = [
     ("mn_hnsw_load_node", C.c_int, [C.c_void_p, C.c_int64, _f32p, C.c_int, C.c_int]),
     ("mn_hnsw_load_neighbors", C.c_int, [C.c_void_p, C.c_int64, C.c_int, _i64p, C.c_int]),
     ("mn_hnsw_set_entry", C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
+    ("mn_hnsw_slot_count", C.c_int, [C.c_void_p]),
+    ("mn_hnsw_export_nodes", C.c_int, [C.c_void_p, _i64p, _i32p, _i32p]),
+    ("mn_hnsw_export_vectors", C.c_int, [C.c_void_p, _f32p]),
+    ("mn_hnsw_export_links", C.c_int, [C.c_void_p, C.c_int, _i32p, C.POINTER(C.c_int)]),
     ("mn_hnsw_last_launch", C.c_int, [C.c_void_p, C.POINTER(LaunchStats)]),
     ("mn_dev_malloc", C.c_void_p, [C.c_void_p, C.c_size_t]),
     ("mn_dev_free", None, [C.c_void_p, C.c_void_p]),
@@ -125,6 +129,7 @@ class HnswIndex:
     def __init__(self, dim, metric="cosine", M=16, ef_construction=200, order=ORDER_SSE, seed=None, device=0):
         self.L = lib()
         self.dim = dim
+        self.M = M
         self.h = self.L.mn_hnsw_create_on(dim, METRIC[metric] if isinstance(metric, str) else metric, M, ef_construction,
                                           device)
         if not self.h:
@@ -234,6 +239,36 @@ class HnswIndex:
                 if self.load_neighbors(int(i), l, buf[:n].copy()) != 0:
                     raise MuninnHipError(_err())
         self.set_entry(other.entry_point, other.max_level)
+
+    # ---- bulk export ----
+    @property
+    def slot_count(self):
+        return self.L.mn_hnsw_slot_count(self.h)
+
+    def export_nodes(self):
+        n = self.slot_count
+        ids = np.empty(n, np.int64)
+        lv = np.empty(n, np.int32)
+        dl = np.empty(n, np.int32)
+        if self.L.mn_hnsw_export_nodes(self.h, ids, lv, dl) != 0:
+            raise MuninnHipError(_err())
+        return ids, lv, dl
+
+    def export_vectors(self):
+        out = np.empty((self.slot_count, self.dim), np.float32)
+        if self.L.mn_hnsw_export_vectors(self.h, out) != 0:
+            raise MuninnHipError(_err())
+        return out
+
+    def export_links(self, level):
+        n = self.slot_count
+        M0 = 2 * self.M if level == 0 else self.M
+        out = np.empty((n, M0), np.int32)
+        w = C.c_int(0)
+        if self.L.mn_hnsw_export_links(self.h, level, out, C.byref(w)) != 0:
+            raise MuninnHipError(_err())
+        assert w.value == M0
+        return out
 
     # ---- measurement ----
     def last_launch(self):
