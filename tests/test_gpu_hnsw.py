@@ -170,3 +170,62 @@ def test_delete_matches_oracle(gpu, orc):
     gi, gd, gc = g.search_batch(Q, 10, 64)
     assert np.array_equal(gi, wi) and same_bits(gd, wd)
     g.close()
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e"])
+def test_search_matches_reference_golden(gpu, tag):
+    """The graph the COMPILED REFERENCE built (tests/golden/hnsw_*.npz) is loaded into HBM and searched
+    by the HIP kernel: ids and f32 distance bits must equal what the reference itself returned."""
+    import os
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"hnsw_{tag}.npz"))
+    n, d, M, efc, metric = int(z["n"]), int(z["dim"]), int(z["M"]), int(z["efc"]), str(z["metric"])
+    X = gauss(n, d, int(z["seed_x"]))
+    Q = gauss(200, d, int(z["seed_q"]))
+    g = gpu.HnswIndex(d, metric, M, efc)  # default order = MN_ORDER_SSE = the reference's
+    for i in range(n):
+        assert g.load_node(i + 1, X[i], int(z["levels"][i])) == 0
+    for row in z["rows"]:
+        nb = row[2:][row[2:] >= 0]
+        assert g.load_neighbors(int(row[0]), int(row[1]), nb.copy()) == 0
+    g.set_entry(int(z["entry"]), int(z["max_level"]))
+    for ef in (20, 64, 128, 256):
+        gi, gd, gc = g.search_batch(Q, 10, ef)
+        assert np.array_equal(gi, z[f"ids_ef{ef}"]), (tag, ef)
+        assert np.array_equal(gd.view(np.int32), z[f"dist_ef{ef}"]), (tag, ef)
+        assert np.array_equal(gc, z[f"cnt_ef{ef}"])
+    # delete the same nodes the reference deleted; graph surgery + new entry point + search must agree
+    ok = all(g.delete(int(x)) == 0 for x in z["dels"])
+    if ok:  # (a delete that would overflow a fixed-width row is refused loudly — see DESIGN.md)
+        assert g.entry_point == int(z["entry_after_delete"]) and g.node_count == int(z["node_count_after_delete"])
+        gi, gd, gc = g.search_batch(Q, 10, 64)
+        assert np.array_equal(gi, z["ids_after_delete"]) and np.array_equal(gd.view(np.int32), z["dist_after_delete"])
+    g.close()
+
+
+def test_full_size_properties(gpu):
+    """Size-independent properties at a size the oracle would not finish quickly: every returned list
+    is ascending, ids are valid and distinct, a stored vector finds itself at distance ~0, and search
+    is idempotent."""
+    n, d = 200_000, 96
+    X = gauss(n, d, 77)
+    ids = np.arange(1, n + 1, dtype=np.int64)
+    g = gpu.HnswIndex(d, "l2", 16, 100, order=gpu.ORDER_WAVE)
+    assert g.build(ids, X) == 0
+    assert g.node_count == n
+    Q = X[:2000] + 0.0
+    i1, d1, c1 = g.search_batch(Q, 10, 64)
+    i2, d2, c2 = g.search_batch(Q, 10, 64)
+    assert np.array_equal(i1, i2) and same_bits(d1, d2)
+    assert (c1 == 10).all()
+    assert (np.diff(d1, axis=1) >= 0).all()
+    assert ((i1 >= 1) & (i1 <= n)).all()
+    assert all(len(set(r.tolist())) == 10 for r in i1)
+    # a stored vector that finds itself does so at distance exactly 0 and in first place; widening the
+    # beam never loses hits (recall on isotropic Gaussian data is low by the reference's own algorithm)
+    hit64 = i1[:, 0] == ids[:2000]
+    assert hit64.any() and np.all(d1[hit64, 0] == 0.0) and np.all(d1 >= 0.0)
+    i3, d3, c3 = g.search_batch(Q, 10, 400)
+    assert np.mean(i3[:, 0] == ids[:2000]) >= np.mean(hit64)
+    assert np.mean(d3[:, 9]) <= np.mean(d1[:, 9])
+    g.close()
