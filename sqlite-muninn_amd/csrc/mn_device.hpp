@@ -93,3 +93,8 @@ struct MnLinkArgs {
     int *newrows;   // [max_tuples][W0]
 };
 void mn_launch_link(const MnDevIndex &ix, const MnLinkArgs &a, int max_tuples, hipStream_t st);
+
+// exact sequential inserts (mn_seq.hip)
+void mn_launch_insert_seq(const MnDevIndex &ix, const int *d_slots, int n, int ef, int *d_state, unsigned *bitmap0,
+                          long long bm0_words, unsigned *bitmap_up, long long bmu_words, uint2 *cand_ovf, int cand_gcap,
+                          uint2 *res_ovf, int res_gcap, unsigned long long *counters, hipStream_t st);

@@ -102,6 +102,7 @@ struct mn_index {
     DevBuf<int> ws_outc, ws_qslots, ws_sel, ws_nsel, ws_upidx;
     DevBuf<int> lk_target, lk_src, lk_counters, lk_count, lk_fill, lk_binoff, lk_touched, lk_bins, lk_newrows;
     DevBuf<unsigned long long> ws_counters;
+    DevBuf<int> ws_state;
     mn_launch_stats last = {0, 0, 0, 0};
 };
 
@@ -432,7 +433,7 @@ extern "C" void mn_hnsw_destroy(mn_index *x) {
     x->ws_outd.release(); x->ws_outi.release(); x->ws_outc.release(); x->ws_qslots.release(); x->ws_sel.release();
     x->ws_nsel.release(); x->ws_upidx.release(); x->lk_target.release(); x->lk_src.release(); x->lk_counters.release();
     x->lk_count.release(); x->lk_fill.release(); x->lk_binoff.release(); x->lk_touched.release(); x->lk_bins.release();
-    x->lk_newrows.release(); x->ws_counters.release();
+    x->lk_newrows.release(); x->ws_counters.release(); x->ws_state.release();
     if (x->ev0) (void)hipEventDestroy(x->ev0);
     if (x->ev1) (void)hipEventDestroy(x->ev1);
     if (x->stream) (void)hipStreamDestroy(x->stream);
@@ -680,6 +681,46 @@ static int run_batch(mn_index *x, const std::vector<int> &slots) {
     return 0;
 }
 
+// the reference's one-at-a-time semantics, all of `slots` in one (chunked) single-wavefront launch
+static int run_sequential(mn_index *x, const std::vector<int> &slots) {
+    hipStream_t st = x->stream;
+    const int n = (int)slots.size();
+    if (n == 0)
+        return 0;
+    MnSearchArgs a;
+    memset(&a, 0, sizeof(a));
+    if (prepare_search_ws(x, 1, x->efc, a))
+        return -1;
+    long long bmu_words = ((int64_t)std::max(1, x->n_pool_rows) + 31) / 32;
+    if (x->ws_bmu.reserve((size_t)bmu_words, false, st)) return -1;
+    if (x->ws_qslots.reserve((size_t)n, false, st)) return -1;
+    if (x->ws_state.reserve(2, false, st)) return -1;
+    int state[2] = {ht_find(x, x->entry_id), x->max_level};
+    HIPCHK(hipMemcpyAsync(x->ws_qslots.p, slots.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(x->ws_state.p, state, sizeof(state), hipMemcpyHostToDevice, st));
+    MnDevIndex v = dev_view(x);
+    HIPCHK(hipEventRecord(x->ev0, st));
+    const int chunk = 1024; // keeps any one launch to about a second
+    for (int pos = 0; pos < n; pos += chunk) {
+        int m = std::min(chunk, n - pos);
+        mn_launch_insert_seq(v, x->ws_qslots.p + pos, m, x->efc, x->ws_state.p, a.bitmap0, a.bm0_words, x->ws_bmu.p,
+                             bmu_words, a.cand_ovf, a.cand_gcap, a.res_ovf, a.res_gcap, a.counters, st);
+    }
+    HIPCHK(hipEventRecord(x->ev1, st));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(state, x->ws_state.p, sizeof(state), hipMemcpyDeviceToHost, st));
+    if (fetch_counters(x))
+        return -1;
+    if (x->last.last_n_overflow) {
+        set_err("mn_hnsw_insert: heap workspace exceeded");
+        return -1;
+    }
+    x->host_links_valid = false;
+    x->entry_id = x->ids[state[0]];
+    x->max_level = state[1];
+    return 0;
+}
+
 static int insert_impl(mn_index *x, const int64_t *ids, const float *vectors, int64_t n, int mode) {
     if (use_device(x))
         return -1;
@@ -721,15 +762,9 @@ static int insert_impl(mn_index *x, const int64_t *ids, const float *vectors, in
         x->max_level = x->levels[slots[0]];
         pos = 1;
     }
-    if (mode == MN_BUILD_SEQUENTIAL) {
-        for (; pos < (size_t)n; pos++) {
-            std::vector<int> one(1, slots[pos]);
-            if (run_batch(x, one))
-                return -1;
-        }
-        return 0;
-    }
     std::vector<int> rest(slots.begin() + pos, slots.end());
+    if (mode == MN_BUILD_SEQUENTIAL)
+        return run_sequential(x, rest);
     return run_batch(x, rest);
 }
 

@@ -140,276 +140,7 @@ void mn_launch_dist_batch(int metric, int order, const float *d_query, const flo
 #undef MN_DB
 }
 
-// ───────────────────────── wave-uniform binary heap (src/priority_queue.c) ─────────────────────────
-// Item = (distance bits, slot).  1-based; index i < lcap lives in LDS, the rest in global memory
-// (agent-scope relaxed atomics there: L1 is bypassed so lanes of the wave see each other's stores).
-
-struct WHeap {
-    uint2 *l;
-    unsigned long long *g;
-    int lcap, gcap;
-    int size;
-    int ovf;
-};
-
-DEVI uint2 hget(const WHeap &h, int i) {
-    if (i < h.lcap)
-        return h.l[i];
-    unsigned long long v = __hip_atomic_load(&h.g[i - h.lcap], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return make_uint2((unsigned)(v & 0xffffffffull), (unsigned)(v >> 32));
-}
-// executed by exactly the lanes that should write
-DEVI void hset(const WHeap &h, int i, uint2 v) {
-    if (i < h.lcap)
-        h.l[i] = v;
-    else
-        __hip_atomic_store(&h.g[i - h.lcap], (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// pq_push + sift_up (src/priority_queue.c:18-26,56-70).  The new item climbs while its parent is
-// strictly greater; lane j inspects ancestor j, one ballot finds where it stops.
-DEVI void heap_push(WHeap &h, int slot, float d, int lane) {
-    if (h.size + 1 >= h.lcap + h.gcap) {
-        h.ovf = 1;
-        return;
-    }
-    h.size++;
-    const int idx = h.size;
-    const int depth = 31 - __clz(idx);
-    const bool anc = lane >= 1 && lane <= depth;
-    const int p = anc ? (idx >> lane) : idx;
-    const uint2 x = make_uint2(f2u(d), (unsigned)slot);
-    uint2 it = x;
-    if (anc)
-        it = hget(h, p);
-    unsigned long long stopm = __ballot(anc && (u2f(it.x) <= d));
-    const int stop = stopm ? (__ffsll((long long)stopm) - 1) : depth + 1;
-    if (lane >= 1 && lane < stop)
-        hset(h, idx >> (lane - 1), it);
-    if (lane == 0)
-        hset(h, idx >> (stop - 1), x);
-    __builtin_amdgcn_wave_barrier();
-}
-
-// pq_pop + sift_down (src/priority_queue.c:28-42,72-80): strict <, left child first.  Wave-uniform.
-DEVI uint2 heap_pop(WHeap &h, int lane) {
-    uint2 top = hget(h, 1);
-    top.x = rflu(top.x);
-    top.y = rflu(top.y);
-    uint2 x = hget(h, h.size);
-    x.x = rflu(x.x);
-    x.y = rflu(x.y);
-    h.size--;
-    if (h.size > 0) {
-        int idx = 1;
-        const float xd = u2f(x.x);
-        for (;;) {
-            int left = 2 * idx;
-            if (left > h.size)
-                break;
-            uint2 L, Rt;
-            if (left + 1 < h.lcap) { // both children in LDS, 16-byte aligned pair
-                uint4 c = *reinterpret_cast<const uint4 *>(&h.l[left]);
-                L = make_uint2(c.x, c.y);
-                Rt = make_uint2(c.z, c.w);
-            } else {
-                L = hget(h, left);
-                Rt = (left + 1 <= h.size) ? hget(h, left + 1) : L;
-            }
-            L.x = rflu(L.x);
-            L.y = rflu(L.y);
-            Rt.x = rflu(Rt.x);
-            Rt.y = rflu(Rt.y);
-            int smallest = idx;
-            float sd = xd;
-            uint2 sv = x;
-            if (u2f(L.x) < sd) {
-                smallest = left;
-                sd = u2f(L.x);
-                sv = L;
-            }
-            if (left + 1 <= h.size && u2f(Rt.x) < sd) {
-                smallest = left + 1;
-                sv = Rt;
-            }
-            if (smallest == idx)
-                break;
-            if (lane == 0)
-                hset(h, idx, sv);
-            idx = smallest;
-        }
-        if (lane == 0)
-            hset(h, idx, x);
-    }
-    __builtin_amdgcn_wave_barrier();
-    return top;
-}
-
-// ───────────────────────── beam search ─────────────────────────
-
-struct WaveCtx {
-    const float *q;  // LDS query, zero padded to ld
-    float qnorm;
-    int *scratch;    // LDS, 64 ints
-    unsigned long long n_dist, n_exp;
-};
-
-DEVI const int *link_row(const MnDevIndex &ix, int node, int level, int &W) {
-    if (level == 0) {
-        W = ix.W0;
-        return ix.links0 + (size_t)node * ix.W0;
-    }
-    W = ix.WU;
-    return ix.links_up + ((size_t)ix.up_off[node] + (level - 1)) * ix.WU;
-}
-
-// src/hnsw_algo.c:257-282 incl. its quirk: after `current` is re-pointed the for-loop carries on at
-// index i+1 of the NEW node's list.
-template <int ORDER, int NCH>
-DEVI int greedy_layer(const MnDevIndex &ix, WaveCtx &w, int entry, int level, int lane) {
-    int cur = entry;
-    float cur_d = rows_distance<ORDER, NCH>(ix, w.q, w.qnorm, cur, 1, lane);
-    cur_d = __shfl(cur_d, 0);
-    w.n_dist += 1;
-    int changed = 1;
-    int guard = 0;
-    while (changed && guard < (1 << 20)) {
-        changed = 0;
-        int i0 = 0;
-        for (;;) {
-            guard++;
-            int W;
-            const int *row = link_row(ix, cur, level, W);
-            w.n_exp++;
-            int nb = (lane < W) ? row[lane] : -1;
-            bool valid = lane >= i0 && nb >= 0 && !ix.deleted[nb >= 0 ? nb : 0];
-            unsigned long long m = __ballot(valid);
-            int n = __popcll(m);
-            if (n == 0)
-                break;
-            int rank = __popcll(m & ((1ull << lane) - 1ull));
-            __builtin_amdgcn_wave_barrier();
-            if (valid)
-                w.scratch[rank] = nb;
-            __builtin_amdgcn_wave_barrier();
-            int myslot = lane < n ? w.scratch[lane] : 0;
-            float d = rows_distance<ORDER, NCH>(ix, w.q, w.qnorm, myslot, n, lane);
-            w.n_dist += n;
-            unsigned long long better = __ballot(lane < n && d < cur_d);
-            if (!better)
-                break;
-            int c = __ffsll((long long)better) - 1; // first compact index that improves
-            cur_d = __shfl(d, c);
-            cur = __shfl(myslot, c);
-            // list position of compact index c = position of the (c+1)-th set bit of m
-            int pos_of_me = lane; // lanes with valid hold their own list position
-            __builtin_amdgcn_wave_barrier();
-            if (valid)
-                w.scratch[rank] = pos_of_me;
-            __builtin_amdgcn_wave_barrier();
-            i0 = w.scratch[c] + 1;
-            i0 = rfl(i0);
-            cur = rfl(cur);
-            changed = 1;
-        }
-    }
-    return cur;
-}
-
-// src/hnsw_algo.c:347-448.  Results are left in the result heap; the caller drains it.
-template <int ORDER, int NCH>
-DEVI void beam_layer(const MnDevIndex &ix, WaveCtx &w, WHeap &cand, WHeap &res, unsigned *bitmap, int entry, int level,
-                     int ef, int lane) {
-    cand.size = 0;
-    res.size = 0;
-    if (!ix.deleted[entry]) { // :360-366
-        float d = rows_distance<ORDER, NCH>(ix, w.q, w.qnorm, entry, 1, lane);
-        d = __shfl(d, 0);
-        w.n_dist += 1;
-        heap_push(cand, entry, d, lane);
-        heap_push(res, entry, -d, lane);
-        if (lane == 0) {
-            int vi = level == 0 ? entry : ix.up_off[entry];
-            atomicOr(&bitmap[vi >> 5], 1u << (vi & 31));
-        }
-    }
-    int patience_max = ef / 4; // :372-375
-    if (patience_max < 10)
-        patience_max = 10;
-    int stale = 0;
-    int guard = 0;
-    while (cand.size > 0 && guard < (1 << 24)) {
-        guard++;
-        uint2 c = heap_pop(cand, lane);
-        const float cd = u2f(c.x);
-        if (res.size >= ef) { // :382-386
-            float worst = -u2f(rflu(hget(res, 1).x));
-            if (cd > worst)
-                break;
-        }
-        if (stale >= patience_max && res.size >= ef) // :391
-            break;
-        const int node = (int)c.y;
-        int W;
-        const int *row = link_row(ix, node, level, W);
-        w.n_exp++;
-        int nb = (lane < W) ? row[lane] : -1;
-        bool todo = false;
-        if (nb >= 0) { // :403-409 — mark visited first, then drop deleted
-            int vi = level == 0 ? nb : ix.up_off[nb];
-            unsigned bit = 1u << (vi & 31);
-            unsigned old = atomicOr(&bitmap[vi >> 5], bit);
-            todo = !(old & bit) && !ix.deleted[nb];
-        }
-        unsigned long long m = __ballot(todo);
-        int n = __popcll(m);
-        int improved = 0;
-        if (n > 0) {
-            int rank = __popcll(m & ((1ull << lane) - 1ull));
-            __builtin_amdgcn_wave_barrier();
-            if (todo)
-                w.scratch[rank] = nb;
-            __builtin_amdgcn_wave_barrier();
-            int myslot = lane < n ? w.scratch[lane] : 0;
-            float d = rows_distance<ORDER, NCH>(ix, w.q, w.qnorm, myslot, n, lane);
-            w.n_dist += n;
-            // :413-425, in list order.  Once the result set is full an element can only be accepted
-            // if it beats the worst AT THAT MOMENT, which never exceeds the worst now: pre-filter.
-            unsigned long long am;
-            if (res.size >= ef) {
-                float worst0 = -u2f(rflu(hget(res, 1).x));
-                am = __ballot(lane < n && d < worst0);
-            } else {
-                am = __ballot(lane < n);
-            }
-            while (am) {
-                int i = __ffsll((long long)am) - 1;
-                am &= am - 1;
-                float di = __shfl(d, i);
-                int si = __shfl(myslot, i);
-                di = u2f(rflu(f2u(di)));
-                si = rfl(si);
-                if (res.size < ef) {
-                    heap_push(cand, si, di, lane);
-                    heap_push(res, si, -di, lane);
-                    improved = 1;
-                } else {
-                    float worst = -u2f(rflu(hget(res, 1).x));
-                    if (di < worst) {
-                        heap_push(cand, si, di, lane);
-                        heap_pop(res, lane);
-                        heap_push(res, si, -di, lane);
-                        improved = 1;
-                    }
-                }
-            }
-        }
-        stale = improved ? 0 : stale + 1; // :428-432
-    }
-    if (guard >= (1 << 24))
-        cand.ovf = 1;
-}
+#include "mn_beam.hpp"
 
 template <int ORDER, int NCH, bool BUILD>
 __global__ void __launch_bounds__(64) k_beam(MnDevIndex ix, MnSearchArgs a) {

@@ -1,0 +1,272 @@
+// mn_seq.hip — hnsw_insert with the reference's exact sequential semantics (src/hnsw_algo.c:520-666)
+// on the device: k_insert_seq, ONE wavefront walking a list of already-uploaded nodes in order.
+//
+// Every insert sees the graph left by all earlier ones (links are updated in place between
+// searches), so the resulting graph is bit-identical to calling the reference's hnsw_insert in a
+// loop — including the MN-RU tie-break, which here reads the LIVE neighbour lists exactly as
+// count_mutual_neighbors does (:460-475).  The 64 lanes parallelise inside one insert: ≤64
+// neighbour distances per expansion / prune, heap sifts, the row scans.  Latency-bound by design
+// (≈1 ms per insert); the batch-synchronous schedule (mn_build.hip) is the throughput path.
+#include "mn_beam.hpp"
+
+struct MnSeqArgs {
+    const int *slots; // nodes to insert, in order
+    int n;
+    int ef;
+    int *state; // [0] entry slot, [1] max level — read at start, written back at the end
+    unsigned *bitmap0;
+    long long bm0_words;
+    unsigned *bitmap_up;
+    long long bmu_words;
+    uint2 *cand_ovf;
+    int cand_gcap;
+    uint2 *res_ovf;
+    int res_gcap;
+    unsigned long long *counters;
+};
+
+DEVI int *seq_row(const MnDevIndex &ix, int node, int level) {
+    if (level == 0)
+        return ix.links0 + (size_t)node * ix.W0;
+    return ix.links_up + ((size_t)ix.up_off[node] + (level - 1)) * ix.WU;
+}
+
+// |list ∩ N(nn)| against nn's live row (src/hnsw_algo.c:460-475)
+DEVI int seq_mutual(const MnDevIndex &ix, const int *list, int nc, int nn, int level, int lane) {
+    if (ix.levels[nn] < level)
+        return 0;
+    const int W = level == 0 ? ix.W0 : ix.WU;
+    const int *row = seq_row(ix, nn, level);
+    int mine = lane < W ? ld_link<true>(row + lane) : -1;
+    int c = 0;
+    for (int i = 0; i < nc; i++) {
+        int a = list[i];
+        if (__ballot(mine >= 0 && mine == a))
+            c++;
+    }
+    return c;
+}
+
+template <int ORDER, int NCH>
+__global__ void __launch_bounds__(64) k_insert_seq(MnDevIndex ix, MnSeqArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    uint2 *cand_l = reinterpret_cast<uint2 *>(smem);
+    uint2 *res_l = cand_l + MN_CAND_LDS;
+    int *scratch = reinterpret_cast<int *>(res_l + MN_RES_LDS); // [64]
+    int *selbuf = scratch + 64;                                 // [64]
+    int *list = selbuf + 64;                                    // [64]
+    float *nd = reinterpret_cast<float *>(list + 64);           // [64]
+    int *mn = reinterpret_cast<int *>(nd + 64);                 // [64]
+    float *q = reinterpret_cast<float *>(mn + 64);              // [ld]
+    float *tv = q + ix.ld;                                      // [ld]
+
+    WaveCtx w;
+    w.q = q;
+    w.scratch = scratch;
+    w.n_dist = 0;
+    w.n_exp = 0;
+    WHeap cand, res;
+    cand.l = cand_l;
+    cand.lcap = MN_CAND_LDS;
+    cand.g = reinterpret_cast<unsigned long long *>(a.cand_ovf);
+    cand.gcap = a.cand_gcap;
+    cand.size = 0;
+    cand.ovf = 0;
+    res.l = res_l;
+    res.lcap = MN_RES_LDS;
+    res.g = reinterpret_cast<unsigned long long *>(a.res_ovf);
+    res.gcap = a.res_gcap;
+    res.size = 0;
+    res.ovf = 0;
+
+    int entry = a.state[0];
+    int maxl = a.state[1];
+
+    for (int it = 0; it < a.n; it++) {
+        const int s = a.slots[it];
+        const int level = ix.levels[s];
+        const float *sv = ix.vectors + (size_t)s * ix.ld;
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < ix.ld; i += 64)
+            q[i] = sv[i];
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        w.qnorm = ix.metric == 1 ? ix.norms[s] : 0.0f;
+
+        int cur = entry;
+        for (int l = maxl; l > level; l--) // :553-555
+            cur = greedy_layer<ORDER, NCH, true>(ix, w, cur, l, lane);
+
+        const int start = level < maxl ? level : maxl;
+        for (int l = start; l >= 0; l--) { // :572-653
+            const int W = l == 0 ? ix.W0 : ix.WU;
+            unsigned *bm = l == 0 ? a.bitmap0 : a.bitmap_up;
+            const long long words = l == 0 ? a.bm0_words : a.bmu_words;
+            for (long long i = lane; i < words; i += 64)
+                bm[i] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_s_waitcnt(0);
+
+            beam_layer<ORDER, NCH, true>(ix, w, cand, res, bm, cur, l, a.ef, lane);
+            const int count = res.size;
+            const int nsel = count < W ? count : W; // :511
+            int first = cur;
+            for (int i = count - 1; i >= 0; i--) {
+                uint2 itx = heap_pop(res, lane);
+                if (i < nsel && lane == 0)
+                    selbuf[i] = (int)itx.y;
+                if (i == 0)
+                    first = (int)itx.y;
+            }
+            __builtin_amdgcn_wave_barrier();
+            int *srow = seq_row(ix, s, l);
+            for (int i = 0; i < nsel; i++) { // :582-648
+                const int t = selbuf[i];
+                if (lane == 0)
+                    st_link(srow + i, t); // node_add_neighbor(new_node, l, selected[i])
+                if (ix.levels[t] < l)      // :590
+                    continue;
+                int *trow = seq_row(ix, t, l);
+                int v = lane < W ? ld_link<true>(trow + lane) : -1;
+                const int cnt = __popcll(__ballot(v >= 0));
+                if (__ballot(v == s)) // already a neighbour (:147-150)
+                    continue;
+                if (cnt < W) {
+                    if (lane == 0)
+                        st_link(trow + cnt, s);
+                    continue;
+                }
+                // ── over-full: MN-RU prune of t's list (:601-646) ──
+                const int nc = W + 1;
+                __builtin_amdgcn_wave_barrier();
+                if (lane < W)
+                    list[lane] = v;
+                if (lane == 0)
+                    list[W] = s;
+                const float *tsrc = ix.vectors + (size_t)t * ix.ld;
+                for (int e = lane; e < ix.ld; e += 64)
+                    tv[e] = tsrc[e];
+                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_wave_barrier();
+                const float tnorm = ix.metric == 1 ? ix.norms[t] : 0.0f;
+                int myslot = lane < nc ? list[lane] : 0;
+                const bool dead = lane < nc && ix.deleted[myslot];
+                float d = rows_distance<ORDER, NCH>(ix, tv, tnorm, myslot, nc, lane);
+                w.n_dist += nc;
+                if (dead)
+                    d = 1e30f;
+                bool clash = false;
+                for (int x = 0; x < nc; x++) {
+                    float o = __shfl(d, x);
+                    if (lane < nc && x != lane && !(o < d) && !(d < o))
+                        clash = true;
+                }
+                if (!__ballot(clash)) {
+                    int rank = 0;
+                    for (int x = 0; x < nc; x++) {
+                        float o = __shfl(d, x);
+                        if (o < d)
+                            rank++;
+                    }
+                    if (lane < nc && rank < W)
+                        st_link(trow + rank, myslot);
+                } else {
+                    nd[lane] = d;
+                    int cm = 0;
+                    for (int j = 0; j < nc; j++) {
+                        int nn = list[j];
+                        int c = ix.deleted[nn] ? -1 : seq_mutual(ix, list, nc, nn, l, lane);
+                        if (lane == j)
+                            cm = c;
+                    }
+                    mn[lane] = cm;
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) {
+                        for (int x = 0; x < W && x < nc; x++) { // :620-639
+                            int bi = x;
+                            for (int y = x + 1; y < nc; y++)
+                                if (nd[y] < nd[bi] || (nd[y] == nd[bi] && mn[y] > mn[bi]))
+                                    bi = y;
+                            if (bi != x) {
+                                float td = nd[x];
+                                nd[x] = nd[bi];
+                                nd[bi] = td;
+                                int tm = mn[x];
+                                mn[x] = mn[bi];
+                                mn[bi] = tm;
+                                int ti = list[x];
+                                list[x] = list[bi];
+                                list[bi] = ti;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < W)
+                        st_link(trow + lane, list[lane]);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (count > 0) // :651-652
+                cur = first;
+        }
+        if (level > maxl) { // :660-663
+            entry = s;
+            maxl = level;
+        }
+    }
+    if (lane == 0) {
+        a.state[0] = entry;
+        a.state[1] = maxl;
+        atomicAdd(&a.counters[0], w.n_dist);
+        atomicAdd(&a.counters[1], w.n_exp);
+        if (cand.ovf || res.ovf)
+            atomicAdd(&a.counters[2], 1ull);
+    }
+}
+
+static int pick_nch_s(int ld) {
+    int need = (ld + 255) / 256;
+    if (need <= 1) return 1;
+    if (need <= 2) return 2;
+    if (need <= 3) return 3;
+    if (need <= 4) return 4;
+    if (need <= 6) return 6;
+    if (need <= 8) return 8;
+    return 0;
+}
+
+void mn_launch_insert_seq(const MnDevIndex &ix, const int *d_slots, int n, int ef, int *d_state, unsigned *bitmap0,
+                          long long bm0_words, unsigned *bitmap_up, long long bmu_words, uint2 *cand_ovf, int cand_gcap,
+                          uint2 *res_ovf, int res_gcap, unsigned long long *counters, hipStream_t st) {
+    MnSeqArgs a;
+    a.slots = d_slots;
+    a.n = n;
+    a.ef = ef;
+    a.state = d_state;
+    a.bitmap0 = bitmap0;
+    a.bm0_words = bm0_words;
+    a.bitmap_up = bitmap_up;
+    a.bmu_words = bmu_words;
+    a.cand_ovf = cand_ovf;
+    a.cand_gcap = cand_gcap;
+    a.res_ovf = res_ovf;
+    a.res_gcap = res_gcap;
+    a.counters = counters;
+    size_t lds = (size_t)(MN_CAND_LDS + MN_RES_LDS) * sizeof(uint2) + 5 * 64 * sizeof(int) + 2 * (size_t)ix.ld * sizeof(float);
+#define MN_SQ(O, N) hipLaunchKernelGGL((k_insert_seq<O, N>), dim3(1), dim3(64), lds, st, ix, a)
+    if (ix.order == MN_ORDER_SSE_V) {
+        MN_SQ(MN_ORDER_SSE_V, 0);
+        return;
+    }
+    switch (pick_nch_s(ix.ld)) {
+    case 1: MN_SQ(MN_ORDER_WAVE_V, 1); break;
+    case 2: MN_SQ(MN_ORDER_WAVE_V, 2); break;
+    case 3: MN_SQ(MN_ORDER_WAVE_V, 3); break;
+    case 4: MN_SQ(MN_ORDER_WAVE_V, 4); break;
+    case 6: MN_SQ(MN_ORDER_WAVE_V, 6); break;
+    case 8: MN_SQ(MN_ORDER_WAVE_V, 8); break;
+    default: MN_SQ(MN_ORDER_WAVE_V, 0); break;
+    }
+#undef MN_SQ
+}

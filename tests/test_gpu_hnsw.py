@@ -229,3 +229,50 @@ def test_full_size_properties(gpu):
     assert np.mean(i3[:, 0] == ids[:2000]) >= np.mean(hit64)
     assert np.mean(d3[:, 9]) <= np.mean(d1[:, 9])
     g.close()
+
+
+def _golden_rows(g, ids, width):
+    rows = []
+    for i in ids:
+        for l in range(g.node_level(int(i)) + 1):
+            nb = g.neighbors(int(i), l)
+            row = np.full(width + 2, -1, np.int64)
+            row[0], row[1] = i, l
+            row[2:2 + len(nb)] = nb
+            rows.append(row)
+    return np.array(rows, np.int64)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e"])
+def test_sequential_insert_reproduces_reference_graph(gpu, tag):
+    """hnsw_insert semantics on the device (k_insert_seq): levels, every neighbour list in order, entry
+    point and max level equal what the compiled reference built from the same vectors."""
+    import os
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"hnsw_{tag}.npz"))
+    n, d, M, efc, metric = int(z["n"]), int(z["dim"]), int(z["M"]), int(z["efc"]), str(z["metric"])
+    X = gauss(n, d, int(z["seed_x"]))
+    ids = np.arange(1, n + 1, dtype=np.int64)
+    g = gpu.HnswIndex(d, metric, M, efc)
+    # mix of the single-insert entry point and the multi-insert call
+    for i in range(5):
+        assert g.insert(int(ids[i]), X[i]) == 0
+    assert g.insert_batch(ids[5:], X[5:], gpu.BUILD_SEQUENTIAL) == 0
+    assert np.array_equal(np.array([g.node_level(int(i)) for i in ids], np.int8), z["levels"])
+    assert np.array_equal(_golden_rows(g, ids, 2 * M), z["rows"])
+    assert g.entry_point == int(z["entry"]) and g.max_level == int(z["max_level"])
+    g.close()
+
+
+def test_sequential_insert_with_ties_matches_oracle(gpu, orc):
+    dim, n = 8, 900
+    base = gauss(30, dim, 41)
+    X = base[np.random.default_rng(42).integers(0, 30, n)]
+    ids = np.arange(1, n + 1, dtype=np.int64)
+    for metric in ("l2", "cosine", "inner_product"):
+        o = orc.Oracle(dim, metric, 4, 40)
+        o.insert_many(ids, X)
+        g = gpu.HnswIndex(dim, metric, 4, 40)
+        assert g.insert_batch(ids, X, gpu.BUILD_SEQUENTIAL) == 0
+        assert g.graph(ids) == o.graph(ids), metric
+        g.close()
