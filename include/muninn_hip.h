@@ -124,6 +124,13 @@ int mn_hnsw_export_vectors(mn_index *idx, float *out);                          
  * rows of nodes whose level < `level` are all -1.  *width = 2M at level 0, M above. */
 int mn_hnsw_export_links(mn_index *idx, int level, int *out, int *width);
 
+/* All edges of the given nodes with the distance persist_node stores next to each one
+ * (src/hnsw_vtab.c:268-279: dist_func(node, neighbour), 0.0 when the neighbour is soft-deleted).
+ * Fills parallel arrays (source id, target id, level, distance) up to `cap`; returns the number of
+ * edges (may exceed cap → call again with more room), -1 on error / unknown id. */
+int64_t mn_hnsw_edges_of(mn_index *idx, const int64_t *ids, int n, int64_t *out_src, int64_t *out_dst, int *out_level,
+                         float *out_dist, int64_t cap);
+
 /* ---- measurement hooks (bench.py) ---- */
 typedef struct {
     double last_kernel_ms;   /* HIP-event time of the last dominant kernel launch on the index's stream */

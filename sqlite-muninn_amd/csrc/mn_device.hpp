@@ -98,3 +98,7 @@ void mn_launch_link(const MnDevIndex &ix, const MnLinkArgs &a, int max_tuples, h
 void mn_launch_insert_seq(const MnDevIndex &ix, const int *d_slots, int n, int ef, int *d_state, unsigned *bitmap0,
                           long long bm0_words, unsigned *bitmap_up, long long bmu_words, uint2 *cand_ovf, int cand_gcap,
                           uint2 *res_ovf, int res_gcap, unsigned long long *counters, hipStream_t st);
+
+// rows[r] = (slot, level): writes the row's neighbour slots and dist(slot, neighbour) (mn_kernels.hip)
+void mn_launch_edge_rows(const MnDevIndex &ix, const int *d_row_slot, const int *d_row_level, int n_rows, int *d_out_nbr,
+                         float *d_out_dist, hipStream_t st);

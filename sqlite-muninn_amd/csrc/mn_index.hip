@@ -103,6 +103,8 @@ struct mn_index {
     DevBuf<int> lk_target, lk_src, lk_counters, lk_count, lk_fill, lk_binoff, lk_touched, lk_bins, lk_newrows;
     DevBuf<unsigned long long> ws_counters;
     DevBuf<int> ws_state;
+    DevBuf<int> er_slot, er_level, er_nbr;
+    DevBuf<float> er_dist;
     mn_launch_stats last = {0, 0, 0, 0};
 };
 
@@ -434,6 +436,7 @@ extern "C" void mn_hnsw_destroy(mn_index *x) {
     x->ws_nsel.release(); x->ws_upidx.release(); x->lk_target.release(); x->lk_src.release(); x->lk_counters.release();
     x->lk_count.release(); x->lk_fill.release(); x->lk_binoff.release(); x->lk_touched.release(); x->lk_bins.release();
     x->lk_newrows.release(); x->ws_counters.release(); x->ws_state.release();
+    x->er_slot.release(); x->er_level.release(); x->er_nbr.release(); x->er_dist.release();
     if (x->ev0) (void)hipEventDestroy(x->ev0);
     if (x->ev1) (void)hipEventDestroy(x->ev1);
     if (x->stream) (void)hipStreamDestroy(x->stream);
@@ -931,10 +934,18 @@ extern "C" int mn_hnsw_neighbors(mn_index *x, int64_t id, int level, int64_t *ou
     int s = ht_find(x, id);
     if (s < 0 || level > x->levels[s])
         return -1;
-    if (pull_links(x))
-        return -1;
-    int W;
-    int *row = h_row(x, s, level, &W);
+    int W = level == 0 ? x->M_max0 : x->M;
+    int tmp[64];
+    const int *row;
+    if (x->host_links_valid) {
+        row = h_row(x, s, level, &W);
+    } else { // one row straight from HBM: do not pull the whole graph for a point read
+        const int *src = level == 0 ? x->d_links0.p + (size_t)s * W
+                                    : x->d_links_up.p + ((size_t)x->up_off[s] + (level - 1)) * W;
+        HIPCHK(hipStreamSynchronize(x->stream));
+        HIPCHK(hipMemcpy(tmp, src, (size_t)W * sizeof(int), hipMemcpyDeviceToHost));
+        row = tmp;
+    }
     int n = h_row_count(row, W);
     for (int i = 0; i < n && i < cap; i++)
         out[i] = x->ids[row[i]];
@@ -1030,6 +1041,59 @@ extern "C" int mn_hnsw_export_links(mn_index *x, int level, int *out, int *width
         }
     }
     return 0;
+}
+
+extern "C" int64_t mn_hnsw_edges_of(mn_index *x, const int64_t *ids, int n, int64_t *out_src, int64_t *out_dst,
+                                    int *out_level, float *out_dist, int64_t cap) {
+    if (use_device(x))
+        return -1;
+    if (push_links(x) || sync_meta(x))
+        return -1;
+    std::vector<int> rs, rl;
+    for (int i = 0; i < n; i++) {
+        int s = ht_find(x, ids[i]);
+        if (s < 0) {
+            set_err("mn_hnsw_edges_of: unknown id %lld", (long long)ids[i]);
+            return -1;
+        }
+        for (int l = 0; l <= x->levels[s]; l++) {
+            rs.push_back(s);
+            rl.push_back(l);
+        }
+    }
+    const int R = (int)rs.size();
+    if (R == 0)
+        return 0;
+    hipStream_t st = x->stream;
+    const int W0 = x->M_max0;
+    if (x->er_slot.reserve((size_t)R, false, st)) return -1;
+    if (x->er_level.reserve((size_t)R, false, st)) return -1;
+    if (x->er_nbr.reserve((size_t)R * W0, false, st)) return -1;
+    if (x->er_dist.reserve((size_t)R * W0, false, st)) return -1;
+    HIPCHK(hipMemcpyAsync(x->er_slot.p, rs.data(), (size_t)R * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(x->er_level.p, rl.data(), (size_t)R * sizeof(int), hipMemcpyHostToDevice, st));
+    mn_launch_edge_rows(dev_view(x), x->er_slot.p, x->er_level.p, R, x->er_nbr.p, x->er_dist.p, st);
+    HIPCHK(hipGetLastError());
+    std::vector<int> nbr((size_t)R * W0);
+    std::vector<float> dist((size_t)R * W0);
+    HIPCHK(hipMemcpyAsync(nbr.data(), x->er_nbr.p, nbr.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(dist.data(), x->er_dist.p, dist.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    int64_t ne = 0;
+    for (int r = 0; r < R; r++)
+        for (int i = 0; i < W0; i++) {
+            int t = nbr[(size_t)r * W0 + i];
+            if (t < 0)
+                break;
+            if (ne < cap) {
+                out_src[ne] = x->ids[rs[r]];
+                out_dst[ne] = x->ids[t];
+                out_level[ne] = rl[r];
+                out_dist[ne] = dist[(size_t)r * W0 + i];
+            }
+            ne++;
+        }
+    return ne;
 }
 
 // ───────────────────────── measurement hooks ─────────────────────────

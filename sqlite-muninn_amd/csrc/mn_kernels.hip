@@ -284,3 +284,61 @@ int mn_launch_search(const MnDevIndex &ix, const MnSearchArgs &a, bool build, hi
     }
     return 0;
 }
+
+// ───────────────────────── k_edge_rows ─────────────────────────
+// persist_node's per-edge distances (src/hnsw_vtab.c:268-279) for a list of (node, level) rows.
+
+template <int ORDER, int NCH>
+__global__ void __launch_bounds__(64)
+    k_edge_rows(MnDevIndex ix, const int *row_slot, const int *row_level, int n_rows, int *out_nbr, float *out_dist) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int r = blockIdx.x;
+    if (r >= n_rows)
+        return;
+    float *q = reinterpret_cast<float *>(smem);
+    const int s = row_slot[r], level = row_level[r];
+    const float *sv = ix.vectors + (size_t)s * ix.ld;
+    for (int i = lane; i < ix.ld; i += 64)
+        q[i] = sv[i];
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    int W;
+    const int *row = link_row(ix, s, level, W);
+    int nb = lane < W ? row[lane] : -1;
+    int n = __popcll(__ballot(nb >= 0));
+    float d = 0.0f;
+    if (n > 0) {
+        int myslot = lane < n ? nb : 0;
+        d = rows_distance<ORDER, NCH>(ix, q, ix.metric == 1 ? ix.norms[s] : 0.0f, myslot, n, lane);
+        if (lane < n && ix.deleted[myslot])
+            d = 0.0f;
+    }
+    if (lane < ix.W0) {
+        out_nbr[(size_t)r * ix.W0 + lane] = lane < W ? nb : -1;
+        out_dist[(size_t)r * ix.W0 + lane] = d;
+    }
+}
+
+void mn_launch_edge_rows(const MnDevIndex &ix, const int *d_row_slot, const int *d_row_level, int n_rows, int *d_out_nbr,
+                         float *d_out_dist, hipStream_t st) {
+    if (n_rows <= 0)
+        return;
+    size_t lds = (size_t)ix.ld * sizeof(float);
+    dim3 grid(n_rows), block(64);
+#define MN_ER(O, N) hipLaunchKernelGGL((k_edge_rows<O, N>), grid, block, lds, st, ix, d_row_slot, d_row_level, n_rows, d_out_nbr, d_out_dist)
+    if (ix.order == MN_ORDER_SSE_V) {
+        MN_ER(MN_ORDER_SSE_V, 0);
+        return;
+    }
+    switch (pick_nch(ix.ld)) {
+    case 1: MN_ER(MN_ORDER_WAVE_V, 1); break;
+    case 2: MN_ER(MN_ORDER_WAVE_V, 2); break;
+    case 3: MN_ER(MN_ORDER_WAVE_V, 3); break;
+    case 4: MN_ER(MN_ORDER_WAVE_V, 4); break;
+    case 6: MN_ER(MN_ORDER_WAVE_V, 6); break;
+    case 8: MN_ER(MN_ORDER_WAVE_V, 8); break;
+    default: MN_ER(MN_ORDER_WAVE_V, 0); break;
+    }
+#undef MN_ER
+}

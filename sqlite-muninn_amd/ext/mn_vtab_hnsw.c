@@ -1,0 +1,576 @@
+/*
+ * mn_vtab_hnsw.c — the `hnsw_index` virtual table (and its `hnsw0` alias) over the device-resident
+ * index of libmuninn_hip.so.
+ *
+ * Drop-in for the reference's module (src/hnsw_vtab.c): same CREATE arguments and error strings
+ * (:80-134), same declared schema (:366-367), same query plans (:498-550), same shadow tables and
+ * config keys (:138-199) so databases written by either implementation open in the other, same
+ * xUpdate contract (:686-784).  What differs is underneath: the index lives in HBM and every
+ * hnsw_* call is the C-ABI of include/muninn_hip.h (k_insert_seq keeps the reference's
+ * one-at-a-time insert semantics, so the persisted graph is the one the reference would persist).
+ */
+#include "../../include/muninn_hip.h"
+#include "mn_sqlite_abi.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+    sqlite3_vtab base;
+    sqlite3 *db;
+    char *name;
+    mn_index *index;
+    int dim, metric, m, efc;
+} VtabHnsw;
+
+typedef struct {
+    sqlite3_vtab_cursor base;
+    mn_search_result *hits;
+    int n_hits, pos;
+    sqlite3_int64 point_id;
+    int is_point, eof;
+    float *vecbuf;
+} CurHnsw;
+
+enum { COL_VECTOR = 0, COL_DISTANCE = 1, COL_K = 2, COL_EF = 3 };
+enum { PLAN_SCAN = 0, PLAN_KNN = 1, PLAN_POINT = 2 };
+
+static const char *SCHEMA = "CREATE TABLE x(vector BLOB, distance REAL, k INTEGER HIDDEN, ef_search INTEGER HIDDEN)";
+
+typedef struct {
+    int dimensions, metric, m, efc;
+} Params;
+
+/* key=value arguments of CREATE VIRTUAL TABLE (src/hnsw_vtab.c:80-134) */
+static int parse_args(int argc, const char *const *argv, Params *p, char **err) {
+    p->dimensions = 0;
+    p->metric = MN_METRIC_COSINE;
+    p->m = 16;
+    p->efc = 200;
+    for (int i = 3; i < argc; i++) {
+        const char *a = argv[i];
+        if (!strncmp(a, "dimensions=", 11)) {
+            p->dimensions = atoi(a + 11);
+            if (p->dimensions <= 0) {
+                *err = sqlite3_mprintf("hnsw_index: dimensions must be > 0, got '%s'", a + 11);
+                return SQLITE_ERROR;
+            }
+        } else if (!strncmp(a, "metric=", 7)) {
+            const char *v = a + 7;
+            char buf[32];
+            size_t n = strlen(v);
+            if (n >= 2 && (v[0] == '\'' || v[0] == '"')) {
+                n -= 2;
+                if (n >= sizeof(buf))
+                    n = sizeof(buf) - 1;
+                memcpy(buf, v + 1, n);
+                buf[n] = 0;
+                v = buf;
+            }
+            if (mn_vec_parse_metric(v, &p->metric) != 0) {
+                *err = sqlite3_mprintf("hnsw_index: unknown metric '%s' (use 'l2', 'cosine', or 'inner_product')", v);
+                return SQLITE_ERROR;
+            }
+        } else if (!strncmp(a, "m=", 2)) {
+            p->m = atoi(a + 2);
+            if (p->m < 2) {
+                *err = sqlite3_mprintf("hnsw_index: m must be >= 2, got '%s'", a + 2);
+                return SQLITE_ERROR;
+            }
+        } else if (!strncmp(a, "ef_construction=", 16)) {
+            p->efc = atoi(a + 16);
+            if (p->efc < 1) {
+                *err = sqlite3_mprintf("hnsw_index: ef_construction must be >= 1, got '%s'", a + 16);
+                return SQLITE_ERROR;
+            }
+        } else {
+            *err = sqlite3_mprintf("hnsw_index: unknown parameter '%s'", a);
+            return SQLITE_ERROR;
+        }
+    }
+    if (p->dimensions == 0) {
+        *err = sqlite3_mprintf("hnsw_index: 'dimensions' parameter is required");
+        return SQLITE_ERROR;
+    }
+    return SQLITE_OK;
+}
+
+static int run_sql(sqlite3 *db, char *sql) {
+    if (!sql)
+        return SQLITE_NOMEM;
+    int rc = sqlite3_exec(db, sql, 0, 0, 0);
+    sqlite3_free(sql);
+    return rc;
+}
+
+/* src/hnsw_vtab.c:138-181 — byte-compatible shadow schema */
+static int make_shadow_tables(sqlite3 *db, const char *t) {
+    int rc = run_sql(db, sqlite3_mprintf("CREATE TABLE IF NOT EXISTS \"%w_config\" (key TEXT PRIMARY KEY, value TEXT NOT NULL)", t));
+    if (rc == SQLITE_OK)
+        rc = run_sql(db, sqlite3_mprintf("CREATE TABLE IF NOT EXISTS \"%w_nodes\" (  id INTEGER PRIMARY KEY,  vector BLOB NOT NULL,"
+                                         "  level INTEGER NOT NULL,  deleted INTEGER NOT NULL DEFAULT 0)", t));
+    if (rc == SQLITE_OK)
+        rc = run_sql(db, sqlite3_mprintf("CREATE TABLE IF NOT EXISTS \"%w_edges\" (  source_id INTEGER NOT NULL,"
+                                         "  target_id INTEGER NOT NULL,  level INTEGER NOT NULL,  distance REAL NOT NULL,"
+                                         "  PRIMARY KEY (source_id, level, target_id)) WITHOUT ROWID", t));
+    if (rc == SQLITE_OK)
+        rc = run_sql(db, sqlite3_mprintf("CREATE INDEX IF NOT EXISTS \"%w_edges_rev\" ON \"%w_edges\"(target_id, level)", t, t));
+    return rc;
+}
+
+/* src/hnsw_vtab.c:183-199 */
+static int write_config(VtabHnsw *v) {
+    return run_sql(v->db, sqlite3_mprintf("INSERT OR REPLACE INTO \"%w_config\" (key, value) VALUES ('dimensions', '%d'),"
+                                          " ('metric', '%d'), ('m', '%d'), ('ef_construction', '%d'),"
+                                          " ('entry_point', '%lld'), ('max_level', '%d')",
+                                          v->name, v->dim, v->metric, v->m, v->efc,
+                                          (long long)mn_hnsw_entry_point(v->index), mn_hnsw_max_level(v->index)));
+}
+
+/* src/hnsw_vtab.c:201-234 */
+static int read_config(sqlite3 *db, const char *t, Params *p, sqlite3_int64 *entry, int *max_level) {
+    p->dimensions = 0;
+    p->metric = MN_METRIC_COSINE;
+    p->m = 16;
+    p->efc = 200;
+    *entry = -1;
+    *max_level = -1;
+    char *sql = sqlite3_mprintf("SELECT key, value FROM \"%w_config\"", t);
+    sqlite3_stmt *st = 0;
+    int rc = sqlite3_prepare_v2(db, sql, -1, &st, 0);
+    sqlite3_free(sql);
+    if (rc != SQLITE_OK)
+        return rc;
+    while (sqlite3_step(st) == SQLITE_ROW) {
+        const char *k = (const char *)sqlite3_column_text(st, 0);
+        const char *val = (const char *)sqlite3_column_text(st, 1);
+        if (!k || !val)
+            continue;
+        if (!strcmp(k, "dimensions")) p->dimensions = atoi(val);
+        else if (!strcmp(k, "metric")) p->metric = atoi(val);
+        else if (!strcmp(k, "m")) p->m = atoi(val);
+        else if (!strcmp(k, "ef_construction")) p->efc = atoi(val);
+        else if (!strcmp(k, "entry_point")) *entry = atoll(val);
+        else if (!strcmp(k, "max_level")) *max_level = atoi(val);
+    }
+    sqlite3_finalize(st);
+    return SQLITE_OK;
+}
+
+static int node_is_live(VtabHnsw *v, sqlite3_int64 id) { /* hnsw_get_node != NULL (src/hnsw_algo.c:226-231) */
+    return mn_hnsw_node_level(v->index, id) >= 0 && mn_hnsw_node_deleted(v->index, id) == 0;
+}
+
+/* persist_node for the new node and for every neighbour it linked to (src/hnsw_vtab.c:237-283,
+ * :755-768), in one device round trip: mn_hnsw_edges_of returns all their edges with the
+ * per-edge distance the reference stores. */
+static int persist_after_insert(VtabHnsw *v, sqlite3_int64 id, const float *vec) {
+    int level = mn_hnsw_node_level(v->index, id);
+    int cap_ids = 1 + (level + 1) * 2 * v->m;
+    sqlite3_int64 *ids = (sqlite3_int64 *)malloc((size_t)cap_ids * sizeof(sqlite3_int64));
+    if (!ids)
+        return SQLITE_NOMEM;
+    int n = 0;
+    ids[n++] = id;
+    for (int l = 0; l <= level; l++) {
+        int64_t nb[128];
+        int c = mn_hnsw_neighbors(v->index, id, l, nb, 128);
+        for (int i = 0; i < c && i < 128; i++) {
+            int seen = 0;
+            for (int j = 0; j < n; j++)
+                if (ids[j] == nb[i])
+                    seen = 1;
+            if (!seen && n < cap_ids && node_is_live(v, nb[i]))
+                ids[n++] = nb[i];
+        }
+    }
+    int64_t cap = (int64_t)n * 4 * v->m + 64;
+    int64_t *src = 0, *dst = 0;
+    int *lvl = 0;
+    float *dist = 0;
+    int64_t ne;
+    for (;;) {
+        src = (int64_t *)malloc((size_t)cap * sizeof(int64_t));
+        dst = (int64_t *)malloc((size_t)cap * sizeof(int64_t));
+        lvl = (int *)malloc((size_t)cap * sizeof(int));
+        dist = (float *)malloc((size_t)cap * sizeof(float));
+        ne = mn_hnsw_edges_of(v->index, (const int64_t *)ids, n, src, dst, lvl, dist, cap);
+        if (ne <= cap)
+            break;
+        free(src); free(dst); free(lvl); free(dist);
+        cap = ne;
+    }
+    int rc = SQLITE_OK;
+    if (ne < 0) {
+        rc = SQLITE_ERROR;
+    } else {
+        sqlite3_stmt *st = 0;
+        char *sql = sqlite3_mprintf("INSERT OR REPLACE INTO \"%w_nodes\" (id, vector, level, deleted) VALUES (?, ?, ?, 0)", v->name);
+        rc = sqlite3_prepare_v2(v->db, sql, -1, &st, 0);
+        sqlite3_free(sql);
+        if (rc == SQLITE_OK) {
+            sqlite3_bind_int64(st, 1, id);
+            sqlite3_bind_blob(st, 2, vec, v->dim * (int)sizeof(float), SQLITE_STATIC);
+            sqlite3_bind_int(st, 3, level);
+            rc = sqlite3_step(st) == SQLITE_DONE ? SQLITE_OK : SQLITE_ERROR;
+            sqlite3_finalize(st);
+        }
+        for (int i = 0; i < n && rc == SQLITE_OK; i++)
+            rc = run_sql(v->db, sqlite3_mprintf("DELETE FROM \"%w_edges\" WHERE source_id = %lld", v->name, (long long)ids[i]));
+        if (rc == SQLITE_OK) {
+            sql = sqlite3_mprintf("INSERT INTO \"%w_edges\" (source_id, target_id, level, distance) VALUES (?, ?, ?, ?)", v->name);
+            rc = sqlite3_prepare_v2(v->db, sql, -1, &st, 0);
+            sqlite3_free(sql);
+            if (rc == SQLITE_OK) {
+                for (int64_t e = 0; e < ne; e++) {
+                    sqlite3_bind_int64(st, 1, src[e]);
+                    sqlite3_bind_int64(st, 2, dst[e]);
+                    sqlite3_bind_int(st, 3, lvl[e]);
+                    sqlite3_bind_double(st, 4, (double)dist[e]);
+                    sqlite3_step(st);
+                    sqlite3_reset(st);
+                }
+                sqlite3_finalize(st);
+            }
+        }
+    }
+    free(src); free(dst); free(lvl); free(dist); free(ids);
+    return rc;
+}
+
+/* load_index_from_shadow (src/hnsw_vtab.c:286-341): nodes in rowid order, edges in primary-key order */
+static int load_from_shadow(VtabHnsw *v) {
+    sqlite3_stmt *st = 0;
+    char *sql = sqlite3_mprintf("SELECT id, vector, level, deleted FROM \"%w_nodes\"", v->name);
+    int rc = sqlite3_prepare_v2(v->db, sql, -1, &st, 0);
+    sqlite3_free(sql);
+    if (rc != SQLITE_OK)
+        return rc;
+    while (sqlite3_step(st) == SQLITE_ROW) {
+        const float *vec = (const float *)sqlite3_column_blob(st, 1);
+        if (!vec || sqlite3_column_bytes(st, 1) != v->dim * (int)sizeof(float) ||
+            mn_hnsw_load_node(v->index, sqlite3_column_int64(st, 0), vec, sqlite3_column_int(st, 2), sqlite3_column_int(st, 3)) != 0) {
+            sqlite3_finalize(st);
+            return SQLITE_ERROR;
+        }
+    }
+    sqlite3_finalize(st);
+    sql = sqlite3_mprintf("SELECT source_id, target_id, level FROM \"%w_edges\"", v->name);
+    rc = sqlite3_prepare_v2(v->db, sql, -1, &st, 0);
+    sqlite3_free(sql);
+    if (rc != SQLITE_OK)
+        return rc;
+    while (sqlite3_step(st) == SQLITE_ROW) {
+        int64_t dst = sqlite3_column_int64(st, 1);
+        int64_t src = sqlite3_column_int64(st, 0);
+        int lv = sqlite3_column_int(st, 2);
+        if (mn_hnsw_node_level(v->index, src) >= lv) /* :333-336 */
+            mn_hnsw_load_neighbors(v->index, src, lv, &dst, 1);
+    }
+    sqlite3_finalize(st);
+    return SQLITE_OK;
+}
+
+static VtabHnsw *new_vtab(sqlite3 *db, const char *name, const Params *p, mn_index *ix) {
+    VtabHnsw *v = (VtabHnsw *)sqlite3_malloc((int)sizeof(VtabHnsw));
+    if (!v)
+        return 0;
+    memset(v, 0, sizeof(*v));
+    v->db = db;
+    v->name = sqlite3_mprintf("%s", name);
+    v->index = ix;
+    v->dim = p->dimensions;
+    v->metric = p->metric;
+    v->m = p->m;
+    v->efc = p->efc;
+    return v;
+}
+
+static int x_create(sqlite3 *db, void *aux, int argc, const char *const *argv, sqlite3_vtab **out, char **err) {
+    (void)aux;
+    Params p;
+    int rc = parse_args(argc, argv, &p, err);
+    if (rc != SQLITE_OK)
+        return rc;
+    rc = sqlite3_declare_vtab(db, SCHEMA);
+    if (rc != SQLITE_OK)
+        return rc;
+    rc = make_shadow_tables(db, argv[2]);
+    if (rc != SQLITE_OK) {
+        *err = sqlite3_mprintf("hnsw_index: failed to create shadow tables");
+        return rc;
+    }
+    mn_index *ix = mn_hnsw_create(p.dimensions, p.metric, p.m, p.efc);
+    if (!ix) {
+        *err = sqlite3_mprintf("hnsw_index: failed to allocate index (%s)", mn_last_error());
+        return SQLITE_NOMEM;
+    }
+    VtabHnsw *v = new_vtab(db, argv[2], &p, ix);
+    if (!v) {
+        mn_hnsw_destroy(ix);
+        return SQLITE_NOMEM;
+    }
+    write_config(v);
+    *out = &v->base;
+    return SQLITE_OK;
+}
+
+static int x_connect(sqlite3 *db, void *aux, int argc, const char *const *argv, sqlite3_vtab **out, char **err) {
+    (void)aux;
+    (void)argc;
+    Params p;
+    sqlite3_int64 entry;
+    int max_level;
+    int rc = read_config(db, argv[2], &p, &entry, &max_level);
+    if (rc != SQLITE_OK) {
+        *err = sqlite3_mprintf("hnsw_index: failed to load config from shadow tables");
+        return rc;
+    }
+    if (p.dimensions == 0) {
+        *err = sqlite3_mprintf("hnsw_index: corrupted config — dimensions is 0");
+        return SQLITE_ERROR;
+    }
+    rc = sqlite3_declare_vtab(db, SCHEMA);
+    if (rc != SQLITE_OK)
+        return rc;
+    mn_index *ix = mn_hnsw_create(p.dimensions, p.metric, p.m, p.efc);
+    if (!ix) {
+        *err = sqlite3_mprintf("hnsw_index: failed to allocate index (%s)", mn_last_error());
+        return SQLITE_NOMEM;
+    }
+    VtabHnsw *v = new_vtab(db, argv[2], &p, ix);
+    if (!v) {
+        mn_hnsw_destroy(ix);
+        return SQLITE_NOMEM;
+    }
+    rc = load_from_shadow(v);
+    if (rc != SQLITE_OK) {
+        mn_hnsw_destroy(ix);
+        sqlite3_free(v->name);
+        sqlite3_free(v);
+        *err = sqlite3_mprintf("hnsw_index: failed to load index from shadow tables");
+        return rc;
+    }
+    mn_hnsw_set_entry(ix, entry, max_level);
+    *out = &v->base;
+    return SQLITE_OK;
+}
+
+static int x_disconnect(sqlite3_vtab *vt) {
+    VtabHnsw *v = (VtabHnsw *)vt;
+    mn_hnsw_destroy(v->index);
+    sqlite3_free(v->name);
+    sqlite3_free(v);
+    return SQLITE_OK;
+}
+
+static int x_destroy(sqlite3_vtab *vt) { /* src/hnsw_vtab.c:471-494 */
+    VtabHnsw *v = (VtabHnsw *)vt;
+    run_sql(v->db, sqlite3_mprintf("DROP TABLE IF EXISTS \"%w_config\"", v->name));
+    run_sql(v->db, sqlite3_mprintf("DROP TABLE IF EXISTS \"%w_nodes\"", v->name));
+    run_sql(v->db, sqlite3_mprintf("DROP INDEX IF EXISTS \"%w_edges_rev\"", v->name));
+    run_sql(v->db, sqlite3_mprintf("DROP TABLE IF EXISTS \"%w_edges\"", v->name));
+    return x_disconnect(vt);
+}
+
+/* src/hnsw_vtab.c:498-550 */
+static int x_best_index(sqlite3_vtab *vt, sqlite3_index_info *ii) {
+    (void)vt;
+    int i_match = -1, i_k = -1, i_rowid = -1, i_ef = -1;
+    for (int i = 0; i < ii->nConstraint; i++) {
+        if (!ii->aConstraint[i].usable)
+            continue;
+        int col = ii->aConstraint[i].iColumn, op = ii->aConstraint[i].op;
+        if (col == COL_VECTOR && op == SQLITE_INDEX_CONSTRAINT_MATCH) i_match = i;
+        else if (col == COL_K && op == SQLITE_INDEX_CONSTRAINT_EQ) i_k = i;
+        else if (col == COL_EF && op == SQLITE_INDEX_CONSTRAINT_EQ) i_ef = i;
+        else if (col == -1 && op == SQLITE_INDEX_CONSTRAINT_EQ) i_rowid = i;
+    }
+    if (i_match >= 0 && i_k >= 0) {
+        int arg = 1;
+        ii->idxNum = PLAN_KNN;
+        ii->aConstraintUsage[i_match].argvIndex = arg++;
+        ii->aConstraintUsage[i_match].omit = 1;
+        ii->aConstraintUsage[i_k].argvIndex = arg++;
+        ii->aConstraintUsage[i_k].omit = 1;
+        if (i_ef >= 0) {
+            ii->aConstraintUsage[i_ef].argvIndex = arg++;
+            ii->aConstraintUsage[i_ef].omit = 1;
+        }
+        ii->estimatedCost = 10.0;
+        ii->estimatedRows = 10;
+    } else if (i_rowid >= 0) {
+        ii->idxNum = PLAN_POINT;
+        ii->aConstraintUsage[i_rowid].argvIndex = 1;
+        ii->aConstraintUsage[i_rowid].omit = 1;
+        ii->estimatedCost = 1.0;
+        ii->estimatedRows = 1;
+    } else {
+        ii->idxNum = PLAN_SCAN;
+        ii->estimatedCost = 1000000.0;
+        ii->estimatedRows = 1000000;
+    }
+    return SQLITE_OK;
+}
+
+static int x_open(sqlite3_vtab *vt, sqlite3_vtab_cursor **out) {
+    (void)vt;
+    CurHnsw *c = (CurHnsw *)sqlite3_malloc((int)sizeof(CurHnsw));
+    if (!c)
+        return SQLITE_NOMEM;
+    memset(c, 0, sizeof(*c));
+    c->eof = 1;
+    *out = &c->base;
+    return SQLITE_OK;
+}
+
+static int x_close(sqlite3_vtab_cursor *cur) {
+    CurHnsw *c = (CurHnsw *)cur;
+    free(c->hits);
+    free(c->vecbuf);
+    sqlite3_free(c);
+    return SQLITE_OK;
+}
+
+/* src/hnsw_vtab.c:572-620 */
+static int x_filter(sqlite3_vtab_cursor *cur, int idxNum, const char *idxStr, int argc, sqlite3_value **argv) {
+    (void)idxStr;
+    CurHnsw *c = (CurHnsw *)cur;
+    VtabHnsw *v = (VtabHnsw *)cur->pVtab;
+    free(c->hits);
+    c->hits = 0;
+    c->n_hits = c->pos = 0;
+    c->is_point = 0;
+    c->eof = 1;
+    if (idxNum == PLAN_KNN) {
+        const float *q = (const float *)sqlite3_value_blob(argv[0]);
+        int qbytes = sqlite3_value_bytes(argv[0]);
+        int k = sqlite3_value_int(argv[1]);
+        int ef = argc >= 3 ? sqlite3_value_int(argv[2]) : k * 2;
+        int want = v->dim * (int)sizeof(float);
+        if (qbytes != want) {
+            v->base.zErrMsg = sqlite3_mprintf("hnsw_index: expected %d-dim vector (%d bytes), got %d bytes", v->dim, want, qbytes);
+            return SQLITE_ERROR;
+        }
+        if (k <= 0)
+            return SQLITE_OK;
+        c->hits = (mn_search_result *)malloc((size_t)k * sizeof(mn_search_result));
+        if (!c->hits)
+            return SQLITE_NOMEM;
+        c->n_hits = mn_hnsw_search(v->index, q, k, ef, c->hits);
+        c->eof = c->n_hits == 0;
+    } else if (idxNum == PLAN_POINT) {
+        c->point_id = sqlite3_value_int64(argv[0]);
+        c->is_point = 1;
+        c->eof = !node_is_live(v, c->point_id);
+    }
+    return SQLITE_OK;
+}
+
+static int x_next(sqlite3_vtab_cursor *cur) {
+    CurHnsw *c = (CurHnsw *)cur;
+    if (c->is_point || ++c->pos >= c->n_hits)
+        c->eof = 1;
+    return SQLITE_OK;
+}
+
+static int x_eof(sqlite3_vtab_cursor *cur) { return ((CurHnsw *)cur)->eof; }
+
+static int x_rowid(sqlite3_vtab_cursor *cur, sqlite3_int64 *out) {
+    CurHnsw *c = (CurHnsw *)cur;
+    *out = c->is_point ? c->point_id : c->hits[c->pos].id;
+    return SQLITE_OK;
+}
+
+static int x_column(sqlite3_vtab_cursor *cur, sqlite3_context *ctx, int col) { /* src/hnsw_vtab.c:648-683 */
+    CurHnsw *c = (CurHnsw *)cur;
+    VtabHnsw *v = (VtabHnsw *)cur->pVtab;
+    sqlite3_int64 id = c->is_point ? c->point_id : c->hits[c->pos].id;
+    if (col == COL_VECTOR) {
+        if (!c->vecbuf)
+            c->vecbuf = (float *)malloc((size_t)v->dim * sizeof(float));
+        if (c->vecbuf && mn_hnsw_get_vector(v->index, id, c->vecbuf) == 0)
+            sqlite3_result_blob(ctx, c->vecbuf, v->dim * (int)sizeof(float), SQLITE_TRANSIENT);
+        else
+            sqlite3_result_null(ctx);
+    } else if (col == COL_DISTANCE) {
+        sqlite3_result_double(ctx, c->is_point ? 0.0 : (double)c->hits[c->pos].distance);
+    } else {
+        sqlite3_result_null(ctx);
+    }
+    return SQLITE_OK;
+}
+
+/* src/hnsw_vtab.c:686-784 */
+static int x_update(sqlite3_vtab *vt, int argc, sqlite3_value **argv, sqlite3_int64 *rowid) {
+    VtabHnsw *v = (VtabHnsw *)vt;
+    if (argc == 1) { /* DELETE */
+        sqlite3_int64 id = sqlite3_value_int64(argv[0]);
+        if (!node_is_live(v, id)) {
+            v->base.zErrMsg = sqlite3_mprintf("hnsw_index: rowid %lld not found", (long long)id);
+            return SQLITE_ERROR;
+        }
+        if (mn_hnsw_delete(v->index, id) != 0) {
+            v->base.zErrMsg = sqlite3_mprintf("hnsw_index: delete failed (%s)", mn_last_error());
+            return SQLITE_ERROR;
+        }
+        run_sql(v->db, sqlite3_mprintf("UPDATE \"%w_nodes\" SET deleted = 1 WHERE id = %lld", v->name, (long long)id));
+        write_config(v);
+        return SQLITE_OK;
+    }
+    if (argc > 1 && sqlite3_value_type(argv[0]) == SQLITE_NULL) { /* INSERT */
+        sqlite3_int64 id;
+        if (sqlite3_value_type(argv[1]) == SQLITE_NULL) {
+            id = mn_hnsw_node_count(v->index) + 1; /* :722-727 */
+            while (node_is_live(v, id))
+                id++;
+        } else {
+            id = sqlite3_value_int64(argv[1]);
+        }
+        if (sqlite3_value_type(argv[2]) != SQLITE_BLOB) {
+            v->base.zErrMsg = sqlite3_mprintf("hnsw_index: vector must be a BLOB");
+            return SQLITE_ERROR;
+        }
+        const float *vec = (const float *)sqlite3_value_blob(argv[2]);
+        int bytes = sqlite3_value_bytes(argv[2]);
+        int want = v->dim * (int)sizeof(float);
+        if (bytes != want) {
+            v->base.zErrMsg = sqlite3_mprintf("hnsw_index: expected %d-dim vector (%d bytes), got %d bytes", v->dim, want, bytes);
+            return SQLITE_ERROR;
+        }
+        if (mn_hnsw_insert(v->index, id, vec) != 0) {
+            v->base.zErrMsg = sqlite3_mprintf("hnsw_index: insert failed (duplicate rowid %lld?)", (long long)id);
+            return SQLITE_ERROR;
+        }
+        persist_after_insert(v, id, vec);
+        write_config(v);
+        *rowid = id;
+        return SQLITE_OK;
+    }
+    v->base.zErrMsg = sqlite3_mprintf("hnsw_index: UPDATE not supported, use DELETE + INSERT");
+    return SQLITE_ERROR;
+}
+
+static sqlite3_module hnsw_module = {
+    .iVersion = 0,
+    .xCreate = x_create,
+    .xConnect = x_connect,
+    .xBestIndex = x_best_index,
+    .xDisconnect = x_disconnect,
+    .xDestroy = x_destroy,
+    .xOpen = x_open,
+    .xClose = x_close,
+    .xFilter = x_filter,
+    .xNext = x_next,
+    .xEof = x_eof,
+    .xColumn = x_column,
+    .xRowid = x_rowid,
+    .xUpdate = x_update,
+};
+
+int mn_register_hnsw_module(sqlite3 *db) {
+    int rc = sqlite3_create_module(db, "hnsw_index", &hnsw_module, 0); /* src/hnsw_vtab.c:805-807 */
+    if (rc == SQLITE_OK)
+        rc = sqlite3_create_module(db, "hnsw0", &hnsw_module, 0); /* alias named by BASELINE.json */
+    return rc;
+}

@@ -71,6 +71,7 @@ SYMBOLS = [
     ("mn_hnsw_export_nodes", C.c_int, [C.c_void_p, _i64p, _i32p, _i32p]),
     ("mn_hnsw_export_vectors", C.c_int, [C.c_void_p, _f32p]),
     ("mn_hnsw_export_links", C.c_int, [C.c_void_p, C.c_int, _i32p, C.POINTER(C.c_int)]),
+    ("mn_hnsw_edges_of", C.c_int64, [C.c_void_p, _i64p, C.c_int, _i64p, _i64p, _i32p, _f32p, C.c_int64]),
     ("mn_hnsw_last_launch", C.c_int, [C.c_void_p, C.POINTER(LaunchStats)]),
     ("mn_dev_malloc", C.c_void_p, [C.c_void_p, C.c_size_t]),
     ("mn_dev_free", None, [C.c_void_p, C.c_void_p]),
@@ -269,6 +270,21 @@ class HnswIndex:
             raise MuninnHipError(_err())
         assert w.value == M0
         return out
+
+    def edges_of(self, ids):
+        ids = np.ascontiguousarray(ids, np.int64)
+        cap = max(64, len(ids) * 4 * self.M)
+        while True:
+            src = np.empty(cap, np.int64)
+            dst = np.empty(cap, np.int64)
+            lvl = np.empty(cap, np.int32)
+            dist = np.empty(cap, np.float32)
+            n = self.L.mn_hnsw_edges_of(self.h, ids, len(ids), src, dst, lvl, dist, cap)
+            if n < 0:
+                raise MuninnHipError(_err())
+            if n <= cap:
+                return src[:n], dst[:n], lvl[:n], dist[:n]
+            cap = n
 
     # ---- measurement ----
     def last_launch(self):
