@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--order", default="sse", choices=["sse", "wave"])
     ap.add_argument("--dataset", default="gaussian", choices=["gaussian", "clustered"])
     ap.add_argument("--recall-queries", type=int, default=500)
-    ap.add_argument("--cpu-queries", type=int, default=300)
+    ap.add_argument("--cpu-queries", type=int, default=4000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ef-sweep", default="", help="comma list of extra ef values to report (q/s, recall)")
     args = ap.parse_args()
