@@ -148,6 +148,31 @@ int mn_dev_download(mn_index *idx, void *dst_host, const void *src_dev, size_t b
  * d_queries device [nq][dim]; out host [nq][k] ids. */
 int mn_hnsw_bruteforce_topk(mn_index *idx, const float *d_queries, int64_t nq, int k, int64_t *out_ids);
 
+/* ---- graph_csr.h / graph_community.c replacements (a18-a22) ---- */
+typedef struct mn_graph mn_graph; /* device-resident adjacency: GraphData.out / .in (src/graph_load.h:27-37) as two
+                                     CsrArray (src/graph_csr.h:27-34: int32 offsets[V+1], int32 targets[E], f64 weights[E]|NULL) */
+/* Per-node edge order must be the adjacency-list order (edge-table row order).  weights NULL = 1.0. */
+mn_graph *mn_graph_create(int n_nodes, const int *off_out, const int *tgt_out, const double *w_out, const int *off_in,
+                          const int *tgt_in, const double *w_in, int device);
+void mn_graph_destroy(mn_graph *g);
+const char *mn_graph_last_error(void);
+
+typedef enum {
+    MN_LEIDEN_SEQUENTIAL = 0, /* the reference's in-order sweep with immediate moves: community[] and Q bit-identical */
+    MN_LEIDEN_BATCHED = 1     /* batch-synchronous parallel rounds */
+} mn_leiden_mode;
+typedef struct {
+    int64_t iterations, moves, move_sweeps, refine_sweeps;
+    int n_communities;
+    double device_ms;
+} mn_leiden_stats;
+/* run_leiden (src/graph_community.c:336-429).  use_both = (direction == "both").  community_out[n_nodes] is
+ * renumbered 0..K-1 in first-seen order; *modularity_out = Q.  batch: nodes per parallel round (BATCHED; <=1 → 65536).
+ * Returns 0 / -1. */
+int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int mode, int batch, int *community_out,
+                    double *modularity_out);
+int mn_graph_leiden_stats(mn_graph *g, mn_leiden_stats *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,51 @@
+"""Seeded graph inputs shared by oracle/gen_golden.py and the tests (TEST INFRASTRUCTURE ONLY).
+Edge lists are regenerated from seeds; only expected outputs live in tests/golden/."""
+import numpy as np
+
+KARATE = [(1, 2), (1, 3), (1, 4), (1, 5), (1, 6), (1, 7), (1, 8), (1, 9), (1, 11), (1, 12), (1, 13), (1, 14), (1, 18), (1, 20),
+          (1, 22), (1, 32), (2, 3), (2, 4), (2, 8), (2, 14), (2, 18), (2, 20), (2, 22), (2, 31), (3, 4), (3, 8), (3, 9), (3, 10),
+          (3, 14), (3, 28), (3, 29), (3, 33), (4, 8), (4, 13), (4, 14), (5, 7), (5, 11), (6, 7), (6, 11), (6, 17), (7, 17), (9, 31),
+          (9, 33), (9, 34), (10, 34), (14, 34), (15, 33), (15, 34), (16, 33), (16, 34), (19, 33), (19, 34), (20, 34), (21, 33),
+          (21, 34), (23, 33), (23, 34), (24, 26), (24, 28), (24, 30), (24, 33), (24, 34), (25, 26), (25, 28), (25, 32), (26, 32),
+          (27, 30), (27, 34), (28, 34), (29, 32), (29, 34), (30, 33), (30, 34), (31, 33), (31, 34), (32, 33), (32, 34), (33, 34)]
+
+
+def er(n, m, seed, weighted=False):
+    r = np.random.default_rng(seed)
+    s = r.integers(0, n, m)
+    d = r.integers(0, n, m)
+    keep = s != d
+    s, d = s[keep].astype(np.int32), d[keep].astype(np.int32)
+    w = (r.random(len(s)) * 3 + 0.1) if weighted else None
+    return s, d, w
+
+
+def planted(n, k, p_in, p_out, seed):
+    """k equal blocks; edge inside a block with prob p_in, across with p_out (small n only)."""
+    r = np.random.default_rng(seed)
+    blk = np.arange(n) % k
+    iu, ju = np.triu_indices(n, 1)
+    p = np.where(blk[iu] == blk[ju], p_in, p_out)
+    keep = r.random(len(iu)) < p
+    o = r.permutation(int(keep.sum()))
+    return iu[keep][o].astype(np.int32), ju[keep][o].astype(np.int32), None
+
+
+def leiden_cases():
+    """name -> (src, dst, w, resolution); direction is always "both" (the reference's default and the
+    only one for which its sweeps are guaranteed to terminate — with out-edges only it can cycle)."""
+    ks = np.array(KARATE, np.int32) - 1
+    c = {}
+    c["barbell"] = (np.array([0, 1, 2, 3, 4, 5, 2], np.int32), np.array([1, 2, 0, 4, 5, 3, 3], np.int32), None, 1.0)
+    c["triangle"] = (np.array([0, 1, 2], np.int32), np.array([1, 2, 0], np.int32), None, 1.0)
+    c["disconnected"] = (np.array([0, 1, 3, 4], np.int32), np.array([1, 2, 4, 5], np.int32), None, 1.0)
+    c["weighted"] = (np.array([0, 1, 2, 2, 3, 4], np.int32), np.array([1, 2, 0, 3, 4, 5], np.int32),
+                     np.array([5.0, 5.0, 5.0, 0.1, 5.0, 5.0]), 1.0)
+    c["karate"] = (ks[:, 0].copy(), ks[:, 1].copy(), None, 1.0)
+    c["karate_r05"] = (ks[:, 0].copy(), ks[:, 1].copy(), None, 0.5)
+    c["er200"] = er(200, 600, 1) + (1.0,)
+    c["er2000"] = er(2000, 10000, 42) + (1.0,)
+    c["er2000w"] = er(2000, 10000, 3, True) + (1.0,)
+    c["er500w_r2"] = er(500, 5000, 4, True) + (2.0,)
+    c["planted600"] = planted(600, 6, 0.15, 0.005, 7) + (1.0,)
+    return c

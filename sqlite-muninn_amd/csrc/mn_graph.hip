@@ -1,0 +1,605 @@
+// mn_graph.hip — Leiden community detection (src/graph_community.c:75-429) over device-resident CSR
+// adjacency (src/graph_csr.h:27-34), gfx950.
+//
+// The reference sweeps nodes in order and applies every move immediately (:158-228); all arithmetic
+// is f64 and every per-community sum is taken in adjacency-list order.  Device design:
+//   best_move        one wavefront evaluates one node: its edges' (community, weight) pairs are staged
+//                    in LDS in list order; lane e decides whether edge e is the first occurrence of
+//                    its community, sums that community's weights in list order, computes the gain
+//                    expression of :209-210 verbatim in f64 and a max-with-lowest-index reduction
+//                    reproduces the strict `gain > best_gain` first-seen tie rule (:212)
+//   k_leiden_seq     MN_LEIDEN_SEQUENTIAL: ONE wavefront walks v = 0..N-1 with in-place updates
+//                    (agent-scope atomics for label/sum_tot: never a stale L1 line) — community
+//                    assignment and Q bit-identical to the reference
+//   k_leiden_eval/cmin/win/apply   MN_LEIDEN_BATCHED: a range of nodes evaluated in parallel against
+//                    frozen state; a mover commits iff it is the smallest-index mover among the
+//                    movers touching its old/target community and its moving neighbours → committed
+//                    moves are pairwise independent, realise exactly their computed gain (Q strictly
+//                    increases) and the result does not depend on execution order
+// O(N) bookkeeping between phases (renumber :317-331, distinct counts :388-403, sum_tot rebuild
+// :413-416, the final per-community accumulation of :128-139) is done by the host in the
+// reference's order from arrays the kernels produce.
+#include "../../include/muninn_hip.h"
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define DEVI __device__ __forceinline__
+#define LEI_CAP 1024 // edges of one node staged in LDS; larger nodes use the global scratch path
+
+struct DevGraph {
+    int n;
+    const int *off_out, *tgt_out;
+    const double *w_out; // null = 1.0
+    const int *off_in, *tgt_in;
+    const double *w_in;
+};
+
+template <bool COH> DEVI int ld_i(const int *p) {
+    if (COH)
+        return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool COH> DEVI double ld_d(const double *p) {
+    if (COH)
+        return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+
+// Returns the community node v should move to (== its current one if no strictly positive gain).
+template <bool COH>
+DEVI int best_move(const DevGraph &g, int v, const int *label, const double *sum_tot, const double *kdeg, double m,
+                   double resolution, int use_both, const int *elig_part, int *ec, double *ew, unsigned char *el, int lane) {
+    const int o0 = g.off_out[v], d_out = g.off_out[v + 1] - o0;
+    const int i0 = use_both ? g.off_in[v] : 0, d_in = use_both ? g.off_in[v + 1] - i0 : 0;
+    const int d = d_out + d_in;
+    const int old = ld_i<COH>(label + v);
+    const int mypart = elig_part ? elig_part[v] : 0;
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < d; e += 64) {
+        int t;
+        double w;
+        if (e < d_out) {
+            t = g.tgt_out[o0 + e];
+            w = g.w_out ? g.w_out[o0 + e] : 1.0;
+        } else {
+            t = g.tgt_in[i0 + (e - d_out)];
+            w = g.w_in ? g.w_in[i0 + (e - d_out)] : 1.0;
+        }
+        ec[e] = ld_i<COH>(label + t);
+        ew[e] = w;
+        el[e] = (!elig_part || elig_part[t] == mypart) ? 1 : 0;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    const double k_v = kdeg[v];
+    double k_v_to_old = 0.0; // weight_to_community(v, old), :163 — list order
+    for (int j = 0; j < d; j++)
+        if (ec[j] == old)
+            k_v_to_old += ew[j];
+    const double st_old = ld_d<COH>(sum_tot + old);
+    double best_gain = 0.0;
+    int best = old;
+    for (int base = 0; base < d; base += 64) {
+        const int e = base + lane;
+        bool cand = e < d && el[e] && ec[e] != old;
+        const int c = e < d ? ec[e] : -1;
+        if (cand)
+            for (int j = 0; j < e; j++)
+                if (el[j] && ec[j] == c) {
+                    cand = false; // seen earlier in the list (:173-199)
+                    break;
+                }
+        double gain = -1.0;
+        if (cand) {
+            double s = 0.0; // weight_to_community(v, c), :206
+            for (int j = 0; j < d; j++)
+                if (ec[j] == c)
+                    s += ew[j];
+            const double st_c = ld_d<COH>(sum_tot + c);
+            gain = (s - k_v_to_old) / m + resolution * k_v * (st_old - k_v - st_c) / (2.0 * m * m); // :209-210
+            if (!(gain > 0.0))
+                gain = -1.0; // also drops NaN: `gain > best_gain` is false for it
+        }
+        // max gain, lowest lane on ties == first candidate with the strictly largest gain
+        double bg = gain;
+        int bl = lane;
+        for (int mk = 32; mk >= 1; mk >>= 1) {
+            double og = __shfl_xor(bg, mk);
+            int ol = __shfl_xor(bl, mk);
+            if (og > bg || (og == bg && ol < bl)) {
+                bg = og;
+                bl = ol;
+            }
+        }
+        if (bg > best_gain) { // strict: an equal gain in a later chunk does not replace (:212)
+            best_gain = bg;
+            best = __shfl(c, bl);
+        }
+    }
+    return best;
+}
+
+struct LeiArgs {
+    DevGraph g;
+    int *label;
+    double *sum_tot;
+    const double *kdeg;
+    double m, resolution;
+    int use_both;
+    const int *elig_part; // refinement: phase-1 partition; null for local moving
+    int *scratch_c;       // global scratch for nodes with more than LEI_CAP edges: [blocks][max_deg]
+    double *scratch_w;
+    unsigned char *scratch_e;
+    int max_deg;
+    int *out; // [0] moves [1] sweeps
+    int max_sweeps;
+    // batched
+    int b0, b1;
+    int *dec, *cmin, *win;
+};
+
+DEVI void pick_scratch(const LeiArgs &a, int v, int slot, int *lds_c, double *lds_w, unsigned char *lds_e, int *&ec,
+                       double *&ew, unsigned char *&el) {
+    int d = a.g.off_out[v + 1] - a.g.off_out[v] + (a.use_both ? a.g.off_in[v + 1] - a.g.off_in[v] : 0);
+    if (d <= LEI_CAP) {
+        ec = lds_c;
+        ew = lds_w;
+        el = lds_e;
+    } else {
+        ec = a.scratch_c + (size_t)slot * a.max_deg;
+        ew = a.scratch_w + (size_t)slot * a.max_deg;
+        el = a.scratch_e + (size_t)slot * a.max_deg;
+    }
+}
+
+__global__ void __launch_bounds__(64) k_leiden_seq(LeiArgs a) {
+    __shared__ double lds_w[LEI_CAP];
+    __shared__ int lds_c[LEI_CAP];
+    __shared__ unsigned char lds_e[LEI_CAP];
+    const int lane = threadIdx.x;
+    int total = 0, improved = 1, sweeps = 0;
+    while (improved && sweeps < a.max_sweeps) { // :154-229
+        improved = 0;
+        sweeps++;
+        for (int v = 0; v < a.g.n; v++) {
+            int *ec;
+            double *ew;
+            unsigned char *el;
+            pick_scratch(a, v, 0, lds_c, lds_w, lds_e, ec, ew, el);
+            const int old = ld_i<true>(a.label + v);
+            const int best = best_move<true>(a.g, v, a.label, a.sum_tot, a.kdeg, a.m, a.resolution, a.use_both, a.elig_part,
+                                             ec, ew, el, lane);
+            if (best != old) { // :220-227
+                if (lane == 0) {
+                    const double k_v = a.kdeg[v];
+                    double so = ld_d<true>(a.sum_tot + old), sb = ld_d<true>(a.sum_tot + best);
+                    __hip_atomic_store(a.sum_tot + old, so - k_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(a.sum_tot + best, sb + k_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(a.label + v, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __builtin_amdgcn_s_waitcnt(0);
+                improved = 1;
+                total++;
+            }
+        }
+    }
+    if (lane == 0) {
+        a.out[0] = total;
+        a.out[1] = sweeps;
+        a.out[2] = improved; // 1 → stopped by max_sweeps, not converged
+    }
+}
+
+__global__ void __launch_bounds__(64) k_leiden_eval(LeiArgs a) {
+    __shared__ double lds_w[LEI_CAP];
+    __shared__ int lds_c[LEI_CAP];
+    __shared__ unsigned char lds_e[LEI_CAP];
+    const int v = a.b0 + blockIdx.x;
+    if (v >= a.b1)
+        return;
+    int *ec;
+    double *ew;
+    unsigned char *el;
+    pick_scratch(a, v, blockIdx.x, lds_c, lds_w, lds_e, ec, ew, el);
+    const int best = best_move<false>(a.g, v, a.label, a.sum_tot, a.kdeg, a.m, a.resolution, a.use_both, a.elig_part, ec, ew,
+                                      el, threadIdx.x);
+    if (threadIdx.x == 0)
+        a.dec[v - a.b0] = best;
+}
+
+__global__ void k_leiden_cmin(LeiArgs a) {
+    const int v = a.b0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= a.b1)
+        return;
+    const int old = a.label[v], best = a.dec[v - a.b0];
+    if (best == old)
+        return;
+    atomicMin(a.cmin + old, v);
+    atomicMin(a.cmin + best, v);
+}
+
+__global__ void k_leiden_win(LeiArgs a) {
+    const int v = a.b0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= a.b1)
+        return;
+    const int old = a.label[v], best = a.dec[v - a.b0];
+    int win = 0;
+    if (best != old && a.cmin[old] == v && a.cmin[best] == v) {
+        win = 1;
+        for (int pass = 0; win && pass < (a.use_both ? 2 : 1); pass++) {
+            const int *off = pass ? a.g.off_in : a.g.off_out;
+            const int *tgt = pass ? a.g.tgt_in : a.g.tgt_out;
+            for (int x = off[v]; x < off[v + 1]; x++) {
+                const int w = tgt[x];
+                if (w >= a.b0 && w < v && a.dec[w - a.b0] != a.label[w]) {
+                    win = 0;
+                    break;
+                }
+            }
+        }
+    }
+    a.win[v - a.b0] = win;
+}
+
+__global__ void k_leiden_apply(LeiArgs a) {
+    const int v = a.b0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= a.b1)
+        return;
+    const int old = a.label[v], best = a.dec[v - a.b0];
+    if (best == old)
+        return;
+    a.cmin[old] = 0x7fffffff;
+    a.cmin[best] = 0x7fffffff;
+    if (a.win[v - a.b0]) { // winners touch pairwise disjoint communities: plain f64 updates, order-free
+        a.sum_tot[old] -= a.kdeg[v];
+        a.sum_tot[best] += a.kdeg[v];
+        a.label[v] = best;
+        atomicAdd(a.out, 1);
+    }
+}
+
+// weighted_degree (:95-104) and weight_to_community(v, community[v]) (:75-90), list order, f64
+__global__ void k_wdeg(DevGraph g, int use_both, double *kdeg) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= g.n)
+        return;
+    double k = 0.0;
+    for (int e = g.off_out[v]; e < g.off_out[v + 1]; e++)
+        k += g.w_out ? g.w_out[e] : 1.0;
+    if (use_both)
+        for (int e = g.off_in[v]; e < g.off_in[v + 1]; e++)
+            k += g.w_in ? g.w_in[e] : 1.0;
+    kdeg[v] = k;
+}
+
+__global__ void k_w2c_self(DevGraph g, int use_both, const int *label, double *out) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= g.n)
+        return;
+    const int c = label[v];
+    double s = 0.0;
+    for (int e = g.off_out[v]; e < g.off_out[v + 1]; e++)
+        if (label[g.tgt_out[e]] == c)
+            s += g.w_out ? g.w_out[e] : 1.0;
+    if (use_both)
+        for (int e = g.off_in[v]; e < g.off_in[v + 1]; e++)
+            if (label[g.tgt_in[e]] == c)
+                s += g.w_in ? g.w_in[e] : 1.0;
+    out[v] = s;
+}
+
+// ───────────────────────── host ─────────────────────────
+
+static thread_local std::string g_gerr;
+static void gset_err(const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_gerr = buf;
+}
+extern "C" const char *mn_graph_last_error(void) { return g_gerr.c_str(); }
+
+#define GCHK(expr)                                                                                 \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess) {                                                                   \
+            gset_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return -1;                                                                             \
+        }                                                                                          \
+    } while (0)
+
+struct mn_graph {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int n = 0;
+    long long e_out = 0, e_in = 0;
+    int max_deg_both = 0, max_deg_out = 0;
+    bool weighted = false;
+    int *off_out = nullptr, *tgt_out = nullptr, *off_in = nullptr, *tgt_in = nullptr;
+    double *w_out = nullptr, *w_in = nullptr;
+    double last_ms = 0;
+    mn_leiden_stats stats = {};
+};
+
+template <typename T> static int up(T **dst, const T *src, size_t n) {
+    *dst = nullptr;
+    GCHK(hipMalloc(dst, (n ? n : 1) * sizeof(T)));
+    if (n)
+        GCHK(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" mn_graph *mn_graph_create(int n_nodes, const int *off_out, const int *tgt_out, const double *w_out,
+                                     const int *off_in, const int *tgt_in, const double *w_in, int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        gset_err("mn_graph_create: HIP device %d not available (no CPU fallback)", device);
+        return nullptr;
+    }
+    if (n_nodes < 0 || !off_out || !off_in) {
+        gset_err("mn_graph_create: bad arguments");
+        return nullptr;
+    }
+    mn_graph *g = new mn_graph();
+    g->device = device;
+    g->n = n_nodes;
+    g->e_out = n_nodes ? off_out[n_nodes] : 0;
+    g->e_in = n_nodes ? off_in[n_nodes] : 0;
+    g->weighted = w_out != nullptr || w_in != nullptr;
+    for (int v = 0; v < n_nodes; v++) {
+        int dO = off_out[v + 1] - off_out[v], dI = off_in[v + 1] - off_in[v];
+        if (dO > g->max_deg_out) g->max_deg_out = dO;
+        if (dO + dI > g->max_deg_both) g->max_deg_both = dO + dI;
+    }
+    bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreate(&g->ev0) == hipSuccess && hipEventCreate(&g->ev1) == hipSuccess;
+    ok = ok && up(&g->off_out, off_out, (size_t)n_nodes + 1) == 0 && up(&g->tgt_out, tgt_out, (size_t)g->e_out) == 0 &&
+         up(&g->off_in, off_in, (size_t)n_nodes + 1) == 0 && up(&g->tgt_in, tgt_in, (size_t)g->e_in) == 0;
+    if (ok && w_out)
+        ok = up(&g->w_out, w_out, (size_t)g->e_out) == 0;
+    if (ok && w_in)
+        ok = up(&g->w_in, w_in, (size_t)g->e_in) == 0;
+    if (!ok) {
+        mn_graph_destroy(g);
+        return nullptr;
+    }
+    return g;
+}
+
+extern "C" void mn_graph_destroy(mn_graph *g) {
+    if (!g)
+        return;
+    (void)hipSetDevice(g->device);
+    if (g->stream)
+        (void)hipStreamSynchronize(g->stream);
+    (void)hipFree(g->off_out); (void)hipFree(g->tgt_out); (void)hipFree(g->off_in); (void)hipFree(g->tgt_in);
+    (void)hipFree(g->w_out); (void)hipFree(g->w_in);
+    if (g->ev0) (void)hipEventDestroy(g->ev0);
+    if (g->ev1) (void)hipEventDestroy(g->ev1);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    delete g;
+}
+
+static int renumber(std::vector<int> &c) { // :317-331
+    const int N = (int)c.size();
+    std::vector<int> map((size_t)N, -1);
+    int next = 0;
+    for (int i = 0; i < N; i++) {
+        if (map[c[i]] == -1)
+            map[c[i]] = next++;
+        c[i] = map[c[i]];
+    }
+    return next;
+}
+
+static int distinct(const std::vector<int> &c) {
+    std::vector<unsigned char> seen(c.size(), 0);
+    int n = 0;
+    for (int x : c)
+        if (!seen[x]) {
+            seen[x] = 1;
+            n++;
+        }
+    return n;
+}
+
+struct LeiDev {
+    int *label = nullptr, *refined = nullptr, *out = nullptr, *dec = nullptr, *cmin = nullptr, *win = nullptr, *sc = nullptr;
+    double *sum_tot = nullptr, *kdeg = nullptr, *tmp = nullptr, *sw = nullptr;
+    unsigned char *se = nullptr;
+    ~LeiDev() {
+        (void)hipFree(label); (void)hipFree(refined); (void)hipFree(out); (void)hipFree(dec); (void)hipFree(cmin);
+        (void)hipFree(win); (void)hipFree(sc); (void)hipFree(sum_tot); (void)hipFree(kdeg); (void)hipFree(tmp);
+        (void)hipFree(sw); (void)hipFree(se);
+    }
+};
+
+// one phase (local moving when part == nullptr, refinement otherwise); returns moves, -1 on error
+static long long run_phase(mn_graph *g, LeiArgs a, int mode, int batch, int64_t *sweeps_out) {
+    hipStream_t st = g->stream;
+    int out[3] = {0, 0, 0};
+    if (mode == MN_LEIDEN_SEQUENTIAL) {
+        GCHK(hipMemsetAsync(a.out, 0, 3 * sizeof(int), st));
+        hipLaunchKernelGGL(k_leiden_seq, dim3(1), dim3(64), 0, st, a);
+        GCHK(hipGetLastError());
+        GCHK(hipMemcpyAsync(out, a.out, sizeof(out), hipMemcpyDeviceToHost, st));
+        GCHK(hipStreamSynchronize(st));
+        *sweeps_out += out[1];
+        if (out[2]) {
+            gset_err("mn_graph_leiden: sweeps did not converge within %d (asymmetric adjacency?)", a.max_sweeps);
+            return -1;
+        }
+        return out[0];
+    }
+    long long total = 0;
+    int improved = 1, sweeps = 0;
+    while (improved && sweeps < a.max_sweeps) {
+        improved = 0;
+        sweeps++;
+        GCHK(hipMemsetAsync(a.out, 0, 3 * sizeof(int), st));
+        for (int b = 0; b < g->n; b += batch) {
+            a.b0 = b;
+            a.b1 = b + batch < g->n ? b + batch : g->n;
+            int nb = a.b1 - a.b0;
+            hipLaunchKernelGGL(k_leiden_eval, dim3(nb), dim3(64), 0, st, a);
+            hipLaunchKernelGGL(k_leiden_cmin, dim3((nb + 255) / 256), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(k_leiden_win, dim3((nb + 255) / 256), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(k_leiden_apply, dim3((nb + 255) / 256), dim3(256), 0, st, a);
+        }
+        GCHK(hipGetLastError());
+        GCHK(hipMemcpyAsync(out, a.out, sizeof(int), hipMemcpyDeviceToHost, st));
+        GCHK(hipStreamSynchronize(st));
+        if (out[0]) {
+            improved = 1;
+            total += out[0];
+        }
+    }
+    *sweeps_out += sweeps;
+    return total;
+}
+
+extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int mode, int batch, int *community_out,
+                               double *modularity_out) {
+    GCHK(hipSetDevice(g->device));
+    const int N = g->n;
+    memset(&g->stats, 0, sizeof(g->stats));
+    if (modularity_out)
+        *modularity_out = 0.0;
+    if (N == 0)
+        return 0;
+    if (mode == MN_LEIDEN_BATCHED && batch <= 1)
+        batch = 65536;
+    hipStream_t st = g->stream;
+    DevGraph dg = {N, g->off_out, g->tgt_out, g->w_out, g->off_in, g->tgt_in, g->w_in};
+    LeiDev d;
+    const int max_deg = use_both ? g->max_deg_both : g->max_deg_out;
+    const int nslots = mode == MN_LEIDEN_SEQUENTIAL ? 1 : batch;
+    GCHK(hipMalloc(&d.label, (size_t)N * sizeof(int)));
+    GCHK(hipMalloc(&d.refined, (size_t)N * sizeof(int)));
+    GCHK(hipMalloc(&d.sum_tot, (size_t)N * sizeof(double)));
+    GCHK(hipMalloc(&d.kdeg, (size_t)N * sizeof(double)));
+    GCHK(hipMalloc(&d.tmp, (size_t)N * sizeof(double)));
+    GCHK(hipMalloc(&d.out, 4 * sizeof(int)));
+    if (mode == MN_LEIDEN_BATCHED) {
+        GCHK(hipMalloc(&d.dec, (size_t)batch * sizeof(int)));
+        GCHK(hipMalloc(&d.win, (size_t)batch * sizeof(int)));
+        GCHK(hipMalloc(&d.cmin, (size_t)N * sizeof(int)));
+        GCHK(hipMemsetAsync(d.cmin, 0x7f, (size_t)N * sizeof(int), st)); // 0x7f7f7f7f > any node index
+    }
+    if (max_deg > LEI_CAP) {
+        GCHK(hipMalloc(&d.sc, (size_t)nslots * max_deg * sizeof(int)));
+        GCHK(hipMalloc(&d.sw, (size_t)nslots * max_deg * sizeof(double)));
+        GCHK(hipMalloc(&d.se, (size_t)nslots * max_deg));
+    }
+    GCHK(hipEventRecord(g->ev0, st));
+    // k[i], m (:344-350) — per-node sums on the device, the running total in node order on the host
+    hipLaunchKernelGGL(k_wdeg, dim3((N + 255) / 256), dim3(256), 0, st, dg, use_both, d.kdeg);
+    std::vector<double> k((size_t)N);
+    GCHK(hipMemcpyAsync(k.data(), d.kdeg, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, st));
+    GCHK(hipStreamSynchronize(st));
+    double m = 0.0;
+    for (int i = 0; i < N; i++)
+        m += k[i];
+    m /= 2.0;
+    std::vector<int> community((size_t)N), refined((size_t)N);
+    for (int i = 0; i < N; i++)
+        community[i] = i;
+    if (m <= 0.0) { // :351-356
+        memcpy(community_out, community.data(), (size_t)N * sizeof(int));
+        return 0;
+    }
+    std::vector<double> sum_tot(k);
+    GCHK(hipMemcpyAsync(d.label, community.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, st));
+    GCHK(hipMemcpyAsync(d.sum_tot, sum_tot.data(), (size_t)N * sizeof(double), hipMemcpyHostToDevice, st));
+
+    LeiArgs a;
+    memset(&a, 0, sizeof(a));
+    a.g = dg;
+    a.kdeg = d.kdeg;
+    a.m = m;
+    a.resolution = resolution;
+    a.use_both = use_both;
+    a.scratch_c = d.sc;
+    a.scratch_w = d.sw;
+    a.scratch_e = d.se;
+    a.max_deg = max_deg;
+    a.out = d.out;
+    a.max_sweeps = 100000;
+    a.dec = d.dec;
+    a.cmin = d.cmin;
+    a.win = d.win;
+
+    for (int iter = 0; iter < 100; iter++) { // :368-417
+        a.label = d.label;
+        a.sum_tot = d.sum_tot;
+        a.elig_part = nullptr;
+        long long moves = run_phase(g, a, mode, batch, &g->stats.move_sweeps);
+        if (moves < 0)
+            return -1;
+        g->stats.iterations++;
+        g->stats.moves += moves;
+        if (moves == 0)
+            break;
+        // refinement (:238-312): singletons, r_sum_tot = k
+        GCHK(hipMemcpyAsync(community.data(), d.label, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, st));
+        for (int i = 0; i < N; i++)
+            refined[i] = i;
+        GCHK(hipMemcpyAsync(d.refined, refined.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, st));
+        GCHK(hipMemcpyAsync(d.tmp, d.kdeg, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, st));
+        a.label = d.refined;
+        a.sum_tot = d.tmp;
+        a.elig_part = d.label;
+        if (run_phase(g, a, mode, batch, &g->stats.refine_sweeps) < 0)
+            return -1;
+        GCHK(hipMemcpyAsync(refined.data(), d.refined, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, st));
+        GCHK(hipStreamSynchronize(st));
+        if (distinct(refined) <= distinct(community)) // :388-408
+            community = refined;
+        renumber(community);
+        std::fill(sum_tot.begin(), sum_tot.end(), 0.0); // :413-416, node order
+        for (int i = 0; i < N; i++)
+            sum_tot[community[i]] += k[i];
+        GCHK(hipMemcpyAsync(d.label, community.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, st));
+        GCHK(hipMemcpyAsync(d.sum_tot, sum_tot.data(), (size_t)N * sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    GCHK(hipMemcpyAsync(community.data(), d.label, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, st));
+    GCHK(hipStreamSynchronize(st));
+    const int K = renumber(community); // :420
+    // compute_modularity (:109-142): per-node terms on the device, accumulation in node order here
+    GCHK(hipMemcpyAsync(d.label, community.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_w2c_self, dim3((N + 255) / 256), dim3(256), 0, st, dg, use_both, d.label, d.tmp);
+    std::vector<double> w2c((size_t)N);
+    GCHK(hipMemcpyAsync(w2c.data(), d.tmp, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, st));
+    GCHK(hipEventRecord(g->ev1, st));
+    GCHK(hipStreamSynchronize(st));
+    std::vector<double> s_in((size_t)K, 0.0), s_tot((size_t)K, 0.0);
+    for (int i = 0; i < N; i++) {
+        s_tot[community[i]] += k[i];
+        s_in[community[i]] += w2c[i];
+    }
+    double Q = 0.0;
+    for (int c = 0; c < K; c++)
+        if (s_tot[c] > 0)
+            Q += s_in[c] / (2.0 * m) - resolution * (s_tot[c] / (2.0 * m)) * (s_tot[c] / (2.0 * m));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, g->ev0, g->ev1) == hipSuccess)
+        g->stats.device_ms = ms;
+    g->stats.n_communities = K;
+    memcpy(community_out, community.data(), (size_t)N * sizeof(int));
+    if (modularity_out)
+        *modularity_out = Q;
+    return 0;
+}
+
+extern "C" int mn_graph_leiden_stats(mn_graph *g, mn_leiden_stats *out) {
+    *out = g->stats;
+    return 0;
+}

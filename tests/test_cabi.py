@@ -21,7 +21,7 @@ def test_library_builds_and_exports_header_symbols(mn):
     assert len(declared) >= 30
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/muninn_hip.h but not exported"
-    bound = {s[0] for s in mn.hnsw.SYMBOLS}
+    bound = {s[0] for s in mn.hnsw.SYMBOLS} | {s[0] for s in mn.graph.GRAPH_SYMBOLS}
     assert set(declared) == bound, (set(declared) ^ bound)
 
 

@@ -1,0 +1,116 @@
+"""Leiden (src/graph_community.c): oracle vs the reference's golden communities/Q (CPU), HIP sequential
+mode vs the same golden (GPU, bit-exact), HIP batched mode vs the oracle's restatement of the same
+schedule (GPU, bit-exact) and within tolerance of the sequential modularity."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import orc_graph as og
+from oracle.graph_cases import er, leiden_cases, planted
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = leiden_cases()
+
+
+def qbits(q):
+    return np.array([q], np.float64).view(np.int64)[0]
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_matches_reference_golden(name):
+    z = np.load(os.path.join(G, "leiden.npz"))
+    s, d, w, res = CASES[name]
+    comm, q, st = og.leiden(og.Csr(s, d, w, "both"), res, 1)
+    assert np.array_equal(comm, z[f"{name}_community"])
+    assert qbits(q) == z[f"{name}_q"][0]
+
+
+def test_reference_structural_contracts():
+    """pytests/test_graph_community.py:129-287 restated on the oracle: barbell → {0,1,2},{3,4,5}; triangle → 1;
+    disconnected → 2; Q > 0; ids contiguous from 0; resolution monotone."""
+    comm, q, _ = og.leiden(og.Csr(*CASES["barbell"][:3], "both"), 1.0, 1)
+    assert len(set(comm[:3])) == 1 and len(set(comm[3:])) == 1 and comm[0] != comm[3] and q > 0
+    comm, q, _ = og.leiden(og.Csr(*CASES["triangle"][:3], "both"), 1.0, 1)
+    assert len(set(comm)) == 1
+    comm, q, _ = og.leiden(og.Csr(*CASES["disconnected"][:3], "both"), 1.0, 1)
+    assert len(set(comm)) == 2
+    s, d, w, _ = CASES["karate"]
+    k_lo = len(set(og.leiden(og.Csr(s, d, w, "both"), 0.5, 1)[0]))
+    k_hi = len(set(og.leiden(og.Csr(s, d, w, "both"), 2.0, 1)[0]))
+    assert k_lo <= k_hi
+    comm = og.leiden(og.Csr(s, d, w, "both"), 1.0, 1)[0]
+    assert sorted(set(comm)) == list(range(comm.max() + 1))
+
+
+def test_live_reference_random_graphs():
+    if not og.have_ref_graph():
+        pytest.skip("compiled reference not present")
+    for seed in range(5):
+        s, d, w = er(300 + 50 * seed, 1500, 100 + seed, weighted=seed % 2 == 1)
+        rc, rq, _ = og.ref_leiden(s, d, w, "both", 1.0)
+        oc, oq, _ = og.leiden(og.Csr(s, d, w, "both"), 1.0, 1)
+        assert np.array_equal(rc, oc) and qbits(rq) == qbits(oq)
+
+
+def test_batched_schedule_quality_on_cpu():
+    s, d, w = planted(600, 6, 0.15, 0.005, 7)
+    csr = og.Csr(s, d, w, "both")
+    _, q_seq, _ = og.leiden(csr, 1.0, 1)
+    for batch in (16, 256, 100000):
+        comm, q, st = og.leiden(csr, 1.0, batch)
+        assert q > 0 and q >= 0.85 * q_seq, (batch, q, q_seq)
+        assert sorted(set(comm)) == list(range(comm.max() + 1))
+
+
+# ───────────────────────── GPU ─────────────────────────
+
+def _dev_graph(gpu, csr):
+    return gpu.Graph(csr.n, csr.off_out, csr.tgt_out, csr.w_out if csr.weighted else None, csr.off_in, csr.tgt_in,
+                     csr.w_in if csr.weighted else None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_gpu_sequential_matches_reference_golden(gpu, name):
+    z = np.load(os.path.join(G, "leiden.npz"))
+    s, d, w, res = CASES[name]
+    g = _dev_graph(gpu, og.Csr(s, d, w, "both"))
+    comm, q, st = g.leiden(res, "both", gpu.LEIDEN_SEQUENTIAL)
+    assert np.array_equal(comm, z[f"{name}_community"]), name
+    assert qbits(q) == z[f"{name}_q"][0]
+    g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["karate", "er200", "er2000", "er2000w", "planted600"])
+@pytest.mark.parametrize("batch", [16, 1000, 65536])
+def test_gpu_batched_matches_oracle_schedule(gpu, name, batch):
+    s, d, w, res = CASES[name]
+    csr = og.Csr(s, d, w, "both")
+    oc, oq, ost = og.leiden(csr, res, batch)
+    g = _dev_graph(gpu, csr)
+    comm, q, st = g.leiden(res, "both", gpu.LEIDEN_BATCHED, batch)
+    assert np.array_equal(comm, oc), (name, batch)
+    assert qbits(q) == qbits(oq)
+    assert st["moves"] == ost["moves"]
+    g.close()
+
+
+@pytest.mark.gpu
+def test_gpu_high_degree_nodes_use_global_scratch(gpu):
+    """a hub with > 1024 edges exercises the global-scratch path of best_move"""
+    n = 3000
+    hub_s = np.zeros(n - 1, np.int32)
+    hub_d = np.arange(1, n, dtype=np.int32)
+    s2, d2, _ = er(n, 6000, 9)
+    s, d = np.concatenate([hub_s, s2]), np.concatenate([hub_d, d2])
+    csr = og.Csr(s, d, None, "both")
+    oc, oq, _ = og.leiden(csr, 1.0, 1)
+    g = _dev_graph(gpu, csr)
+    comm, q, _ = g.leiden(1.0, "both", gpu.LEIDEN_SEQUENTIAL)
+    assert np.array_equal(comm, oc) and qbits(q) == qbits(oq)
+    bc, bq, _ = og.leiden(csr, 1.0, 512)
+    comm, q, _ = g.leiden(1.0, "both", gpu.LEIDEN_BATCHED, 512)
+    assert np.array_equal(comm, bc) and qbits(q) == qbits(bq)
+    g.close()
