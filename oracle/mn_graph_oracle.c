@@ -10,10 +10,11 @@
  */
 #include "mn_graph_oracle.h"
 
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
-#define ORC_LEIDEN_MAX_SWEEPS 10000 /* batched schedule only; Q increases strictly, so this is a backstop */
+#define ORC_LEIDEN_MAX_SWEEPS 100000 /* batched schedule only; Q increases strictly, so this is a backstop */
 
 static double ew(const double *w, int e) {
     return w ? w[e] : 1.0;
@@ -72,7 +73,7 @@ double orc_modularity(const orc_graph *g, const int *community, double resolutio
 /* best move of node v against the given state (the loop body of :158-216).  `elig` restricts the
  * candidate edges (refinement: partition[w] == partition[v], :263-266); NULL = all edges. */
 static int best_move(const orc_graph *g, int v, const int *label, const double *sum_tot, const double *k, double m,
-                     double resolution, int use_both, const int *elig_part, int *scratch) {
+                     double resolution, int use_both, const int *elig_part, int *scratch, double *dk_out) {
     int old = label[v];
     double k_v = k[v];
     double k_v_to_old = w2c(g, v, label, old, use_both);
@@ -103,6 +104,8 @@ static int best_move(const orc_graph *g, int v, const int *label, const double *
             if (gain > best_gain) {
                 best_gain = gain;
                 best = nc;
+                if (dk_out)
+                    *dk_out = k_v_to_t - k_v_to_old;
             }
         }
     }
@@ -119,101 +122,154 @@ static int max_degree(const orc_graph *g, int use_both) {
     return md;
 }
 
+/* Fixed-point upper bound of a weighted degree: tallies of movers are kept as integers so that they
+ * are exact and order-independent on the device (integer atomics). */
+#define ORC_FX 1048576.0
+static unsigned long long fx_up(double k) {
+    return (unsigned long long)ceil(k * ORC_FX);
+}
+
 /* One parallel round of the batch-synchronous schedule (HIP fast mode) over nodes
- * [b, e): every node is evaluated against the frozen state; a mover v commits iff it is the
- * smallest-index mover among (i) the movers touching its old or its target community and (ii) its
- * moving neighbours.  Committed moves touch pairwise disjoint communities and have unchanged
- * inputs, so each realises exactly its computed positive gain (Q strictly increases: no swap
- * cycles) and the round's result is independent of execution order.  Returns moves committed. */
+ * [b, e).  Every node is evaluated against the frozen state (best_move).  Let J[c] / L[c] be the total
+ * degree of movers that want to join / leave community c.  A mover v (old → c) is a SAFE winner iff no
+ * neighbour with a smaller index inside [b, e) is a mover, and its gain stays positive in the worst
+ * order of application: old already drained by every other leaver, c already filled by every other
+ * joiner.  Then every applied move has positive gain whatever the order → Q strictly increases.  If a
+ * round has movers but no safe winner, the STRICT rule is used instead: v wins iff it is the smallest
+ * index among the movers touching old or c (and has no smaller moving neighbour).  Winners are applied
+ * in node order.  Returns the number of moves. */
+typedef struct {
+    int *dec;
+    double *dk;
+    unsigned char *win;
+    int *cmin;                    /* [N] = INT_MAX when idle */
+    unsigned long long *Jq, *Lq;  /* [N] zero when idle */
+} round_ws;
+
 static int batch_round(const orc_graph *g, int b, int e, int *label, double *sum_tot, const double *k, double m,
-                       double resolution, int use_both, const int *elig_part, int *scratch, int *dec, int *cmin) {
-    int moves = 0;
-    for (int v = b; v < e; v++)
-        dec[v - b] = best_move(g, v, label, sum_tot, k, m, resolution, use_both, elig_part, scratch);
+                       double resolution, int use_both, const int *elig_part, int *scratch, round_ws *ws) {
+    int movers = 0, safe = 0, moves = 0;
     for (int v = b; v < e; v++) {
-        int old = label[v], best = dec[v - b];
-        if (best == old)
-            continue;
-        if (cmin[old] < 0 || v < cmin[old])
-            cmin[old] = v;
-        if (cmin[best] < 0 || v < cmin[best])
-            cmin[best] = v;
+        ws->dk[v - b] = 0.0;
+        ws->dec[v - b] = best_move(g, v, label, sum_tot, k, m, resolution, use_both, elig_part, scratch, &ws->dk[v - b]);
     }
     for (int v = b; v < e; v++) {
-        int old = label[v], best = dec[v - b];
+        int old = label[v], best = ws->dec[v - b];
         if (best == old)
             continue;
-        int win = cmin[old] == v && cmin[best] == v;
-        for (int pass = 0; win && pass < (use_both ? 2 : 1); pass++) {
+        movers++;
+        if (v < ws->cmin[old]) ws->cmin[old] = v;
+        if (v < ws->cmin[best]) ws->cmin[best] = v;
+        ws->Lq[old] += fx_up(k[v]);
+        ws->Jq[best] += fx_up(k[v]);
+    }
+    for (int v = b; v < e; v++) {
+        int old = label[v], best = ws->dec[v - b];
+        ws->win[v - b] = 0;
+        if (best == old)
+            continue;
+        int free_nb = 1;
+        for (int pass = 0; free_nb && pass < (use_both ? 2 : 1); pass++) {
             const int *off = pass ? g->off_in : g->off_out;
             const int *tgt = pass ? g->tgt_in : g->tgt_out;
             for (int x = off[v]; x < off[v + 1]; x++) {
                 int w = tgt[x];
-                if (w >= b && w < v && dec[w - b] != label[w]) {
-                    win = 0;
+                if (w >= b && w < v && ws->dec[w - b] != label[w]) {
+                    free_nb = 0;
                     break;
                 }
             }
         }
-        if (!win)
-            dec[v - b] = -1 - best; /* loser: remembered only to clear cmin below */
+        if (!free_nb)
+            continue;
+        double Lo = (double)(ws->Lq[old] - fx_up(k[v])) / ORC_FX, Jc = (double)(ws->Jq[best] - fx_up(k[v])) / ORC_FX;
+        double gain2 = ws->dk[v - b] / m + resolution * k[v] * (sum_tot[old] - Lo - k[v] - sum_tot[best] - Jc) / (2.0 * m * m);
+        int strict = ws->cmin[old] == v && ws->cmin[best] == v;
+        ws->win[v - b] = (unsigned char)((gain2 > 0.0 ? 1 : 0) | (strict ? 2 : 0));
+        if (gain2 > 0.0)
+            safe++;
     }
+    const int use_bit = safe > 0 ? 1 : 2;
     for (int v = b; v < e; v++) {
-        int old = label[v], d = dec[v - b];
-        int best = d < 0 ? -1 - d : d;
+        int old = label[v], best = ws->dec[v - b];
         if (best == old)
             continue;
-        cmin[old] = -1;
-        cmin[best] = -1;
-        if (d >= 0) {
+        ws->cmin[old] = 0x7fffffff;
+        ws->cmin[best] = 0x7fffffff;
+        ws->Lq[old] = 0;
+        ws->Jq[best] = 0;
+    }
+    for (int v = b; v < e; v++) {
+        int old = label[v], best = ws->dec[v - b];
+        if (best != old && (ws->win[v - b] & use_bit)) {
             sum_tot[old] -= k[v];
             sum_tot[best] += k[v];
             label[v] = best;
             moves++;
         }
     }
+    (void)movers;
     return moves;
 }
 
-/* src/graph_community.c:150-231.  batch <= 1: the reference's Gauss-Seidel sweep.  batch > 1:
- * sweeps of batch_round over consecutive node ranges until a whole sweep commits nothing. */
-static int local_moving(const orc_graph *g, int *community, double *sum_tot, const double *k, double m, double resolution,
-                        int use_both, int batch, int max_sweeps, int *scratch, int64_t *n_sweeps) {
+static void ws_init(round_ws *ws, int N, int batch) {
+    ws->dec = (int *)malloc((size_t)batch * sizeof(int));
+    ws->dk = (double *)malloc((size_t)batch * sizeof(double));
+    ws->win = (unsigned char *)malloc((size_t)batch);
+    ws->cmin = (int *)malloc((size_t)N * sizeof(int));
+    ws->Jq = (unsigned long long *)calloc((size_t)N, sizeof(unsigned long long));
+    ws->Lq = (unsigned long long *)calloc((size_t)N, sizeof(unsigned long long));
+    for (int i = 0; i < N; i++)
+        ws->cmin[i] = 0x7fffffff;
+}
+static void ws_free(round_ws *ws) {
+    free(ws->dec); free(ws->dk); free(ws->win); free(ws->cmin); free(ws->Jq); free(ws->Lq);
+}
+
+/* sweeps of batch_round over consecutive node ranges until a whole sweep commits nothing */
+static int batched_phase(const orc_graph *g, int *label, double *sum_tot, const double *k, double m, double resolution,
+                         int use_both, const int *elig_part, int batch, int max_sweeps, int *scratch, int64_t *n_sweeps) {
     int N = g->n, total = 0, improved = 1, sweeps = 0;
-    int *dec = batch > 1 ? (int *)malloc((size_t)batch * sizeof(int)) : NULL;
-    int *cmin = NULL;
-    if (batch > 1) {
-        cmin = (int *)malloc((size_t)N * sizeof(int));
-        for (int i = 0; i < N; i++)
-            cmin[i] = -1;
-    }
-    while (improved && (batch <= 1 || sweeps < max_sweeps)) {
+    round_ws ws;
+    ws_init(&ws, N, batch);
+    while (improved && sweeps < max_sweeps) {
         improved = 0;
         sweeps++;
-        if (batch <= 1) {
-            for (int v = 0; v < N; v++) {
-                int old = community[v];
-                int best = best_move(g, v, community, sum_tot, k, m, resolution, use_both, NULL, scratch);
-                if (best != old) { /* :220-227 */
-                    sum_tot[old] -= k[v];
-                    sum_tot[best] += k[v];
-                    community[v] = best;
-                    improved = 1;
-                    total++;
-                }
-            }
-        } else {
-            for (int b = 0; b < N; b += batch) {
-                int mv = batch_round(g, b, b + batch < N ? b + batch : N, community, sum_tot, k, m, resolution, use_both,
-                                     NULL, scratch, dec, cmin);
-                if (mv)
-                    improved = 1;
-                total += mv;
+        for (int b = 0; b < N; b += batch) {
+            int mv = batch_round(g, b, b + batch < N ? b + batch : N, label, sum_tot, k, m, resolution, use_both, elig_part,
+                                 scratch, &ws);
+            if (mv)
+                improved = 1;
+            total += mv;
+        }
+    }
+    ws_free(&ws);
+    if (n_sweeps)
+        *n_sweeps += sweeps;
+    return total;
+}
+
+/* src/graph_community.c:150-231.  mode 0: the reference's Gauss-Seidel sweep; mode 1: sync_phase. */
+static int local_moving(const orc_graph *g, int *community, double *sum_tot, const double *k, double m, double resolution,
+                        int use_both, int batch, int max_sweeps, int *scratch, int64_t *n_sweeps) {
+    if (batch > 1)
+        return batched_phase(g, community, sum_tot, k, m, resolution, use_both, NULL, batch, max_sweeps, scratch, n_sweeps);
+    int N = g->n, total = 0, improved = 1, sweeps = 0;
+    while (improved) {
+        improved = 0;
+        sweeps++;
+        for (int v = 0; v < N; v++) {
+            int old = community[v];
+            int best = best_move(g, v, community, sum_tot, k, m, resolution, use_both, NULL, scratch, NULL);
+            if (best != old) { /* :220-227 */
+                sum_tot[old] -= k[v];
+                sum_tot[best] += k[v];
+                community[v] = best;
+                improved = 1;
+                total++;
             }
         }
     }
-    free(dec);
-    free(cmin);
     if (n_sweeps)
         *n_sweeps += sweeps;
     return total;
@@ -228,29 +284,19 @@ static void refinement(const orc_graph *g, const int *partition, int *refined, c
         refined[i] = i;
         r_sum_tot[i] = k[i];
     }
-    int improved = 1, sweeps = 0;
-    int *dec = NULL, *cmin = NULL;
     if (batch > 1) {
-        dec = (int *)malloc((size_t)batch * sizeof(int));
-        cmin = (int *)malloc((size_t)N * sizeof(int));
-        for (int i = 0; i < N; i++)
-            cmin[i] = -1;
+        batched_phase(g, refined, r_sum_tot, k, m, resolution, use_both, partition, batch, max_sweeps, scratch, n_sweeps);
+        free(r_sum_tot);
+        return;
     }
-    while (improved && (batch <= 1 || sweeps < max_sweeps)) {
+    int improved = 1;
+    while (improved) {
         improved = 0;
-        sweeps++;
         if (n_sweeps)
             (*n_sweeps)++;
-        if (batch > 1) {
-            for (int b = 0; b < N; b += batch)
-                if (batch_round(g, b, b + batch < N ? b + batch : N, refined, r_sum_tot, k, m, resolution, use_both, partition,
-                                scratch, dec, cmin))
-                    improved = 1;
-            continue;
-        }
         for (int v = 0; v < N; v++) {
             int old = refined[v];
-            int best = best_move(g, v, refined, r_sum_tot, k, m, resolution, use_both, partition, scratch);
+            int best = best_move(g, v, refined, r_sum_tot, k, m, resolution, use_both, partition, scratch, NULL);
             if (best != old) {
                 r_sum_tot[old] -= k[v];
                 r_sum_tot[best] += k[v];
@@ -260,8 +306,6 @@ static void refinement(const orc_graph *g, const int *partition, int *refined, c
         }
     }
     free(r_sum_tot);
-    free(dec);
-    free(cmin);
 }
 
 /* src/graph_community.c:317-331 */

@@ -22,6 +22,8 @@
 #include "../../include/muninn_hip.h"
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -53,7 +55,8 @@ template <bool COH> DEVI double ld_d(const double *p) {
 // Returns the community node v should move to (== its current one if no strictly positive gain).
 template <bool COH>
 DEVI int best_move(const DevGraph &g, int v, const int *label, const double *sum_tot, const double *kdeg, double m,
-                   double resolution, int use_both, const int *elig_part, int *ec, double *ew, unsigned char *el, int lane) {
+                   double resolution, int use_both, const int *elig_part, int *ec, double *ew, unsigned char *el, int lane,
+                   double *dk_out = nullptr) {
     const int o0 = g.off_out[v], d_out = g.off_out[v + 1] - o0;
     const int i0 = use_both ? g.off_in[v] : 0, d_in = use_both ? g.off_in[v + 1] - i0 : 0;
     const int d = d_out + d_in;
@@ -94,13 +97,14 @@ DEVI int best_move(const DevGraph &g, int v, const int *label, const double *sum
                     cand = false; // seen earlier in the list (:173-199)
                     break;
                 }
-        double gain = -1.0;
+        double gain = -1.0, dk = 0.0;
         if (cand) {
             double s = 0.0; // weight_to_community(v, c), :206
             for (int j = 0; j < d; j++)
                 if (ec[j] == c)
                     s += ew[j];
             const double st_c = ld_d<COH>(sum_tot + c);
+            dk = s - k_v_to_old;
             gain = (s - k_v_to_old) / m + resolution * k_v * (st_old - k_v - st_c) / (2.0 * m * m); // :209-210
             if (!(gain > 0.0))
                 gain = -1.0; // also drops NaN: `gain > best_gain` is false for it
@@ -119,6 +123,9 @@ DEVI int best_move(const DevGraph &g, int v, const int *label, const double *sum
         if (bg > best_gain) { // strict: an equal gain in a later chunk does not replace (:212)
             best_gain = bg;
             best = __shfl(c, bl);
+            double bdk = __shfl(dk, bl);
+            if (dk_out)
+                *dk_out = bdk;
         }
     }
     return best;
@@ -140,8 +147,15 @@ struct LeiArgs {
     int max_sweeps;
     // batched
     int b0, b1;
-    int *dec, *cmin, *win;
+    int *dec, *cmin;
+    unsigned char *win;
+    double *dk;
+    unsigned long long *Jq, *Lq; // fixed-point (2^20) tallies of the movers' degrees per community
+    int apply_on_device;         // 0: weighted graph → the host applies winners in node order
 };
+
+#define LEI_FX 1048576.0
+DEVI unsigned long long fx_up(double k) { return (unsigned long long)ceil(k * LEI_FX); }
 
 DEVI void pick_scratch(const LeiArgs &a, int v, int slot, int *lds_c, double *lds_w, unsigned char *lds_e, int *&ec,
                        double *&ew, unsigned char *&el) {
@@ -206,10 +220,13 @@ __global__ void __launch_bounds__(64) k_leiden_eval(LeiArgs a) {
     double *ew;
     unsigned char *el;
     pick_scratch(a, v, blockIdx.x, lds_c, lds_w, lds_e, ec, ew, el);
+    double dk = 0.0;
     const int best = best_move<false>(a.g, v, a.label, a.sum_tot, a.kdeg, a.m, a.resolution, a.use_both, a.elig_part, ec, ew,
-                                      el, threadIdx.x);
-    if (threadIdx.x == 0)
+                                      el, threadIdx.x, &dk);
+    if (threadIdx.x == 0) {
         a.dec[v - a.b0] = best;
+        a.dk[v - a.b0] = dk;
+    }
 }
 
 __global__ void k_leiden_cmin(LeiArgs a) {
@@ -221,6 +238,9 @@ __global__ void k_leiden_cmin(LeiArgs a) {
         return;
     atomicMin(a.cmin + old, v);
     atomicMin(a.cmin + best, v);
+    const unsigned long long q = fx_up(a.kdeg[v]);
+    atomicAdd(a.Lq + old, q);
+    atomicAdd(a.Jq + best, q);
 }
 
 __global__ void k_leiden_win(LeiArgs a) {
@@ -228,19 +248,30 @@ __global__ void k_leiden_win(LeiArgs a) {
     if (v >= a.b1)
         return;
     const int old = a.label[v], best = a.dec[v - a.b0];
-    int win = 0;
-    if (best != old && a.cmin[old] == v && a.cmin[best] == v) {
-        win = 1;
-        for (int pass = 0; win && pass < (a.use_both ? 2 : 1); pass++) {
+    unsigned char win = 0;
+    if (best != old) {
+        int free_nb = 1;
+        for (int pass = 0; free_nb && pass < (a.use_both ? 2 : 1); pass++) {
             const int *off = pass ? a.g.off_in : a.g.off_out;
             const int *tgt = pass ? a.g.tgt_in : a.g.tgt_out;
             for (int x = off[v]; x < off[v + 1]; x++) {
                 const int w = tgt[x];
                 if (w >= a.b0 && w < v && a.dec[w - a.b0] != a.label[w]) {
-                    win = 0;
+                    free_nb = 0;
                     break;
                 }
             }
+        }
+        if (free_nb) {
+            const double k_v = a.kdeg[v];
+            const unsigned long long q = fx_up(k_v);
+            const double Lo = (double)(a.Lq[old] - q) / LEI_FX, Jc = (double)(a.Jq[best] - q) / LEI_FX;
+            const double gain2 = a.dk[v - a.b0] / a.m +
+                                 a.resolution * k_v * (a.sum_tot[old] - Lo - k_v - a.sum_tot[best] - Jc) / (2.0 * a.m * a.m);
+            const int strict = a.cmin[old] == v && a.cmin[best] == v;
+            win = (unsigned char)((gain2 > 0.0 ? 1 : 0) | (strict ? 2 : 0));
+            if (gain2 > 0.0)
+                atomicAdd(a.out + 1, 1); // safe winners in this round
         }
     }
     a.win[v - a.b0] = win;
@@ -255,12 +286,28 @@ __global__ void k_leiden_apply(LeiArgs a) {
         return;
     a.cmin[old] = 0x7fffffff;
     a.cmin[best] = 0x7fffffff;
-    if (a.win[v - a.b0]) { // winners touch pairwise disjoint communities: plain f64 updates, order-free
-        a.sum_tot[old] -= a.kdeg[v];
-        a.sum_tot[best] += a.kdeg[v];
+    a.Lq[old] = 0;
+    a.Jq[best] = 0;
+    const int use_bit = a.out[1] > 0 ? 1 : 2;
+    if (a.apply_on_device && (a.win[v - a.b0] & use_bit)) {
+        // unweighted graph: degrees are integers, f64 atomic adds are exact → order-free
+        atomicAdd(a.sum_tot + old, -a.kdeg[v]);
+        atomicAdd(a.sum_tot + best, a.kdeg[v]);
         a.label[v] = best;
         atomicAdd(a.out, 1);
     }
+}
+
+// host-ordered application for weighted graphs: scatter the changed entries back
+__global__ void k_scatter_d(double *dst, const int *idx, const double *val, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        dst[idx[i]] = val[i];
+}
+__global__ void k_scatter_i(int *dst, const int *idx, const int *val, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        dst[idx[i]] = val[i];
 }
 
 // weighted_degree (:95-104) and weight_to_community(v, community[v]) (:75-90), list order, f64
@@ -412,18 +459,30 @@ static int distinct(const std::vector<int> &c) {
 }
 
 struct LeiDev {
-    int *label = nullptr, *refined = nullptr, *out = nullptr, *dec = nullptr, *cmin = nullptr, *win = nullptr, *sc = nullptr;
-    double *sum_tot = nullptr, *kdeg = nullptr, *tmp = nullptr, *sw = nullptr;
-    unsigned char *se = nullptr;
+    int *label = nullptr, *refined = nullptr, *out = nullptr, *dec = nullptr, *cmin = nullptr, *sc = nullptr, *sidx = nullptr,
+        *sival = nullptr;
+    unsigned char *win = nullptr, *se = nullptr;
+    double *sum_tot = nullptr, *kdeg = nullptr, *tmp = nullptr, *sw = nullptr, *dk = nullptr, *sdval = nullptr;
+    unsigned long long *Jq = nullptr, *Lq = nullptr;
     ~LeiDev() {
         (void)hipFree(label); (void)hipFree(refined); (void)hipFree(out); (void)hipFree(dec); (void)hipFree(cmin);
         (void)hipFree(win); (void)hipFree(sc); (void)hipFree(sum_tot); (void)hipFree(kdeg); (void)hipFree(tmp);
-        (void)hipFree(sw); (void)hipFree(se);
+        (void)hipFree(sw); (void)hipFree(se); (void)hipFree(dk); (void)hipFree(Jq); (void)hipFree(Lq); (void)hipFree(sidx);
+        (void)hipFree(sival); (void)hipFree(sdval);
     }
 };
 
-// one phase (local moving when part == nullptr, refinement otherwise); returns moves, -1 on error
-static long long run_phase(mn_graph *g, LeiArgs a, int mode, int batch, int64_t *sweeps_out) {
+// host mirrors of the phase's label / sum_tot (weighted graphs: winners are applied here in node order)
+struct HostState {
+    std::vector<int> *label;
+    std::vector<double> *sum_tot;
+    const std::vector<double> *k;
+    int *d_sidx, *d_sival;
+    double *d_sdval;
+};
+
+// one phase (local moving when elig_part == nullptr, refinement otherwise); returns moves, -1 on error
+static long long run_phase(mn_graph *g, LeiArgs a, int mode, int batch, int64_t *sweeps_out, HostState *hs) {
     hipStream_t st = g->stream;
     int out[3] = {0, 0, 0};
     if (mode == MN_LEIDEN_SEQUENTIAL) {
@@ -441,22 +500,73 @@ static long long run_phase(mn_graph *g, LeiArgs a, int mode, int batch, int64_t 
     }
     long long total = 0;
     int improved = 1, sweeps = 0;
+    std::vector<int> h_dec((size_t)batch), ch_idx, ch_ival, touched;
+    std::vector<unsigned char> h_win((size_t)batch);
+    std::vector<double> ch_dval;
     while (improved && sweeps < a.max_sweeps) {
         improved = 0;
         sweeps++;
         GCHK(hipMemsetAsync(a.out, 0, 3 * sizeof(int), st));
+        long long sweep_moves = 0;
         for (int b = 0; b < g->n; b += batch) {
             a.b0 = b;
             a.b1 = b + batch < g->n ? b + batch : g->n;
-            int nb = a.b1 - a.b0;
+            const int nb = a.b1 - a.b0;
+            GCHK(hipMemsetAsync(a.out + 1, 0, sizeof(int), st)); // safe winners of this round
             hipLaunchKernelGGL(k_leiden_eval, dim3(nb), dim3(64), 0, st, a);
             hipLaunchKernelGGL(k_leiden_cmin, dim3((nb + 255) / 256), dim3(256), 0, st, a);
             hipLaunchKernelGGL(k_leiden_win, dim3((nb + 255) / 256), dim3(256), 0, st, a);
-            hipLaunchKernelGGL(k_leiden_apply, dim3((nb + 255) / 256), dim3(256), 0, st, a);
+            ch_idx.clear();
+            ch_ival.clear();
+            touched.clear();
+            if (!a.apply_on_device) {
+                // weighted graph: several winners may share a community and f64 addition is not
+                // associative → apply them here, in node order, on the host mirrors
+                GCHK(hipMemcpyAsync(h_dec.data(), a.dec, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, st));
+                GCHK(hipMemcpyAsync(h_win.data(), a.win, (size_t)nb, hipMemcpyDeviceToHost, st));
+                GCHK(hipMemcpyAsync(out, a.out, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+                GCHK(hipStreamSynchronize(st));
+                const int use_bit = out[1] > 0 ? 1 : 2;
+                std::vector<int> &L = *hs->label;
+                std::vector<double> &S = *hs->sum_tot;
+                for (int v = a.b0; v < a.b1; v++) {
+                    const int old = L[v], best = h_dec[v - a.b0];
+                    if (best != old && (h_win[v - a.b0] & use_bit)) {
+                        S[old] -= (*hs->k)[v];
+                        S[best] += (*hs->k)[v];
+                        L[v] = best;
+                        ch_idx.push_back(v);
+                        ch_ival.push_back(best);
+                        touched.push_back(old);
+                        touched.push_back(best);
+                        sweep_moves++;
+                    }
+                }
+            }
+            hipLaunchKernelGGL(k_leiden_apply, dim3((nb + 255) / 256), dim3(256), 0, st, a); // resets tallies (+ applies)
+            if (!ch_idx.empty()) {
+                int nc = (int)ch_idx.size();
+                GCHK(hipMemcpyAsync(hs->d_sidx, ch_idx.data(), (size_t)nc * sizeof(int), hipMemcpyHostToDevice, st));
+                GCHK(hipMemcpyAsync(hs->d_sival, ch_ival.data(), (size_t)nc * sizeof(int), hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(k_scatter_i, dim3((nc + 255) / 256), dim3(256), 0, st, a.label, hs->d_sidx, hs->d_sival, nc);
+                GCHK(hipStreamSynchronize(st)); // d_sidx is reused for the sum_tot scatter
+                std::sort(touched.begin(), touched.end());
+                touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
+                nc = (int)touched.size();
+                ch_dval.resize((size_t)nc);
+                for (int i = 0; i < nc; i++)
+                    ch_dval[(size_t)i] = (*hs->sum_tot)[touched[(size_t)i]];
+                GCHK(hipMemcpyAsync(hs->d_sidx, touched.data(), (size_t)nc * sizeof(int), hipMemcpyHostToDevice, st));
+                GCHK(hipMemcpyAsync(hs->d_sdval, ch_dval.data(), (size_t)nc * sizeof(double), hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(k_scatter_d, dim3((nc + 255) / 256), dim3(256), 0, st, a.sum_tot, hs->d_sidx, hs->d_sdval, nc);
+                GCHK(hipStreamSynchronize(st));
+            }
         }
         GCHK(hipGetLastError());
         GCHK(hipMemcpyAsync(out, a.out, sizeof(int), hipMemcpyDeviceToHost, st));
         GCHK(hipStreamSynchronize(st));
+        if (!a.apply_on_device)
+            out[0] = (int)sweep_moves;
         if (out[0]) {
             improved = 1;
             total += out[0];
@@ -475,8 +585,12 @@ extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int
         *modularity_out = 0.0;
     if (N == 0)
         return 0;
-    if (mode == MN_LEIDEN_BATCHED && batch <= 1)
-        batch = 65536;
+    if (mode == MN_LEIDEN_BATCHED && batch <= 1) {
+        // few in-batch neighbours per node keeps the rounds close to the sequential sweep: ~N / (2·avg degree)
+        long long avg = N ? (g->e_out + (use_both ? g->e_in : 0)) / N : 1;
+        long long bsz = N / std::max<long long>(8, 2 * avg);
+        batch = (int)std::min<long long>(65536, std::max<long long>(256, bsz));
+    }
     hipStream_t st = g->stream;
     DevGraph dg = {N, g->off_out, g->tgt_out, g->w_out, g->off_in, g->tgt_in, g->w_in};
     LeiDev d;
@@ -490,9 +604,17 @@ extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int
     GCHK(hipMalloc(&d.out, 4 * sizeof(int)));
     if (mode == MN_LEIDEN_BATCHED) {
         GCHK(hipMalloc(&d.dec, (size_t)batch * sizeof(int)));
-        GCHK(hipMalloc(&d.win, (size_t)batch * sizeof(int)));
+        GCHK(hipMalloc(&d.dk, (size_t)batch * sizeof(double)));
+        GCHK(hipMalloc(&d.win, (size_t)batch));
         GCHK(hipMalloc(&d.cmin, (size_t)N * sizeof(int)));
+        GCHK(hipMalloc(&d.Jq, (size_t)N * sizeof(unsigned long long)));
+        GCHK(hipMalloc(&d.Lq, (size_t)N * sizeof(unsigned long long)));
+        GCHK(hipMalloc(&d.sidx, (size_t)(2 * batch + 2) * sizeof(int)));
+        GCHK(hipMalloc(&d.sival, (size_t)(2 * batch + 2) * sizeof(int)));
+        GCHK(hipMalloc(&d.sdval, (size_t)(2 * batch + 2) * sizeof(double)));
         GCHK(hipMemsetAsync(d.cmin, 0x7f, (size_t)N * sizeof(int), st)); // 0x7f7f7f7f > any node index
+        GCHK(hipMemsetAsync(d.Jq, 0, (size_t)N * sizeof(unsigned long long), st));
+        GCHK(hipMemsetAsync(d.Lq, 0, (size_t)N * sizeof(unsigned long long), st));
     }
     if (max_deg > LEI_CAP) {
         GCHK(hipMalloc(&d.sc, (size_t)nslots * max_deg * sizeof(int)));
@@ -536,12 +658,20 @@ extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int
     a.dec = d.dec;
     a.cmin = d.cmin;
     a.win = d.win;
+    a.dk = d.dk;
+    a.Jq = d.Jq;
+    a.Lq = d.Lq;
+    a.apply_on_device = g->weighted ? 0 : 1;
+    std::vector<double> r_sum_tot;
+    HostState hs = {&community, &sum_tot, &k, d.sidx, d.sival, d.sdval};
 
     for (int iter = 0; iter < 100; iter++) { // :368-417
         a.label = d.label;
         a.sum_tot = d.sum_tot;
         a.elig_part = nullptr;
-        long long moves = run_phase(g, a, mode, batch, &g->stats.move_sweeps);
+        hs.label = &community;
+        hs.sum_tot = &sum_tot;
+        long long moves = run_phase(g, a, mode, batch, &g->stats.move_sweeps, &hs);
         if (moves < 0)
             return -1;
         g->stats.iterations++;
@@ -557,7 +687,10 @@ extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int
         a.label = d.refined;
         a.sum_tot = d.tmp;
         a.elig_part = d.label;
-        if (run_phase(g, a, mode, batch, &g->stats.refine_sweeps) < 0)
+        r_sum_tot = k;
+        hs.label = &refined;
+        hs.sum_tot = &r_sum_tot;
+        if (run_phase(g, a, mode, batch, &g->stats.refine_sweeps, &hs) < 0)
             return -1;
         GCHK(hipMemcpyAsync(refined.data(), d.refined, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, st));
         GCHK(hipStreamSynchronize(st));
