@@ -174,6 +174,29 @@ int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int mode, int 
                     double *modularity_out);
 int mn_graph_leiden_stats(mn_graph *g, mn_leiden_stats *out);
 
+/* ---- node2vec.c replacements (a14-a17) ---- */
+typedef struct {
+    int dim;            /* 1..1024 (src/node2vec.c:447) */
+    double p, q;        /* return / in-out parameters */
+    int num_walks, walk_length, window, neg_samples;
+    double learning_rate;
+    int epochs;
+} mn_n2v_params;
+typedef enum {
+    MN_N2V_SEQUENTIAL = 0 /* the reference's single serial SGD stream: output bytes identical to the reference's */
+} mn_n2v_mode;
+typedef struct {
+    int64_t pairs;    /* (center, context) pairs trained */
+    double device_ms;
+} mn_n2v_stats;
+/* The compute of node2vec_train (src/node2vec.c:486-551): sgns_create (rng 42), walks + SGNS, L2 normalisation.
+ * Graph = node2vec.c's own adjacency (first-seen node order, undirected, de-duplicated, :72-138) as CSR:
+ * neighbours of node i are adj[off[i] .. off[i+1]) in list order.  out is host [n][dim] f32 — the vectors the
+ * reference INSERTs with rowid = i + 1 (:575).  Returns n, or -1. */
+int mn_node2vec_train(int n_nodes, const int *off, const int *adj, const mn_n2v_params *prm, int mode, int device, float *out,
+                      mn_n2v_stats *stats);
+const char *mn_node2vec_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

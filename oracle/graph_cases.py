@@ -49,3 +49,20 @@ def leiden_cases():
     c["er500w_r2"] = er(500, 5000, 4, True) + (2.0,)
     c["planted600"] = planted(600, 6, 0.15, 0.005, 7) + (1.0,)
     return c
+
+
+TWO_CLIQUES = [(1, 2), (1, 3), (1, 4), (2, 3), (2, 4), (3, 4), (5, 6), (5, 7), (5, 8), (6, 7), (6, 8), (7, 8), (4, 5)]
+
+
+def n2v_cases():
+    """name -> (edges, (dim, p, q, num_walks, walk_length, window, neg, lr, epochs)); parameters of
+    pytests/test_node2vec.py:160,203,233 plus p/q != 1 variants and a random graph with isolated-ish nodes."""
+    er_s, er_d, _ = er(60, 150, 11)
+    return {
+        "cliques16": (TWO_CLIQUES, (16, 1.0, 1.0, 5, 20, 3, 3, 0.025, 3)),
+        "cliques32": (TWO_CLIQUES, (32, 1.0, 1.0, 10, 40, 5, 5, 0.025, 5)),
+        "cliques_pq": (TWO_CLIQUES, (8, 0.5, 2.0, 4, 15, 2, 2, 0.05, 2)),
+        "karate64": (KARATE, (64, 1.0, 1.0, 10, 80, 5, 5, 0.025, 5)),
+        "karate_pq": (KARATE, (12, 0.25, 4.0, 3, 30, 4, 3, 0.025, 2)),
+        "er60_dim70": ([(int(a), int(b)) for a, b in zip(er_s, er_d)], (70, 2.0, 0.5, 2, 25, 3, 4, 0.03, 1)),
+    }

@@ -386,3 +386,257 @@ double orc_leiden(const orc_graph *g, int *community, double resolution, int use
     free(seen);
     return Q;
 }
+
+/* ───────────────────────── a14-a17: Node2Vec (src/node2vec.c) ───────────────────────── */
+
+static unsigned n2v_xorshift32(unsigned *state) { /* :27-34 */
+    unsigned x = *state;
+    x ^= x << 13;
+    x ^= x >> 17;
+    x ^= x << 5;
+    *state = x;
+    return x;
+}
+
+static double n2v_rand(unsigned *state) { /* :36-38 */
+    return (double)n2v_xorshift32(state) / (double)0xFFFFFFFFu;
+}
+
+int orc_n2v_build_graph(int n_edges, const int *src, const int *dst, int n_ids, int *off, int *adj, int *index_of_id) {
+    /* graph_load_edges (:112-138): node index = first appearance (src before dst), both directions, duplicates dropped */
+    int *idx = (int *)malloc((size_t)(n_ids > 0 ? n_ids : 1) * sizeof(int));
+    for (int i = 0; i < n_ids; i++)
+        idx[i] = -1;
+    int n = 0;
+    int *es = (int *)malloc((size_t)(n_edges > 0 ? n_edges : 1) * sizeof(int));
+    int *ed = (int *)malloc((size_t)(n_edges > 0 ? n_edges : 1) * sizeof(int));
+    for (int e = 0; e < n_edges; e++) {
+        if (idx[src[e]] < 0)
+            idx[src[e]] = n++;
+        if (idx[dst[e]] < 0)
+            idx[dst[e]] = n++;
+        es[e] = idx[src[e]];
+        ed[e] = idx[dst[e]];
+    }
+    /* per-node growable lists with the reference's duplicate check (:96-109) */
+    int **lst = (int **)calloc((size_t)(n > 0 ? n : 1), sizeof(int *));
+    int *cnt = (int *)calloc((size_t)(n > 0 ? n : 1), sizeof(int));
+    int *cap = (int *)calloc((size_t)(n > 0 ? n : 1), sizeof(int));
+    for (int e = 0; e < n_edges; e++)
+        for (int dir = 0; dir < 2; dir++) {
+            int a = dir ? ed[e] : es[e], b = dir ? es[e] : ed[e];
+            int dup = 0;
+            for (int i = 0; i < cnt[a]; i++)
+                if (lst[a][i] == b) {
+                    dup = 1;
+                    break;
+                }
+            if (dup)
+                continue;
+            if (cnt[a] >= cap[a]) {
+                cap[a] = cap[a] ? cap[a] * 2 : 8;
+                lst[a] = (int *)realloc(lst[a], (size_t)cap[a] * sizeof(int));
+            }
+            lst[a][cnt[a]++] = b;
+        }
+    off[0] = 0;
+    for (int i = 0; i < n; i++) {
+        memcpy(adj + off[i], lst[i], (size_t)cnt[i] * sizeof(int));
+        off[i + 1] = off[i] + cnt[i];
+        free(lst[i]);
+    }
+    if (index_of_id)
+        memcpy(index_of_id, idx, (size_t)n_ids * sizeof(int));
+    free(lst);
+    free(cnt);
+    free(cap);
+    free(idx);
+    free(es);
+    free(ed);
+    return n;
+}
+
+static int n2v_is_neighbor(const orc_n2v_graph *g, int node, int target) { /* :154-161 */
+    for (int i = g->off[node]; i < g->off[node + 1]; i++)
+        if (g->adj[i] == target)
+            return 1;
+    return 0;
+}
+
+int orc_biased_walk(const orc_n2v_graph *g, int start, double p, double q, int walk_length, int *walk, unsigned *rng) {
+    walk[0] = start; /* :168-226 */
+    int deg0 = g->off[start + 1] - g->off[start];
+    if (deg0 == 0)
+        return 1;
+    int idx = (int)(n2v_rand(rng) * deg0);
+    if (idx >= deg0)
+        idx = deg0 - 1;
+    walk[1] = g->adj[g->off[start] + idx];
+    for (int step = 2; step < walk_length; step++) {
+        int cur = walk[step - 1], prev = walk[step - 2];
+        int c0 = g->off[cur], deg = g->off[cur + 1] - c0;
+        if (deg == 0)
+            return step;
+        double total = 0.0;
+        for (int i = 0; i < deg; i++) {
+            int x = g->adj[c0 + i];
+            double w = (x == prev) ? 1.0 / p : (n2v_is_neighbor(g, prev, x) ? 1.0 : 1.0 / q);
+            total += w;
+        }
+        double r = n2v_rand(rng) * total;
+        double cum = 0.0;
+        int chosen = g->adj[c0];
+        for (int i = 0; i < deg; i++) {
+            int x = g->adj[c0 + i];
+            double w = (x == prev) ? 1.0 / p : (n2v_is_neighbor(g, prev, x) ? 1.0 : 1.0 / q);
+            cum += w;
+            if (r <= cum) {
+                chosen = x;
+                break;
+            }
+        }
+        walk[step] = chosen;
+    }
+    return walk_length;
+}
+
+#define N2V_SIG_SIZE 1000   /* :241 */
+#define N2V_MAX_SIG 6.0f    /* :242 */
+#define N2V_NEG_TABLE 100000 /* :274 */
+
+static float n2v_sig[N2V_SIG_SIZE + 1];
+static int n2v_sig_ready = 0;
+
+static void n2v_init_sig(void) { /* :247-258 */
+    if (n2v_sig_ready)
+        return;
+    for (int i = 0; i <= N2V_SIG_SIZE; i++) {
+        float x = (float)i / (float)N2V_SIG_SIZE * 2.0f * N2V_MAX_SIG - N2V_MAX_SIG;
+        n2v_sig[i] = 1.0f / (1.0f + expf(-x));
+    }
+    n2v_sig_ready = 1;
+}
+
+static float n2v_fast_sigmoid(float x) { /* :260-271 */
+    if (x >= N2V_MAX_SIG)
+        return 1.0f;
+    if (x <= -N2V_MAX_SIG)
+        return 0.0f;
+    int idx = (int)((x + N2V_MAX_SIG) / (2.0f * N2V_MAX_SIG) * N2V_SIG_SIZE);
+    if (idx < 0)
+        idx = 0;
+    if (idx > N2V_SIG_SIZE)
+        idx = N2V_SIG_SIZE;
+    return n2v_sig[idx];
+}
+
+const float *orc_n2v_sigmoid_table(void) {
+    n2v_init_sig();
+    return n2v_sig;
+}
+
+void orc_n2v_neg_table(const orc_n2v_graph *g, int *table) { /* build_neg_table :284-303 */
+    int N = g->n;
+    double total = 0.0;
+    for (int i = 0; i < N; i++)
+        total += pow((double)(g->off[i + 1] - g->off[i] + 1), 0.75);
+    int idx = 0;
+    double cum = 0.0;
+    for (int i = 0; i < N && idx < N2V_NEG_TABLE; i++) {
+        cum += pow((double)(g->off[i + 1] - g->off[i] + 1), 0.75) / total;
+        while (idx < N2V_NEG_TABLE && (double)idx / N2V_NEG_TABLE < cum)
+            table[idx++] = i;
+    }
+    while (idx < N2V_NEG_TABLE)
+        table[idx++] = N - 1;
+}
+
+/* sgns_train_pair (:345-394) */
+static void n2v_train_pair(float *syn0, float *syn1neg, const int *neg_table, int dim, int center, int context, int neg,
+                           float lr, unsigned *rng, float *neu1e) {
+    float *vc = syn0 + (size_t)center * dim;
+    memset(neu1e, 0, (size_t)dim * sizeof(float));
+    for (int s = 0; s <= neg; s++) {
+        int target;
+        float label;
+        if (s == 0) {
+            target = context;
+            label = 1.0f;
+        } else {
+            target = neg_table[n2v_xorshift32(rng) % N2V_NEG_TABLE];
+            if (target == center || target == context)
+                continue;
+            label = 0.0f;
+        }
+        float *vt = syn1neg + (size_t)target * dim;
+        float dot = 0.0f;
+        for (int d = 0; d < dim; d++)
+            dot += vc[d] * vt[d];
+        float sig = n2v_fast_sigmoid(dot);
+        float err = (label - sig) * lr;
+        for (int d = 0; d < dim; d++)
+            neu1e[d] += err * vt[d];
+        for (int d = 0; d < dim; d++)
+            vt[d] += err * vc[d];
+    }
+    for (int d = 0; d < dim; d++)
+        vc[d] += neu1e[d];
+}
+
+int orc_node2vec_train(const orc_n2v_graph *g, const orc_n2v_params *p, float *out, int64_t *n_pairs) {
+    int N = g->n, dim = p->dim;
+    if (N == 0)
+        return 0;
+    n2v_init_sig();
+    unsigned rng = 42; /* :486 */
+    float *syn0 = out;
+    float *syn1neg = (float *)calloc((size_t)N * dim, sizeof(float));
+    int *neg_table = (int *)malloc(N2V_NEG_TABLE * sizeof(int));
+    float *neu1e = (float *)malloc((size_t)dim * sizeof(float));
+    int *walk = (int *)malloc((size_t)p->walk_length * sizeof(int));
+    for (int i = 0; i < N * dim; i++) /* :323-325 */
+        syn0[i] = ((float)n2v_rand(&rng) - 0.5f) / (float)dim;
+    orc_n2v_neg_table(g, neg_table);
+    int total_words = N * p->num_walks * p->walk_length * p->epochs; /* :503 (32-bit, as the reference) */
+    int word_count = 0;
+    int64_t pairs = 0;
+    for (int epoch = 0; epoch < p->epochs; epoch++)
+        for (int w = 0; w < p->num_walks; w++)
+            for (int n = 0; n < N; n++) {
+                float lr = (float)(p->lr * (1.0 - (double)word_count / (double)total_words)); /* :510-512 */
+                if (lr < (float)(p->lr * 0.0001))
+                    lr = (float)(p->lr * 0.0001);
+                int wlen = orc_biased_walk(g, n, p->p, p->q, p->walk_length, walk, &rng);
+                for (int pos = 0; pos < wlen; pos++) {
+                    int cs = pos - p->window, ce = pos + p->window;
+                    if (cs < 0)
+                        cs = 0;
+                    if (ce >= wlen)
+                        ce = wlen - 1;
+                    for (int c = cs; c <= ce; c++) {
+                        if (c == pos)
+                            continue;
+                        n2v_train_pair(syn0, syn1neg, neg_table, dim, walk[pos], walk[c], p->neg_samples, lr, &rng, neu1e);
+                        pairs++;
+                    }
+                    word_count++;
+                }
+            }
+    for (int i = 0; i < N; i++) { /* :540-551 */
+        float *emb = syn0 + (size_t)i * dim;
+        float norm = 0.0f;
+        for (int d = 0; d < dim; d++)
+            norm += emb[d] * emb[d];
+        norm = sqrtf(norm);
+        if (norm > 1e-10f)
+            for (int d = 0; d < dim; d++)
+                emb[d] /= norm;
+    }
+    if (n_pairs)
+        *n_pairs = pairs;
+    free(syn1neg);
+    free(neg_table);
+    free(neu1e);
+    free(walk);
+    return N;
+}

@@ -29,6 +29,31 @@ double orc_leiden(const orc_graph *g, int *community, double resolution, int use
 /* compute_modularity (src/graph_community.c:109-142) */
 double orc_modularity(const orc_graph *g, const int *community, double resolution, double m, int use_both);
 
+/* ---- a14-a17: Node2Vec (src/node2vec.c) ----
+ * Undirected, de-duplicated adjacency in first-seen node order (graph_node_index / graph_add_edge,
+ * src/node2vec.c:72-109) given as CSR: neighbours of node i are adj[off[i] .. off[i+1]) in list order. */
+typedef struct {
+    int n;
+    const int *off, *adj;
+} orc_n2v_graph;
+
+typedef struct {
+    int dim;
+    double p, q;
+    int num_walks, walk_length, window, neg_samples;
+    double lr;
+    int epochs;
+} orc_n2v_params;
+
+/* node2vec_train's compute (src/node2vec.c:486-551): sgns_create (rng 42), the serial walk + SGNS stream,
+ * then L2 normalisation.  out is [n][dim] f32 — the bytes the reference INSERTs into the output table. */
+int orc_node2vec_train(const orc_n2v_graph *g, const orc_n2v_params *p, float *out, int64_t *n_pairs);
+/* biased_walk (src/node2vec.c:168-226) from an explicit rng state; returns the walk length */
+int orc_biased_walk(const orc_n2v_graph *g, int start, double p, double q, int walk_length, int *walk, unsigned *rng);
+/* Builds the reference's Graph from an edge list (first-seen indices, undirected, de-duplicated);
+ * returns n; off must hold n_max+1 ints, adj 2*n_edges ints, index_of_id n_ids ints (or NULL). */
+int orc_n2v_build_graph(int n_edges, const int *src, const int *dst, int n_ids, int *off, int *adj, int *index_of_id);
+
 #ifdef __cplusplus
 }
 #endif

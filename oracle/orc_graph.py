@@ -122,3 +122,87 @@ def ref_leiden(src, dst, w=None, direction="both", resolution=1.0):
     q = _ref.ref_leiden_edges(n_ids, len(src), src, dst, wv.ctypes.data if wv is not None else None, d, float(resolution), idx,
                               comm, C.byref(nn))
     return comm[:nn.value].copy(), q, idx[:n_ids].copy()
+
+
+# ───────────────────────── Node2Vec ─────────────────────────
+
+class _N2vGraph(C.Structure):
+    _fields_ = [("n", C.c_int), ("off", C.c_void_p), ("adj", C.c_void_p)]
+
+
+class _N2vParams(C.Structure):
+    _fields_ = [("dim", C.c_int), ("p", C.c_double), ("q", C.c_double), ("num_walks", C.c_int), ("walk_length", C.c_int),
+                ("window", C.c_int), ("neg_samples", C.c_int), ("lr", C.c_double), ("epochs", C.c_int)]
+
+
+def _n2v_lib():
+    L = _lib()
+    if not getattr(L, "_n2v_bound", False):
+        L.orc_n2v_build_graph.argtypes = [C.c_int, _i32p, _i32p, C.c_int, _i32p, _i32p, _i32p]
+        L.orc_node2vec_train.argtypes = [C.POINTER(_N2vGraph), C.POINTER(_N2vParams), np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS"),
+                                         C.POINTER(C.c_int64)]
+        L.orc_biased_walk.argtypes = [C.POINTER(_N2vGraph), C.c_int, C.c_double, C.c_double, C.c_int, _i32p, C.POINTER(C.c_uint)]
+        L.orc_n2v_sigmoid_table.restype = C.POINTER(C.c_float)
+        L.orc_n2v_neg_table.argtypes = [C.POINTER(_N2vGraph), _i32p]
+        L._n2v_bound = True
+    return L
+
+
+class N2vGraph:
+    """node2vec.c's Graph (first-seen node order, undirected, de-duplicated) as CSR."""
+
+    def __init__(self, src, dst):
+        src = np.ascontiguousarray(src, np.int32)
+        dst = np.ascontiguousarray(dst, np.int32)
+        n_ids = int(max(src.max(), dst.max())) + 1 if len(src) else 0
+        off = np.zeros(n_ids + 2, np.int32)
+        adj = np.zeros(max(1, 2 * len(src)), np.int32)
+        idx = np.full(max(1, n_ids), -1, np.int32)
+        self.n = _n2v_lib().orc_n2v_build_graph(len(src), src, dst, n_ids, off, adj, idx)
+        self.off = off[:self.n + 1].copy()
+        self.adj = adj[:self.off[-1]].copy() if self.n else np.zeros(0, np.int32)
+        self.index_of_id = idx[:n_ids]
+
+    def c_struct(self):
+        g = _N2vGraph()
+        g.n = self.n
+        g.off = self.off.ctypes.data
+        g.adj = self.adj.ctypes.data
+        return g
+
+
+def node2vec_train(g: N2vGraph, dim, p, q, num_walks, walk_length, window, neg, lr, epochs):
+    """→ (embeddings [n][dim] f32 L2-normalised, number of (center, context) pairs)"""
+    out = np.zeros((max(g.n, 1), dim), np.float32)
+    prm = _N2vParams(dim, p, q, num_walks, walk_length, window, neg, lr, epochs)
+    cg = g.c_struct()
+    npairs = C.c_int64(0)
+    _n2v_lib().orc_node2vec_train(C.byref(cg), C.byref(prm), out, C.byref(npairs))
+    return out[:g.n], npairs.value
+
+
+def biased_walk(g: N2vGraph, start, p, q, walk_length, rng_state):
+    walk = np.zeros(walk_length, np.int32)
+    st = C.c_uint(rng_state)
+    cg = g.c_struct()
+    n = _n2v_lib().orc_biased_walk(C.byref(cg), start, p, q, walk_length, walk, C.byref(st))
+    return walk[:n].copy(), st.value
+
+
+def ref_node2vec_sql(edges, dim, p, q, num_walks, walk_length, window, neg, lr, epochs):
+    """The reference's node2vec_train through its own SQL surface (oracle/_ref/muninn.so): returns the
+    embedding bytes it INSERTs (read back from the output table's _nodes shadow table), in rowid order."""
+    import sqlite3
+
+    c = sqlite3.connect(":memory:")
+    c.enable_load_extension(True)
+    c.load_extension(orc.REF_EXT)
+    c.execute("CREATE TABLE e (src TEXT, dst TEXT)")
+    c.executemany("INSERT INTO e VALUES (?, ?)", [(str(a), str(b)) for a, b in edges])
+    c.execute(f"CREATE VIRTUAL TABLE emb USING hnsw_index(dimensions={dim}, metric='cosine', m=8, ef_construction=50)")
+    n = c.execute("SELECT node2vec_train('e', 'src', 'dst', 'emb', ?, ?, ?, ?, ?, ?, ?, ?, ?)",
+                  (dim, p, q, num_walks, walk_length, window, neg, lr, epochs)).fetchone()[0]
+    rows = c.execute("SELECT id, vector FROM emb_nodes ORDER BY id").fetchall()
+    c.close()
+    assert n == len(rows)
+    return np.array([np.frombuffer(r[1], np.float32) for r in rows], np.float32).reshape(n, dim)

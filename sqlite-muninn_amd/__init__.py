@@ -11,4 +11,4 @@ from .build import LIB, build  # noqa: F401
 from .hnsw import (BUILD_BATCHED, BUILD_SEQUENTIAL, METRIC, ORDER_SSE, ORDER_WAVE, HnswIndex, MuninnHipError,  # noqa: F401
                    device_count, lib, vec_dist_batch, vec_parse_metric)
 from . import graph  # noqa: E402,F401
-from .graph import LEIDEN_BATCHED, LEIDEN_SEQUENTIAL, Graph  # noqa: E402,F401
+from .graph import LEIDEN_BATCHED, LEIDEN_SEQUENTIAL, N2V_SEQUENTIAL, Graph, node2vec_train  # noqa: E402,F401

@@ -1,0 +1,427 @@
+// mn_n2v.hip — Node2Vec biased walks + skip-gram negative sampling (src/node2vec.c:154-394,:486-551)
+// on gfx950.
+//
+// The reference is ONE serial stochastic-gradient stream: a single xorshift32 state feeds the walk
+// sampler and the negative sampler alike (:486,:514,:529), every pair updates the embedding rows in
+// place, and every f32 dot product is a left-to-right chain over d (:372-375).
+//   k_n2v_seq (MN_N2V_SEQUENTIAL)  one wavefront replays that stream exactly: lanes parallelise inside
+//        a step (transition weights of the ≤deg neighbours, is_neighbor scans, the dim products, the
+//        row updates) while every order-sensitive reduction (Σ weights in f64, the dot chain in f32)
+//        is carried out in the reference's order.  Embedding rows are accessed with agent-scope
+//        relaxed atomics (L2-served) because the wavefront re-reads rows it has just written.
+//        Output bytes are identical to what the reference INSERTs into the output table.
+//   k_n2v_normalize                L2 normalisation (:540-551), one wavefront per row, same chain order.
+// Host side prepares exactly what the reference prepares serially before training: syn0 from the RNG
+// stream (:323-325), the (deg+1)^0.75 negative table (:284-303, f64 pow) and the 1001-entry sigmoid
+// LUT (:247-258, expf) — these are inputs of the hot loop, not part of it.
+#include "../../include/muninn_hip.h"
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define DEVI __device__ __forceinline__
+#define N2V_SIG_SIZE 1000
+#define N2V_MAX_SIG 6.0f
+#define N2V_NEG_TABLE 100000
+#define N2V_LDS_DEG 2048
+#define N2V_LDS_WALK 4096
+
+DEVI unsigned xs32(unsigned &s) { // :27-34
+    unsigned x = s;
+    x ^= x << 13;
+    x ^= x >> 17;
+    x ^= x << 5;
+    s = x;
+    return x;
+}
+DEVI double xs_rand(unsigned &s) { return (double)xs32(s) / (double)0xFFFFFFFFu; } // :36-38
+
+DEVI float ldf(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// running-total array of one walk step: LDS when it fits, else global scratch through L2 (sc1)
+DEVI double cum_ld(const double *lds, const double *glb, bool in_lds, int i) {
+    return in_lds ? lds[i] : __hip_atomic_load(glb + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+DEVI void cum_st(double *lds, double *glb, bool in_lds, int i, double v) {
+    if (in_lds)
+        lds[i] = v;
+    else
+        __hip_atomic_store(glb + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+DEVI void stf(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct N2vArgs {
+    int n;
+    const int *off, *adj;
+    float *syn0, *syn1neg;
+    const int *neg_table;
+    const float *sig_table;
+    int dim, num_walks, walk_length, window, neg, epochs;
+    double p, q, lr;
+    unsigned rng;
+    double *cum_scratch; // [max_deg] for nodes with more than N2V_LDS_DEG neighbours
+    int *walk_scratch;   // [walk_length] when longer than N2V_LDS_WALK
+    unsigned long long *out; // [0] pairs, [1] final rng
+};
+
+DEVI float fast_sigmoid(const float *tab, float x) { // :260-271
+    if (x >= N2V_MAX_SIG)
+        return 1.0f;
+    if (x <= -N2V_MAX_SIG)
+        return 0.0f;
+    int idx = (int)((x + N2V_MAX_SIG) / (2.0f * N2V_MAX_SIG) * N2V_SIG_SIZE);
+    if (idx < 0)
+        idx = 0;
+    if (idx > N2V_SIG_SIZE)
+        idx = N2V_SIG_SIZE;
+    return tab[idx];
+}
+
+__global__ void __launch_bounds__(64) k_n2v_seq(N2vArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    double *cum_l = reinterpret_cast<double *>(smem);            // [N2V_LDS_DEG]
+    float *prod = reinterpret_cast<float *>(cum_l + N2V_LDS_DEG); // [dim]
+    float *vc = prod + a.dim;                                     // [dim]
+    float *neu = vc + a.dim;                                      // [dim]
+    float *sig = neu + a.dim;                                     // [1001]
+    int *walk_l = reinterpret_cast<int *>(sig + N2V_SIG_SIZE + 1);
+    int *walk = a.walk_length <= N2V_LDS_WALK ? walk_l : a.walk_scratch;
+    for (int i = lane; i <= N2V_SIG_SIZE; i += 64)
+        sig[i] = a.sig_table[i];
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+
+    unsigned rng = a.rng;
+    const int dim = a.dim;
+    const int total_words = a.n * a.num_walks * a.walk_length * a.epochs; // :503 — 32-bit, as the reference
+    int word_count = 0;
+    unsigned long long pairs = 0;
+    for (int epoch = 0; epoch < a.epochs; epoch++)
+        for (int w = 0; w < a.num_walks; w++)
+            for (int n = 0; n < a.n; n++) {
+                float lr = (float)(a.lr * (1.0 - (double)word_count / (double)total_words)); // :510-512
+                if (lr < (float)(a.lr * 0.0001))
+                    lr = (float)(a.lr * 0.0001);
+                // ── biased_walk (:168-226) ──
+                int wlen;
+                {
+                    if (lane == 0)
+                        walk[0] = n;
+                    const int s0 = a.off[n], deg0 = a.off[n + 1] - s0;
+                    if (deg0 == 0) {
+                        wlen = 1;
+                    } else {
+                        int idx = (int)(xs_rand(rng) * deg0);
+                        if (idx >= deg0)
+                            idx = deg0 - 1;
+                        int cur = a.adj[s0 + idx], prev = n;
+                        if (lane == 0)
+                            walk[1] = cur;
+                        wlen = a.walk_length;
+                        for (int step = 2; step < a.walk_length; step++) {
+                            const int c0 = a.off[cur], deg = a.off[cur + 1] - c0;
+                            if (deg == 0) {
+                                wlen = step;
+                                break;
+                            }
+                            const bool in_lds = deg <= N2V_LDS_DEG;
+                            const int p0 = a.off[prev], degp = a.off[prev + 1] - p0;
+                            __builtin_amdgcn_wave_barrier();
+                            for (int i = lane; i < deg; i += 64) { // transition weights, :186-195
+                                const int x = a.adj[c0 + i];
+                                double wt;
+                                if (x == prev) {
+                                    wt = 1.0 / a.p;
+                                } else {
+                                    bool nb = false;
+                                    for (int j = 0; j < degp; j++)
+                                        if (a.adj[p0 + j] == x) {
+                                            nb = true;
+                                            break;
+                                        }
+                                    wt = nb ? 1.0 : 1.0 / a.q;
+                                }
+                                cum_st(cum_l, a.cum_scratch, in_lds, i, wt);
+                            }
+                            __builtin_amdgcn_s_waitcnt(0);
+                            __builtin_amdgcn_wave_barrier();
+                            if (lane == 0) { // Σ in list order, f64 (:196, :213) → running totals
+                                double t = 0.0;
+                                for (int i = 0; i < deg; i++) {
+                                    t += cum_ld(cum_l, a.cum_scratch, in_lds, i);
+                                    cum_st(cum_l, a.cum_scratch, in_lds, i, t);
+                                }
+                            }
+                            __builtin_amdgcn_s_waitcnt(0);
+                            __builtin_amdgcn_wave_barrier();
+                            const double total = cum_ld(cum_l, a.cum_scratch, in_lds, deg - 1);
+                            const double r = xs_rand(rng) * total; // :200
+                            int chosen_i = 0x7fffffff;
+                            for (int i = lane; i < deg; i += 64)
+                                if (r <= cum_ld(cum_l, a.cum_scratch, in_lds, i)) { // first i with r <= cumulative (:214-217)
+                                    chosen_i = i;
+                                    break;
+                                }
+                            for (int m = 32; m >= 1; m >>= 1) {
+                                int o = __shfl_xor(chosen_i, m);
+                                chosen_i = o < chosen_i ? o : chosen_i;
+                            }
+                            const int chosen = chosen_i == 0x7fffffff ? a.adj[c0] : a.adj[c0 + chosen_i]; // fallback :202
+                            if (lane == 0)
+                                walk[step] = chosen;
+                            prev = cur;
+                            cur = chosen;
+                        }
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_wave_barrier();
+                // ── skip-gram over the walk (:517-533) ──
+                for (int pos = 0; pos < wlen; pos++) {
+                    const int center = walk[pos];
+                    int cs = pos - a.window, ce = pos + a.window;
+                    if (cs < 0)
+                        cs = 0;
+                    if (ce >= wlen)
+                        ce = wlen - 1;
+                    float *rowc = a.syn0 + (size_t)center * dim;
+                    for (int c = cs; c <= ce; c++) {
+                        if (c == pos)
+                            continue;
+                        const int context = walk[c];
+                        // sgns_train_pair (:345-394)
+                        __builtin_amdgcn_wave_barrier();
+                        for (int d = lane; d < dim; d += 64) {
+                            vc[d] = ldf(rowc + d);
+                            neu[d] = 0.0f;
+                        }
+                        for (int s = 0; s <= a.neg; s++) {
+                            int target;
+                            float label;
+                            if (s == 0) {
+                                target = context;
+                                label = 1.0f;
+                            } else {
+                                target = a.neg_table[xs32(rng) % N2V_NEG_TABLE];
+                                if (target == center || target == context)
+                                    continue; // the draw is consumed first (:361-363)
+                                label = 0.0f;
+                            }
+                            float *rowt = a.syn1neg + (size_t)target * dim;
+                            __builtin_amdgcn_s_waitcnt(0);
+                            __builtin_amdgcn_wave_barrier();
+                            float vt_reg[16]; // dim <= 1024 → at most 16 elements per lane
+                            for (int d = lane, r = 0; d < dim; d += 64, r++) {
+                                vt_reg[r] = ldf(rowt + d);
+                                prod[d] = __fmul_rn(vc[d], vt_reg[r]);
+                            }
+                            __builtin_amdgcn_s_waitcnt(0);
+                            __builtin_amdgcn_wave_barrier();
+                            float dot = 0.0f; // left-to-right chain (:372-375), every lane redundantly
+                            for (int d = 0; d < dim; d++)
+                                dot = __fadd_rn(dot, prod[d]);
+                            const float sg = fast_sigmoid(sig, dot);
+                            const float err = __fmul_rn(__fsub_rn(label, sg), lr);
+                            for (int d = lane, r = 0; d < dim; d += 64, r++) {
+                                neu[d] = __fadd_rn(neu[d], __fmul_rn(err, vt_reg[r]));  // :382-384
+                                stf(rowt + d, __fadd_rn(vt_reg[r], __fmul_rn(err, vc[d]))); // :386-388
+                            }
+                        }
+                        __builtin_amdgcn_s_waitcnt(0);
+                        __builtin_amdgcn_wave_barrier();
+                        for (int d = lane; d < dim; d += 64) // :391-393
+                            stf(rowc + d, __fadd_rn(vc[d], neu[d]));
+                        __builtin_amdgcn_s_waitcnt(0);
+                        pairs++;
+                    }
+                    word_count++;
+                }
+            }
+    if (lane == 0) {
+        a.out[0] = pairs;
+        a.out[1] = rng;
+    }
+}
+
+// :540-551 — one wavefront per row; the Σ emb[d]² chain in d order
+__global__ void __launch_bounds__(64) k_n2v_normalize(float *syn0, int n, int dim) {
+    extern __shared__ float row[];
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= n)
+        return;
+    float *emb = syn0 + (size_t)i * dim;
+    for (int d = lane; d < dim; d += 64)
+        row[d] = emb[d];
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    float norm = 0.0f;
+    for (int d = 0; d < dim; d++)
+        norm = __fadd_rn(norm, __fmul_rn(row[d], row[d]));
+    norm = sqrtf(norm);
+    if (norm > 1e-10f)
+        for (int d = lane; d < dim; d += 64)
+            emb[d] = __fdiv_rn(row[d], norm);
+}
+
+// ───────────────────────── host ─────────────────────────
+
+static thread_local std::string g_nerr;
+static void nset_err(const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_nerr = buf;
+}
+extern "C" const char *mn_node2vec_last_error(void) { return g_nerr.c_str(); }
+
+#define NCHK(expr)                                                                                 \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess) {                                                                   \
+            nset_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return -1;                                                                             \
+        }                                                                                          \
+    } while (0)
+
+static unsigned h_xs32(unsigned *s) {
+    unsigned x = *s;
+    x ^= x << 13;
+    x ^= x >> 17;
+    x ^= x << 5;
+    *s = x;
+    return x;
+}
+
+struct N2vDev {
+    int *off = nullptr, *adj = nullptr, *neg = nullptr, *walk = nullptr;
+    float *syn0 = nullptr, *syn1 = nullptr, *sig = nullptr;
+    double *cum = nullptr;
+    unsigned long long *out = nullptr;
+    ~N2vDev() {
+        (void)hipFree(off); (void)hipFree(adj); (void)hipFree(neg); (void)hipFree(walk); (void)hipFree(syn0);
+        (void)hipFree(syn1); (void)hipFree(sig); (void)hipFree(cum); (void)hipFree(out);
+    }
+};
+
+extern "C" int mn_node2vec_train(int n, const int *off, const int *adj, const mn_n2v_params *prm, int mode, int device,
+                                 float *out, mn_n2v_stats *stats) {
+    if (stats)
+        memset(stats, 0, sizeof(*stats));
+    if (n == 0)
+        return 0;
+    if (!prm || prm->dim <= 0 || prm->dim > 1024 || prm->p <= 0 || prm->q <= 0 || prm->num_walks <= 0 ||
+        prm->walk_length <= 0 || prm->window <= 0 || prm->neg_samples <= 0 || prm->learning_rate <= 0 || prm->epochs <= 0) {
+        nset_err("mn_node2vec_train: invalid parameters (src/node2vec.c:443-464)");
+        return -1;
+    }
+    if (mode != MN_N2V_SEQUENTIAL) {
+        nset_err("mn_node2vec_train: mode %d not available", mode);
+        return -1;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        nset_err("mn_node2vec_train: HIP device %d not available (no CPU fallback)", device);
+        return -1;
+    }
+    NCHK(hipSetDevice(device));
+    const int dim = prm->dim;
+    const size_t nd = (size_t)n * dim;
+    // inputs of the hot loop, prepared as the reference prepares them (sgns_create, :305-330)
+    unsigned rng = 42; // :486
+    std::vector<float> syn0(nd);
+    for (size_t i = 0; i < nd; i++) // :323-325
+        syn0[i] = ((float)((double)h_xs32(&rng) / (double)0xFFFFFFFFu) - 0.5f) / (float)dim;
+    std::vector<int> neg(N2V_NEG_TABLE);
+    {
+        double total = 0.0; // :284-303
+        for (int i = 0; i < n; i++)
+            total += pow((double)(off[i + 1] - off[i] + 1), 0.75);
+        int idx = 0;
+        double cum = 0.0;
+        for (int i = 0; i < n && idx < N2V_NEG_TABLE; i++) {
+            cum += pow((double)(off[i + 1] - off[i] + 1), 0.75) / total;
+            while (idx < N2V_NEG_TABLE && (double)idx / N2V_NEG_TABLE < cum)
+                neg[idx++] = i;
+        }
+        while (idx < N2V_NEG_TABLE)
+            neg[idx++] = n - 1;
+    }
+    std::vector<float> sig(N2V_SIG_SIZE + 1);
+    for (int i = 0; i <= N2V_SIG_SIZE; i++) { // :247-258
+        float x = (float)i / (float)N2V_SIG_SIZE * 2.0f * N2V_MAX_SIG - N2V_MAX_SIG;
+        sig[i] = 1.0f / (1.0f + expf(-x));
+    }
+    int max_deg = 0;
+    for (int i = 0; i < n; i++)
+        max_deg = std::max(max_deg, off[i + 1] - off[i]);
+    const size_t ne = (size_t)off[n];
+    N2vDev d;
+    NCHK(hipMalloc(&d.off, ((size_t)n + 1) * sizeof(int)));
+    NCHK(hipMalloc(&d.adj, std::max<size_t>(1, ne) * sizeof(int)));
+    NCHK(hipMalloc(&d.neg, N2V_NEG_TABLE * sizeof(int)));
+    NCHK(hipMalloc(&d.sig, (N2V_SIG_SIZE + 1) * sizeof(float)));
+    NCHK(hipMalloc(&d.syn0, nd * sizeof(float)));
+    NCHK(hipMalloc(&d.syn1, nd * sizeof(float)));
+    NCHK(hipMalloc(&d.cum, (size_t)std::max(1, max_deg) * sizeof(double)));
+    NCHK(hipMalloc(&d.walk, (size_t)prm->walk_length * sizeof(int)));
+    NCHK(hipMalloc(&d.out, 2 * sizeof(unsigned long long)));
+    NCHK(hipMemcpy(d.off, off, ((size_t)n + 1) * sizeof(int), hipMemcpyHostToDevice));
+    if (ne)
+        NCHK(hipMemcpy(d.adj, adj, ne * sizeof(int), hipMemcpyHostToDevice));
+    NCHK(hipMemcpy(d.neg, neg.data(), N2V_NEG_TABLE * sizeof(int), hipMemcpyHostToDevice));
+    NCHK(hipMemcpy(d.sig, sig.data(), sig.size() * sizeof(float), hipMemcpyHostToDevice));
+    NCHK(hipMemcpy(d.syn0, syn0.data(), nd * sizeof(float), hipMemcpyHostToDevice));
+    NCHK(hipMemset(d.syn1, 0, nd * sizeof(float)));
+    N2vArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n = n;
+    a.off = d.off;
+    a.adj = d.adj;
+    a.syn0 = d.syn0;
+    a.syn1neg = d.syn1;
+    a.neg_table = d.neg;
+    a.sig_table = d.sig;
+    a.dim = dim;
+    a.num_walks = prm->num_walks;
+    a.walk_length = prm->walk_length;
+    a.window = prm->window;
+    a.neg = prm->neg_samples;
+    a.epochs = prm->epochs;
+    a.p = prm->p;
+    a.q = prm->q;
+    a.lr = prm->learning_rate;
+    a.rng = rng;
+    a.cum_scratch = d.cum;
+    a.walk_scratch = d.walk;
+    a.out = d.out;
+    hipEvent_t e0, e1;
+    NCHK(hipEventCreate(&e0));
+    NCHK(hipEventCreate(&e1));
+    size_t lds = N2V_LDS_DEG * sizeof(double) + 3 * (size_t)dim * sizeof(float) + (N2V_SIG_SIZE + 1) * sizeof(float) +
+                 (size_t)std::min(prm->walk_length, N2V_LDS_WALK) * sizeof(int) + 64;
+    NCHK(hipEventRecord(e0, nullptr));
+    hipLaunchKernelGGL(k_n2v_seq, dim3(1), dim3(64), lds, nullptr, a);
+    NCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_n2v_normalize, dim3(n), dim3(64), (size_t)dim * sizeof(float), nullptr, d.syn0, n, dim);
+    NCHK(hipEventRecord(e1, nullptr));
+    NCHK(hipDeviceSynchronize());
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    unsigned long long o[2];
+    NCHK(hipMemcpy(o, d.out, sizeof(o), hipMemcpyDeviceToHost));
+    NCHK(hipMemcpy(out, d.syn0, nd * sizeof(float), hipMemcpyDeviceToHost));
+    if (stats) {
+        stats->pairs = (int64_t)o[0];
+        stats->device_ms = ms;
+    }
+    return n;
+}

@@ -1,0 +1,101 @@
+"""Node2Vec (src/node2vec.c): the oracle's serial restatement against the embedding bytes the compiled
+reference produced through its own SQL function (tests/golden/node2vec.npz), and the HIP sequential
+kernel against the same bytes.  Plus the reference's statistical acceptance tests
+(pytests/test_node2vec.py:194-273)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import orc_graph as og
+from oracle.graph_cases import n2v_cases
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = n2v_cases()
+
+
+def _graph(edges):
+    e = np.array(edges, np.int32)
+    return og.N2vGraph(e[:, 0], e[:, 1])
+
+
+def _within_between(emb, index_of_id, a_ids, b_ids):
+    def cos(x, y):
+        return float(np.dot(x, y) / (np.linalg.norm(x) * np.linalg.norm(y)))
+
+    A = [emb[index_of_id[i]] for i in a_ids]
+    B = [emb[index_of_id[i]] for i in b_ids]
+    within = [cos(A[i], A[j]) for i in range(len(A)) for j in range(i + 1, len(A))]
+    within += [cos(B[i], B[j]) for i in range(len(B)) for j in range(i + 1, len(B))]
+    between = [cos(x, y) for x in A for y in B]
+    return np.mean(within), np.mean(between)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_bytes_equal_reference(name):
+    z = np.load(os.path.join(G, "node2vec.npz"))
+    edges, prm = CASES[name]
+    emb, npairs = og.node2vec_train(_graph(edges), *prm)
+    assert np.array_equal(emb.view(np.int32), z[name]), name
+
+
+def test_first_seen_dedup_graph():
+    """graph_load_edges (src/node2vec.c:112-138): first-seen indices, both directions, duplicates dropped"""
+    g = og.N2vGraph(np.array([5, 5, 7, 2], np.int32), np.array([7, 7, 5, 5], np.int32))
+    assert g.n == 3 and g.index_of_id[5] == 0 and g.index_of_id[7] == 1 and g.index_of_id[2] == 2
+    assert g.off.tolist() == [0, 2, 3, 4] and g.adj.tolist() == [1, 2, 0, 0]
+
+
+def test_acceptance_karate_within_gt_between():
+    edges, prm = CASES["karate64"]
+    g = _graph(edges)
+    emb, _ = og.node2vec_train(g, *prm)
+    a = [1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 17, 18, 20, 22]
+    b = [9, 10, 15, 16, 19, 21, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34]
+    w, bt = _within_between(emb, g.index_of_id, a, b)
+    assert w > bt
+
+
+def test_walk_properties():
+    edges, _ = CASES["karate64"]
+    g = _graph(edges)
+    walk, st = og.biased_walk(g, 0, 0.5, 2.0, 40, 12345)
+    assert len(walk) == 40 and walk[0] == 0
+    for a, b in zip(walk[:-1], walk[1:]):
+        assert b in g.adj[g.off[a]:g.off[a + 1]]
+    walk2, st2 = og.biased_walk(g, 0, 0.5, 2.0, 40, 12345)
+    assert np.array_equal(walk, walk2) and st == st2
+
+
+# ───────────────────────── GPU ─────────────────────────
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_gpu_sequential_bytes_equal_reference(gpu, name):
+    z = np.load(os.path.join(G, "node2vec.npz"))
+    edges, prm = CASES[name]
+    g = _graph(edges)
+    dim, p, q, nw, wl, win, neg, lr, ep = prm
+    emb, st = gpu.node2vec_train(g.off, g.adj, dim, p, q, nw, wl, win, neg, lr, ep)
+    assert np.array_equal(emb.view(np.int32), z[name]), name
+    _, npairs = og.node2vec_train(g, *prm)
+    assert st["pairs"] == npairs
+
+
+@pytest.mark.gpu
+def test_gpu_acceptance_two_cliques(gpu):
+    edges, prm = CASES["cliques32"]
+    g = _graph(edges)
+    dim, p, q, nw, wl, win, neg, lr, ep = prm
+    emb, _ = gpu.node2vec_train(g.off, g.adj, dim, p, q, nw, wl, win, neg, lr, ep)
+    w, b = _within_between(emb, g.index_of_id, [1, 2, 3, 4], [5, 6, 7, 8])
+    assert w > b
+    assert np.allclose(np.linalg.norm(emb, axis=1), 1.0, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_gpu_empty_and_invalid(gpu):
+    emb, st = gpu.node2vec_train(np.zeros(1, np.int32), np.zeros(0, np.int32), 8)
+    assert emb.shape == (0, 8)
+    with pytest.raises(Exception):
+        gpu.node2vec_train(np.array([0, 1, 2], np.int32), np.array([1, 0], np.int32), 2000)
