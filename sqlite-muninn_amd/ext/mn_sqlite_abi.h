@@ -53,6 +53,7 @@ typedef void (*sqlite3_destructor_type)(void *);
 #define MN_SLOT_bind_int64 5
 #define MN_SLOT_bind_null 6
 #define MN_SLOT_bind_text 10
+#define MN_SLOT_bind_value 12
 #define MN_SLOT_column_blob 19
 #define MN_SLOT_column_bytes 20
 #define MN_SLOT_column_count 22
@@ -191,6 +192,7 @@ struct sqlite3_index_info {
 #define sqlite3_bind_int MN_API(MN_SLOT_bind_int, int (*)(sqlite3_stmt *, int, int))
 #define sqlite3_bind_int64 MN_API(MN_SLOT_bind_int64, int (*)(sqlite3_stmt *, int, sqlite3_int64))
 #define sqlite3_bind_null MN_API(MN_SLOT_bind_null, int (*)(sqlite3_stmt *, int))
+#define sqlite3_bind_value MN_API(MN_SLOT_bind_value, int (*)(sqlite3_stmt *, int, const sqlite3_value *))
 #define sqlite3_bind_text MN_API(MN_SLOT_bind_text, int (*)(sqlite3_stmt *, int, const char *, int, void (*)(void *)))
 #define sqlite3_column_blob MN_API(MN_SLOT_column_blob, const void *(*)(sqlite3_stmt *, int))
 #define sqlite3_column_bytes MN_API(MN_SLOT_column_bytes, int (*)(sqlite3_stmt *, int))

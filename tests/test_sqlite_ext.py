@@ -224,3 +224,73 @@ def test_shadow_tables_identical_to_reference(ext_built, gpu, tmp_path):
         # answers were recorded from the reference after ITS reopen of the same file
         assert [g[0] for g in got] == ri.tolist() and [g[1] for g in got] == rd.tolist()
     c.close()
+
+
+# ───────────────────────── node2vec_train / graph_leiden through SQL ─────────────────────────
+
+def test_graph_functions_registered_and_validate_args(conn):
+    mods = {r[0] for r in conn.execute("SELECT name FROM pragma_module_list")}
+    assert "graph_leiden" in mods
+    assert conn.execute("SELECT 1 FROM pragma_function_list WHERE name='node2vec_train'").fetchone()
+    conn.execute("CREATE TABLE e (src TEXT, dst TEXT)")
+    for args, pat in [(("e;drop", "src", "dst", "o", 8, 1.0, 1.0, 1, 5, 2, 2, 0.025, 1), "invalid edge_table"),
+                      (("e", "src", "dst", "o", 0, 1.0, 1.0, 1, 5, 2, 2, 0.025, 1), "dimensions must be 1-1024"),
+                      (("e", "src", "dst", "o", 8, 0.0, 1.0, 1, 5, 2, 2, 0.025, 1), "p and q must be > 0"),
+                      (("e", "src", "dst", "o", 8, 1.0, 1.0, 0, 5, 2, 2, 0.025, 1), "num_walks and walk_length"),
+                      (("e", "src", "dst", "o", 8, 1.0, 1.0, 1, 5, 0, 2, 0.025, 1), "window and neg_samples"),
+                      (("e", "src", "dst", "o", 8, 1.0, 1.0, 1, 5, 2, 2, 0.0, 1), "learning_rate and epochs")]:
+        with pytest.raises(Exception, match=pat):  # src/node2vec.c:427-464
+            conn.execute("SELECT node2vec_train(?,?,?,?,?,?,?,?,?,?,?,?,?)", args).fetchone()
+    # empty graph → 0 without touching the device (pytests/test_node2vec.py:178-190)
+    assert conn.execute("SELECT node2vec_train('e','src','dst','o',8,1.0,1.0,5,10,3,3,0.025,1)").fetchone()[0] == 0
+    # missing required constraint → no rows / planner refusal, bad identifier → error
+    with pytest.raises(Exception):
+        conn.execute("SELECT * FROM graph_leiden WHERE edge_table='e;x' AND src_col='src' AND dst_col='dst'").fetchall()
+    assert conn.execute("SELECT * FROM graph_leiden WHERE edge_table='e' AND src_col='src' AND dst_col='dst'").fetchall() == []
+
+
+@gpu_mark
+def test_node2vec_train_sql_matches_reference_bytes(conn, gpu):
+    from oracle.graph_cases import n2v_cases
+
+    z = np.load(os.path.join(ROOT, "tests", "golden", "node2vec.npz"))
+    for name in ("cliques16", "karate_pq"):
+        edges, (dim, p, q, nw, wl, win, neg, lr, ep) = n2v_cases()[name]
+        conn.execute(f"CREATE TABLE e_{name} (src TEXT, dst TEXT)")
+        conn.executemany(f"INSERT INTO e_{name} VALUES (?, ?)", [(str(a), str(b)) for a, b in edges])
+        conn.execute(f"CREATE VIRTUAL TABLE emb_{name} USING hnsw_index(dimensions={dim}, metric='cosine', m=8, ef_construction=50)")
+        n = conn.execute(f"SELECT node2vec_train('e_{name}', 'src', 'dst', 'emb_{name}', ?, ?, ?, ?, ?, ?, ?, ?, ?)",
+                         (dim, p, q, nw, wl, win, neg, lr, ep)).fetchone()[0]
+        want = z[name].view(np.float32)
+        assert n == want.shape[0]
+        rows = conn.execute(f"SELECT id, vector FROM emb_{name}_nodes ORDER BY id").fetchall()
+        got = np.array([np.frombuffer(r[1], np.float32) for r in rows], np.float32)
+        assert np.array_equal(got.view(np.int32), want.view(np.int32)), name
+        for rowid in range(1, n + 1):  # retrievable through the vtab (pytests/test_node2vec.py:164-176)
+            assert len(conn.execute(f"SELECT vector FROM emb_{name} WHERE rowid = ?", (rowid,)).fetchone()[0]) == dim * 4
+
+
+@gpu_mark
+def test_graph_leiden_sql_matches_reference(conn, gpu):
+    from oracle.graph_cases import leiden_cases
+
+    z = np.load(os.path.join(ROOT, "tests", "golden", "leiden.npz"))
+    # barbell: exactly {A,B,C},{D,E,F} (pytests/test_graph_community.py:129-150)
+    conn.execute("CREATE TABLE bb (src TEXT, dst TEXT)")
+    conn.executemany("INSERT INTO bb VALUES (?,?)", [("A", "B"), ("B", "C"), ("C", "A"), ("D", "E"), ("E", "F"), ("F", "D"), ("C", "D")])
+    rows = conn.execute("SELECT node, community_id, modularity FROM graph_leiden WHERE edge_table='bb' AND src_col='src' AND dst_col='dst'").fetchall()
+    comm = {r[0]: r[1] for r in rows}
+    assert len(rows) == 6 and comm["A"] == comm["B"] == comm["C"] != comm["D"] and comm["D"] == comm["E"] == comm["F"]
+    assert all(r[2] == rows[0][2] for r in rows) and rows[0][2] > 0
+    assert sorted(set(comm.values())) == [0, 1]
+    for name in ("karate", "er2000w", "er500w_r2"):
+        s, d, w, res = leiden_cases()[name]
+        conn.execute(f"CREATE TABLE g_{name} (src TEXT, dst TEXT, w REAL)")
+        conn.executemany(f"INSERT INTO g_{name} VALUES (?,?,?)",
+                         [(str(int(a)), str(int(b)), float(w[i]) if w is not None else 1.0) for i, (a, b) in enumerate(zip(s, d))])
+        wc = "AND weight_col='w'" if w is not None else ""
+        rows = conn.execute(f"SELECT node, community_id, modularity FROM graph_leiden WHERE edge_table='g_{name}' AND src_col='src' "
+                            f"AND dst_col='dst' {wc} AND resolution = ?", (res,)).fetchall()
+        got = np.array([r[1] for r in rows], np.int32)  # rows come out in first-seen node order
+        assert np.array_equal(got, z[f"{name}_community"]), name
+        assert np.array([rows[0][2]], np.float64).view(np.int64)[0] == z[f"{name}_q"][0]
