@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--cpu-queries", type=int, default=4000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ef-sweep", default="", help="comma list of extra ef values to report (q/s, recall)")
+    ap.add_argument("--mode", default="replica", choices=["replica", "sharded"],
+                    help="N>1: replica = same index on every GPU, queries sharded (no collective); sharded = config 3: "
+                         "rowid mod N shards, same queries everywhere, RCCL all-gather + merge of per-shard top-k")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -94,9 +97,15 @@ def main():
     M, EFC = 16, 200
 
     # ---- synthetic data (same seed on every rank → replicas are identical) ----
-    X = gen_vectors(N, D, 42, args.dataset)
-    ids = np.arange(1, N + 1, dtype=np.int64)
-    Q = gen_vectors(NQ, D, 43 + rank, args.dataset)
+    sharded = args.mode == "sharded" and world > 1
+    if sharded:  # shard r holds the rowids ≡ r (mod world); every rank searches the SAME queries
+        X = gen_vectors(N, D, 42 + 1000 * rank, args.dataset)
+        ids = np.arange(N, dtype=np.int64) * world + rank
+        Q = gen_vectors(NQ, D, 43, args.dataset)
+    else:
+        X = gen_vectors(N, D, 42, args.dataset)
+        ids = np.arange(1, N + 1, dtype=np.int64)
+        Q = gen_vectors(NQ, D, 43 + rank, args.dataset)
 
     # ---- build on the device (reported, not the timed step) ----
     g = pkg.HnswIndex(D, args.metric, M, EFC, order=order, device=local_rank)
@@ -109,9 +118,17 @@ def main():
     # ---- HBM-resident inputs / outputs ----
     dq = g.dev_malloc(Q.nbytes)
     g.dev_upload(dq, Q)
-    d_ids = g.dev_malloc(NQ * K * 8)
-    d_ds = g.dev_malloc(NQ * K * 4)
-    d_cnt = g.dev_malloc(NQ * 4)
+    if sharded:  # outputs live in torch tensors so that RCCL can all-gather them in place
+        import torch
+
+        t_ids = torch.empty((NQ, K), dtype=torch.int64, device="cuda")
+        t_ds = torch.empty((NQ, K), dtype=torch.float32, device="cuda")
+        t_cnt = torch.empty((NQ,), dtype=torch.int32, device="cuda")
+        d_ids, d_ds, d_cnt = t_ids.data_ptr(), t_ds.data_ptr(), t_cnt.data_ptr()
+    else:
+        d_ids = g.dev_malloc(NQ * K * 8)
+        d_ds = g.dev_malloc(NQ * K * 4)
+        d_cnt = g.dev_malloc(NQ * 4)
 
     def barrier():
         if dist is not None:
@@ -125,6 +142,9 @@ def main():
         kms, nd, ne = [], 0, 0
         for _ in range(nsteps):
             g.search_batch_dev(dq, NQ, K, ef, d_ids, d_ds, d_cnt)
+            if sharded:  # the one exchange step of the sharded index: per-shard top-k → global top-k
+                g.sync()
+                pkg.parallel.allgather_merge_topk(t_ids, t_ds, t_cnt, K)
             if collect:  # per-launch HIP-event time on the kernel's own stream (syncs that launch)
                 st = g.last_launch()
                 kms.append(st["last_kernel_ms"])
@@ -197,7 +217,7 @@ def main():
                          f"bitmap visited set; {cpu_s:.1f}s of CPU work"}
 
     if rank == 0:
-        total_q = NQ * args.steps * world
+        total_q = NQ * args.steps * (1 if sharded else world)
         line = {
             "metric": "kNN queries/sec (10k-query batch, k=10, ef=128, 1M x 768 f32 HNSW index) + recall@10",
             "value": total_q / elapsed,
@@ -214,7 +234,8 @@ def main():
             "config": {"workload": f"{N}x{D} f32 {args.dataset}, HNSW M={M} efC={EFC} {args.metric}, build on GPU + "
                                    f"{NQ}-query batched kNN k={K} ef={EF}",
                        "n": N, "dim": D, "nq": NQ, "k": K, "ef": EF, "order": args.order, "dataset": args.dataset,
-                       "parallelism": "replica per GPU, queries sharded" if world > 1 else "single GPU"},
+                       "parallelism": ("sharded index (rowid mod N) + RCCL all-gather top-k merge" if sharded else
+                                       "replica per GPU, queries sharded") if world > 1 else "single GPU"},
             "recall_at_10": recall,
             "recall_queries": nrec,
             "n_dist_per_query": n_dist / NQ,

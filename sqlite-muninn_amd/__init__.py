@@ -12,3 +12,15 @@ from .hnsw import (BUILD_BATCHED, BUILD_SEQUENTIAL, METRIC, ORDER_SSE, ORDER_WAV
                    device_count, lib, vec_dist_batch, vec_parse_metric)
 from . import graph  # noqa: E402,F401
 from .graph import LEIDEN_BATCHED, LEIDEN_SEQUENTIAL, N2V_SEQUENTIAL, Graph, node2vec_train  # noqa: E402,F401
+
+
+def __getattr__(name):  # torch is only needed for the multi-GPU plumbing: import it lazily
+    if name == "parallel":
+        import importlib
+
+        return importlib.import_module("sqlite_muninn_amd.parallel")
+    if name == "lfr":
+        import importlib
+
+        return importlib.import_module("sqlite_muninn_amd.lfr")
+    raise AttributeError(name)
