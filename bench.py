@@ -39,6 +39,19 @@ def gen_vectors(n, dim, seed, dataset, chunk=65536):
             b = min(n, a + chunk)
             out[a:b] = rng.standard_normal((b - a, dim), dtype=np.float32)
         return out
+    if dataset == "lowrank":
+        # embedding-like data: intrinsic dimension 32 embedded in `dim` (x = zA + 0.02 eps), unit-normalised.
+        # Isotropic Gaussian and the sigma=0.1 "clustered" set are both ~768-dimensional intrinsically (the
+        # cluster noise 0.1*sqrt(768) dwarfs the unit centres), where every graph index has poor recall.
+        arng = np.random.default_rng(777)
+        A = arng.standard_normal((32, dim), dtype=np.float32) / np.float32(np.sqrt(32))
+        for a in range(0, n, chunk):
+            b = min(n, a + chunk)
+            v = rng.standard_normal((b - a, 32), dtype=np.float32) @ A
+            v += np.float32(0.02) * rng.standard_normal((b - a, dim), dtype=np.float32)
+            v /= np.linalg.norm(v, axis=1, keepdims=True)
+            out[a:b] = v
+        return out
     # "clustered": 64 Gaussian clusters, sigma 0.1, unit-normalised — mimics embeddings
     crng = np.random.default_rng(4242)  # centres shared by base vectors and queries
     centres = crng.standard_normal((64, dim), dtype=np.float32)
@@ -64,7 +77,7 @@ def main():
     ap.add_argument("--ef", type=int, default=128)
     ap.add_argument("--metric", default="cosine")
     ap.add_argument("--order", default="sse", choices=["sse", "wave"])
-    ap.add_argument("--dataset", default="gaussian", choices=["gaussian", "clustered"])
+    ap.add_argument("--dataset", default="gaussian", choices=["gaussian", "clustered", "lowrank"])
     ap.add_argument("--recall-queries", type=int, default=500)
     ap.add_argument("--cpu-queries", type=int, default=4000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -216,6 +229,16 @@ def main():
                "sample": f"{nc} of the {NQ} queries (same graph, k={K}, ef={EF}), oracle/mn_oracle.c single thread, "
                          f"bitmap visited set; {cpu_s:.1f}s of CPU work"}
 
+    # HBM traffic per launch from the committed PMC passes (profiles/traffic.json), when this exact workload was profiled
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        key = f"{N}x{D}_{args.dataset}_{args.order}_nq{NQ}_k{K}_ef{EF}"
+        if key in tj:
+            traffic = tj[key]["traffic_bytes"]
+    except (OSError, ValueError):
+        pass
+
     if rank == 0:
         total_q = NQ * args.steps * (1 if sharded else world)
         line = {
@@ -245,7 +268,7 @@ def main():
             "parity_vs_oracle": parity,
             "ef_sweep": sweep,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_beam",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_beam",
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes},
             "cpu_baseline": cpu,
         }
