@@ -181,9 +181,13 @@ typedef struct {
     int num_walks, walk_length, window, neg_samples;
     double learning_rate;
     int epochs;
+    int batch_walks; /* MN_N2V_BATCHED only: walks per batch; <= 0 → clamp(n/64, 1, 16384) */
 } mn_n2v_params;
 typedef enum {
-    MN_N2V_SEQUENTIAL = 0 /* the reference's single serial SGD stream: output bytes identical to the reference's */
+    MN_N2V_SEQUENTIAL = 0, /* the reference's single serial SGD stream: output bytes identical to the reference's */
+    MN_N2V_BATCHED = 1     /* batch-synchronous mini-batch schedule: one wavefront per walk,
+                              per-walk RNG streams, deterministic per-row accumulation; bit-identical to the CPU
+                              restatement of the same schedule, statistically equivalent to the serial stream */
 } mn_n2v_mode;
 typedef struct {
     int64_t pairs;    /* (center, context) pairs trained */

@@ -640,3 +640,144 @@ int orc_node2vec_train(const orc_n2v_graph *g, const orc_n2v_params *p, float *o
     free(walk);
     return N;
 }
+
+/* ───────────── batch-synchronous Node2Vec schedule (HIP MN_N2V_BATCHED) ─────────────
+ * Per (epoch, w) pass the start nodes are cut into batches of B walks.  Inside a batch:
+ *  (1) walk n has its own xorshift32 stream seeded from (epoch, w, n); it draws the walk (biased_walk,
+ *      unchanged) and then, in pair order, the negatives of its pairs;
+ *  (2) every sample's error is computed against the matrices as they stood at batch start:
+ *      err = (label - sigmoid_lut(dot)) * lr_walk, dot in wave order (lane L folds d ≡ L mod 64 with fmaf,
+ *      xor butterfly 32..1);
+ *  (3) syn0[c] += Σ err·syn1neg_old[t] over the batch's samples with centre c, in sample order (fmaf);
+ *      syn1neg[t] += Σ err·syn0_old[c] likewise.
+ * Final L2 normalisation as the reference (:540-551). */
+static unsigned n2v_walk_seed(int epoch, int w, int n) {
+    unsigned s = 42u ^ ((unsigned)epoch * 0x9E3779B9u) ^ ((unsigned)w * 0x85EBCA6Bu) ^ ((unsigned)n * 0xC2B2AE35u);
+    s ^= s >> 15;
+    s *= 0x2C1B3C6Du;
+    s ^= s >> 12;
+    return s ? s : 1u;
+}
+
+static float n2v_dot_wave(const float *a, const float *b, int dim) {
+    float part[64];
+    for (int l = 0; l < 64; l++) {
+        float acc = 0.0f;
+        for (int d = l; d < dim; d += 64)
+            acc = fmaf(a[d], b[d], acc);
+        part[l] = acc;
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        float nxt[64];
+        for (int l = 0; l < 64; l++)
+            nxt[l] = part[l] + part[l ^ m];
+        memcpy(part, nxt, sizeof(nxt));
+    }
+    return part[0];
+}
+
+typedef struct {
+    int center, target;
+    float err;
+} n2v_sample;
+
+int orc_node2vec_train_batched(const orc_n2v_graph *g, const orc_n2v_params *p, int B, float *out, int64_t *n_pairs) {
+    int N = g->n, dim = p->dim;
+    if (N == 0)
+        return 0;
+    if (B < 1)
+        B = 1;
+    n2v_init_sig();
+    unsigned rng = 42;
+    float *syn0 = out;
+    float *syn1 = (float *)calloc((size_t)N * dim, sizeof(float));
+    float *old0 = (float *)malloc((size_t)N * dim * sizeof(float));
+    float *old1 = (float *)malloc((size_t)N * dim * sizeof(float));
+    int *neg_table = (int *)malloc(N2V_NEG_TABLE * sizeof(int));
+    int *walk = (int *)malloc((size_t)p->walk_length * sizeof(int));
+    for (int i = 0; i < N * dim; i++)
+        syn0[i] = ((float)n2v_rand(&rng) - 0.5f) / (float)dim;
+    orc_n2v_neg_table(g, neg_table);
+    const size_t cap = (size_t)p->walk_length * 2 * p->window * (1 + p->neg_samples);
+    n2v_sample *smp = (n2v_sample *)malloc((size_t)B * cap * sizeof(n2v_sample));
+    const double total_words = (double)N * p->num_walks * p->walk_length * p->epochs;
+    int64_t pairs = 0;
+    for (int epoch = 0; epoch < p->epochs; epoch++)
+        for (int w = 0; w < p->num_walks; w++)
+            for (int b = 0; b < N; b += B) {
+                int e = b + B < N ? b + B : N;
+                size_t ns = 0;
+                memcpy(old0, syn0, (size_t)N * dim * sizeof(float));
+                memcpy(old1, syn1, (size_t)N * dim * sizeof(float));
+                for (int n = b; n < e; n++) {
+                    unsigned st = n2v_walk_seed(epoch, w, n);
+                    double wc = ((double)(epoch * p->num_walks + w) * N + n) * p->walk_length;
+                    float lr = (float)(p->lr * (1.0 - wc / total_words));
+                    if (lr < (float)(p->lr * 0.0001))
+                        lr = (float)(p->lr * 0.0001);
+                    int wlen = orc_biased_walk(g, n, p->p, p->q, p->walk_length, walk, &st);
+                    for (int pos = 0; pos < wlen; pos++) {
+                        int cs = pos - p->window, ce = pos + p->window;
+                        if (cs < 0)
+                            cs = 0;
+                        if (ce >= wlen)
+                            ce = wlen - 1;
+                        for (int c = cs; c <= ce; c++) {
+                            if (c == pos)
+                                continue;
+                            int center = walk[pos], context = walk[c];
+                            pairs++;
+                            for (int s = 0; s <= p->neg_samples; s++) {
+                                int target;
+                                float label;
+                                if (s == 0) {
+                                    target = context;
+                                    label = 1.0f;
+                                } else {
+                                    target = neg_table[n2v_xorshift32(&st) % N2V_NEG_TABLE];
+                                    if (target == center || target == context)
+                                        continue;
+                                    label = 0.0f;
+                                }
+                                float dot = n2v_dot_wave(old0 + (size_t)center * dim, old1 + (size_t)target * dim, dim);
+                                float err = (label - n2v_fast_sigmoid(dot)) * lr;
+                                smp[ns].center = center;
+                                smp[ns].target = target;
+                                smp[ns].err = err;
+                                ns++;
+                            }
+                        }
+                    }
+                }
+                /* (3) per-destination accumulation in sample order */
+                for (size_t i = 0; i < ns; i++) {
+                    float *dc = syn0 + (size_t)smp[i].center * dim;
+                    const float *st1 = old1 + (size_t)smp[i].target * dim;
+                    float *dt = syn1 + (size_t)smp[i].target * dim;
+                    const float *sc0 = old0 + (size_t)smp[i].center * dim;
+                    for (int d = 0; d < dim; d++) {
+                        dc[d] = fmaf(smp[i].err, st1[d], dc[d]);
+                        dt[d] = fmaf(smp[i].err, sc0[d], dt[d]);
+                    }
+                }
+            }
+    for (int i = 0; i < N; i++) {
+        float *emb = syn0 + (size_t)i * dim;
+        float norm = 0.0f;
+        for (int d = 0; d < dim; d++)
+            norm += emb[d] * emb[d];
+        norm = sqrtf(norm);
+        if (norm > 1e-10f)
+            for (int d = 0; d < dim; d++)
+                emb[d] /= norm;
+    }
+    if (n_pairs)
+        *n_pairs = pairs;
+    free(syn1);
+    free(old0);
+    free(old1);
+    free(neg_table);
+    free(walk);
+    free(smp);
+    return N;
+}

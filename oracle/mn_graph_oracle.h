@@ -48,6 +48,8 @@ typedef struct {
 /* node2vec_train's compute (src/node2vec.c:486-551): sgns_create (rng 42), the serial walk + SGNS stream,
  * then L2 normalisation.  out is [n][dim] f32 — the bytes the reference INSERTs into the output table. */
 int orc_node2vec_train(const orc_n2v_graph *g, const orc_n2v_params *p, float *out, int64_t *n_pairs);
+/* the batch-synchronous schedule of the HIP MN_N2V_BATCHED mode (B walks per batch) */
+int orc_node2vec_train_batched(const orc_n2v_graph *g, const orc_n2v_params *p, int B, float *out, int64_t *n_pairs);
 /* biased_walk (src/node2vec.c:168-226) from an explicit rng state; returns the walk length */
 int orc_biased_walk(const orc_n2v_graph *g, int start, double p, double q, int walk_length, int *walk, unsigned *rng);
 /* Builds the reference's Graph from an edge list (first-seen indices, undirected, de-duplicated);

@@ -141,6 +141,8 @@ def _n2v_lib():
         L.orc_n2v_build_graph.argtypes = [C.c_int, _i32p, _i32p, C.c_int, _i32p, _i32p, _i32p]
         L.orc_node2vec_train.argtypes = [C.POINTER(_N2vGraph), C.POINTER(_N2vParams), np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS"),
                                          C.POINTER(C.c_int64)]
+        L.orc_node2vec_train_batched.argtypes = [C.POINTER(_N2vGraph), C.POINTER(_N2vParams), C.c_int,
+                                                 np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS"), C.POINTER(C.c_int64)]
         L.orc_biased_walk.argtypes = [C.POINTER(_N2vGraph), C.c_int, C.c_double, C.c_double, C.c_int, _i32p, C.POINTER(C.c_uint)]
         L.orc_n2v_sigmoid_table.restype = C.POINTER(C.c_float)
         L.orc_n2v_neg_table.argtypes = [C.POINTER(_N2vGraph), _i32p]
@@ -178,6 +180,15 @@ def node2vec_train(g: N2vGraph, dim, p, q, num_walks, walk_length, window, neg, 
     cg = g.c_struct()
     npairs = C.c_int64(0)
     _n2v_lib().orc_node2vec_train(C.byref(cg), C.byref(prm), out, C.byref(npairs))
+    return out[:g.n], npairs.value
+
+
+def node2vec_train_batched(g: N2vGraph, dim, p, q, num_walks, walk_length, window, neg, lr, epochs, batch):
+    out = np.zeros((max(g.n, 1), dim), np.float32)
+    prm = _N2vParams(dim, p, q, num_walks, walk_length, window, neg, lr, epochs)
+    cg = g.c_struct()
+    npairs = C.c_int64(0)
+    _n2v_lib().orc_node2vec_train_batched(C.byref(cg), C.byref(prm), int(batch), out, C.byref(npairs))
     return out[:g.n], npairs.value
 
 

@@ -299,6 +299,8 @@ static unsigned h_xs32(unsigned *s) {
     return x;
 }
 
+#include "mn_n2v_batched.hpp"
+
 struct N2vDev {
     int *off = nullptr, *adj = nullptr, *neg = nullptr, *walk = nullptr;
     float *syn0 = nullptr, *syn1 = nullptr, *sig = nullptr;
@@ -321,7 +323,7 @@ extern "C" int mn_node2vec_train(int n, const int *off, const int *adj, const mn
         nset_err("mn_node2vec_train: invalid parameters (src/node2vec.c:443-464)");
         return -1;
     }
-    if (mode != MN_N2V_SEQUENTIAL) {
+    if (mode != MN_N2V_SEQUENTIAL && mode != MN_N2V_BATCHED) {
         nset_err("mn_node2vec_train: mode %d not available", mode);
         return -1;
     }
@@ -407,7 +409,16 @@ extern "C" int mn_node2vec_train(int n, const int *off, const int *adj, const mn
     size_t lds = N2V_LDS_DEG * sizeof(double) + 3 * (size_t)dim * sizeof(float) + (N2V_SIG_SIZE + 1) * sizeof(float) +
                  (size_t)std::min(prm->walk_length, N2V_LDS_WALK) * sizeof(int) + 64;
     NCHK(hipEventRecord(e0, nullptr));
-    hipLaunchKernelGGL(k_n2v_seq, dim3(1), dim3(64), lds, nullptr, a);
+    if (mode == MN_N2V_BATCHED) {
+        int B = prm->batch_walks;
+        if (B <= 0) // ~75 contributions per row and batch at the default walk/window/neg settings
+            B = std::min(16384, std::max(1, n / 64));
+        NCHK(hipMemset(d.out, 0, 2 * sizeof(unsigned long long)));
+        if (n2v_run_batched(a, B, max_deg, d.out) != 0)
+            return -1;
+    } else {
+        hipLaunchKernelGGL(k_n2v_seq, dim3(1), dim3(64), lds, nullptr, a);
+    }
     NCHK(hipGetLastError());
     hipLaunchKernelGGL(k_n2v_normalize, dim3(n), dim3(64), (size_t)dim * sizeof(float), nullptr, d.syn0, n, dim);
     NCHK(hipEventRecord(e1, nullptr));

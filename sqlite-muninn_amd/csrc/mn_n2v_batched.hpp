@@ -1,0 +1,376 @@
+// mn_n2v_batched.hpp — MN_N2V_BATCHED: the batch-synchronous Node2Vec schedule (included by mn_n2v.hip).
+//
+// Per (epoch, w) pass the start nodes are cut into batches of B walks (DESIGN.md §node2vec;
+// oracle/mn_graph_oracle.c orc_node2vec_train_batched restates it):
+//   k_n2v_walk_grad  one wavefront per walk: its own xorshift32 stream (seeded from epoch, w, n) draws the
+//                    biased walk and then the negatives of its pairs in pair order; every sample's error is
+//                    taken against the matrices frozen at batch start (centre row in registers, target rows
+//                    as coalesced 256-B loads, lane-strided fmaf + xor butterfly, the reference's sigmoid LUT)
+//   sort             rocPRIM stable radix sort of sample indices by destination row (plumbing)
+//   k_n2v_apply      one wavefront per destination row: row += Σ err · source_row in sample order (fmaf);
+//                    centres into a staging matrix first (targets read the old centres), targets in place,
+//                    then k_n2v_commit copies the staged centre rows back
+// No float atomics anywhere: embeddings are bit-reproducible and equal the CPU restatement's.
+#pragma once
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#define N2VB_LDS_DEG 512
+
+struct N2vBatchArgs {
+    N2vArgs a;
+    int epoch, w, b0, b1;
+    double total_words;
+    int cap; // sample slots per walk
+    int *s_center, *s_target;
+    float *s_err;
+    double *cum_scratch; // [walks][max_deg], used when a node has more than N2VB_LDS_DEG neighbours
+    int max_deg;
+    unsigned long long *pairs_out;
+};
+
+DEVI unsigned n2v_walk_seed(int epoch, int w, int n) {
+    unsigned s = 42u ^ ((unsigned)epoch * 0x9E3779B9u) ^ ((unsigned)w * 0x85EBCA6Bu) ^ ((unsigned)n * 0xC2B2AE35u);
+    s ^= s >> 15;
+    s *= 0x2C1B3C6Du;
+    s ^= s >> 12;
+    return s ? s : 1u;
+}
+
+// biased_walk (src/node2vec.c:168-226) for one wavefront; walk[] in LDS.  With p == q == 1 every weight is
+// 1.0, the running totals are the exact integers 1..deg and "first i with r <= i+1" is ceil(r)-1: the
+// is_neighbor scans are skipped with identical results.
+DEVI int gen_walk(const N2vArgs &a, int n, unsigned &rng, int *walk, double *cum_l, double *cum_g, int lane) {
+    if (lane == 0)
+        walk[0] = n;
+    const int s0 = a.off[n], deg0 = a.off[n + 1] - s0;
+    if (deg0 == 0)
+        return 1;
+    int idx = (int)(xs_rand(rng) * deg0);
+    if (idx >= deg0)
+        idx = deg0 - 1;
+    int cur = a.adj[s0 + idx], prev = n;
+    if (lane == 0)
+        walk[1] = cur;
+    const bool uniform = a.p == 1.0 && a.q == 1.0;
+    for (int step = 2; step < a.walk_length; step++) {
+        const int c0 = a.off[cur], deg = a.off[cur + 1] - c0;
+        if (deg == 0)
+            return step;
+        int chosen;
+        if (uniform) {
+            const double r = xs_rand(rng) * (double)deg;
+            int i = (int)ceil(r) - 1;
+            if (i < 0)
+                i = 0;
+            if (i >= deg)
+                i = deg - 1;
+            chosen = a.adj[c0 + i];
+        } else {
+            const bool in_lds = deg <= N2VB_LDS_DEG;
+            const int p0 = a.off[prev], degp = a.off[prev + 1] - p0;
+            __builtin_amdgcn_wave_barrier();
+            for (int i = lane; i < deg; i += 64) {
+                const int x = a.adj[c0 + i];
+                double wt;
+                if (x == prev) {
+                    wt = 1.0 / a.p;
+                } else {
+                    bool nb = false;
+                    for (int j = 0; j < degp; j++)
+                        if (a.adj[p0 + j] == x) {
+                            nb = true;
+                            break;
+                        }
+                    wt = nb ? 1.0 : 1.0 / a.q;
+                }
+                cum_st(cum_l, cum_g, in_lds, i, wt);
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                double t = 0.0;
+                for (int i = 0; i < deg; i++) {
+                    t += cum_ld(cum_l, cum_g, in_lds, i);
+                    cum_st(cum_l, cum_g, in_lds, i, t);
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+            const double total = cum_ld(cum_l, cum_g, in_lds, deg - 1);
+            const double r = xs_rand(rng) * total;
+            int ci = 0x7fffffff;
+            for (int i = lane; i < deg; i += 64)
+                if (r <= cum_ld(cum_l, cum_g, in_lds, i)) {
+                    ci = i;
+                    break;
+                }
+            for (int m = 32; m >= 1; m >>= 1) {
+                int o = __shfl_xor(ci, m);
+                ci = o < ci ? o : ci;
+            }
+            chosen = ci == 0x7fffffff ? a.adj[c0] : a.adj[c0 + ci];
+        }
+        if (lane == 0)
+            walk[step] = chosen;
+        prev = cur;
+        cur = chosen;
+    }
+    return a.walk_length;
+}
+
+template <int NR> // NR = ceil(dim / 64) register slots per lane
+__global__ void __launch_bounds__(64) k_n2v_walk_grad(N2vBatchArgs b) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const N2vArgs &a = b.a;
+    const int lane = threadIdx.x;
+    const int n = b.b0 + blockIdx.x;
+    if (n >= b.b1)
+        return;
+    double *cum_l = reinterpret_cast<double *>(smem);
+    int *walk = reinterpret_cast<int *>(cum_l + N2VB_LDS_DEG);
+    double *cum_g = b.cum_scratch ? b.cum_scratch + (size_t)blockIdx.x * b.max_deg : nullptr;
+    unsigned rng = n2v_walk_seed(b.epoch, b.w, n);
+    const double wc = ((double)(b.epoch * a.num_walks + b.w) * a.n + n) * a.walk_length;
+    float lr = (float)(a.lr * (1.0 - wc / b.total_words));
+    if (lr < (float)(a.lr * 0.0001))
+        lr = (float)(a.lr * 0.0001);
+    const int wlen = gen_walk(a, n, rng, walk, cum_l, cum_g, lane);
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    const int dim = a.dim;
+    const size_t base = (size_t)blockIdx.x * b.cap;
+    int ns = 0;
+    unsigned long long pairs = 0;
+    for (int pos = 0; pos < wlen; pos++) {
+        const int center = walk[pos];
+        int cs = pos - a.window, ce = pos + a.window;
+        if (cs < 0)
+            cs = 0;
+        if (ce >= wlen)
+            ce = wlen - 1;
+        float vc[NR];
+        const float *rowc = a.syn0 + (size_t)center * dim;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            int d = lane + 64 * r;
+            vc[r] = d < dim ? rowc[d] : 0.0f;
+        }
+        for (int c = cs; c <= ce; c++) {
+            if (c == pos)
+                continue;
+            const int context = walk[c];
+            pairs++;
+            for (int s = 0; s <= a.neg; s++) {
+                int target;
+                float label;
+                if (s == 0) {
+                    target = context;
+                    label = 1.0f;
+                } else {
+                    target = a.neg_table[xs32(rng) % N2V_NEG_TABLE];
+                    if (target == center || target == context)
+                        continue;
+                    label = 0.0f;
+                }
+                const float *rowt = a.syn1neg + (size_t)target * dim;
+                float acc = 0.0f;
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    int d = lane + 64 * r;
+                    if (d < dim)
+                        acc = fmaf(vc[r], rowt[d], acc);
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1)
+                    acc = __fadd_rn(acc, __shfl_xor(acc, m));
+                const float err = __fmul_rn(__fsub_rn(label, fast_sigmoid(a.sig_table, acc)), lr);
+                if (lane == 0) {
+                    b.s_center[base + ns] = center;
+                    b.s_target[base + ns] = target;
+                    b.s_err[base + ns] = err;
+                }
+                ns++;
+            }
+        }
+    }
+    for (int i = ns + lane; i < b.cap; i += 64) {
+        b.s_center[base + i] = -1;
+        b.s_target[base + i] = -1;
+    }
+    if (lane == 0)
+        atomicAdd(b.pairs_out, pairs);
+}
+
+__global__ void k_n2v_keys(const int *dest, int n_samples, int n_nodes, int *keys, int *vals) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n_samples)
+        return;
+    int d = dest[i];
+    keys[i] = d < 0 ? n_nodes : d;
+    vals[i] = (int)i;
+}
+
+__global__ void k_n2v_segments(const int *keys_sorted, int n_samples, int n_nodes, int *seg_start, int *n_seg) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n_samples)
+        return;
+    int k = keys_sorted[i];
+    if (k >= n_nodes)
+        return;
+    if (i == 0 || keys_sorted[i - 1] != k)
+        seg_start[atomicAdd(n_seg, 1)] = (int)i;
+}
+
+// dest row += Σ err · src row over the segment, in sorted (= sample) order
+template <int NR>
+__global__ void __launch_bounds__(64)
+    k_n2v_apply(const int *keys_sorted, const int *vals_sorted, const int *seg_start, const int *n_seg, int n_samples,
+                const int *other, const float *s_err, const float *dst_old, const float *src_mat, float *dst_out, int dim) {
+    if ((int)blockIdx.x >= *n_seg)
+        return;
+    const int lane = threadIdx.x;
+    int j = seg_start[blockIdx.x];
+    const int k = keys_sorted[j];
+    float acc[NR];
+    const float *row = dst_old + (size_t)k * dim;
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        int d = lane + 64 * r;
+        acc[r] = d < dim ? row[d] : 0.0f;
+    }
+    for (; j < n_samples && keys_sorted[j] == k; j++) {
+        const int i = vals_sorted[j];
+        const float err = s_err[i];
+        const float *src = src_mat + (size_t)other[i] * dim;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            int d = lane + 64 * r;
+            if (d < dim)
+                acc[r] = fmaf(err, src[d], acc[r]);
+        }
+    }
+    float *out = dst_out + (size_t)k * dim;
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        int d = lane + 64 * r;
+        if (d < dim)
+            out[d] = acc[r];
+    }
+}
+
+__global__ void __launch_bounds__(64)
+    k_n2v_commit(const int *keys_sorted, const int *seg_start, const int *n_seg, const float *staged, float *dst, int dim) {
+    if ((int)blockIdx.x >= *n_seg)
+        return;
+    const int k = keys_sorted[seg_start[blockIdx.x]];
+    for (int d = threadIdx.x; d < dim; d += 64)
+        dst[(size_t)k * dim + d] = staged[(size_t)k * dim + d];
+}
+
+struct N2vBatchDev {
+    int *s_center = nullptr, *s_target = nullptr, *keys = nullptr, *vals = nullptr, *keys_s = nullptr, *vals_s = nullptr,
+        *seg = nullptr, *nseg = nullptr, *keys_c = nullptr, *seg_c = nullptr, *nseg_c = nullptr;
+    float *s_err = nullptr, *staged = nullptr;
+    double *cum = nullptr;
+    void *tmp = nullptr;
+    ~N2vBatchDev() {
+        (void)hipFree(s_center); (void)hipFree(s_target); (void)hipFree(keys); (void)hipFree(vals); (void)hipFree(keys_s);
+        (void)hipFree(vals_s); (void)hipFree(seg); (void)hipFree(nseg); (void)hipFree(s_err); (void)hipFree(staged);
+        (void)hipFree(cum); (void)hipFree(tmp); (void)hipFree(keys_c); (void)hipFree(seg_c); (void)hipFree(nseg_c);
+    }
+};
+
+template <int NR> static int n2v_run_batched_t(const N2vArgs &a, int B, int max_deg, unsigned long long *d_pairs) {
+    const int N = a.n, dim = a.dim;
+    const int cap = a.walk_length * 2 * a.window * (1 + a.neg);
+    const size_t ns_max = (size_t)B * cap;
+    if (ns_max > 0x7fffffffULL) {
+        nset_err("mn_node2vec_train: batch of %d walks x %d samples exceeds 2^31", B, cap);
+        return -1;
+    }
+    N2vBatchDev d;
+    NCHK(hipMalloc(&d.s_center, ns_max * sizeof(int)));
+    NCHK(hipMalloc(&d.s_target, ns_max * sizeof(int)));
+    NCHK(hipMalloc(&d.s_err, ns_max * sizeof(float)));
+    NCHK(hipMalloc(&d.keys, ns_max * sizeof(int)));
+    NCHK(hipMalloc(&d.vals, ns_max * sizeof(int)));
+    NCHK(hipMalloc(&d.keys_s, ns_max * sizeof(int)));
+    NCHK(hipMalloc(&d.vals_s, ns_max * sizeof(int)));
+    NCHK(hipMalloc(&d.keys_c, ns_max * sizeof(int)));
+    NCHK(hipMalloc(&d.seg, ((size_t)N + 1) * sizeof(int)));
+    NCHK(hipMalloc(&d.seg_c, ((size_t)N + 1) * sizeof(int)));
+    NCHK(hipMalloc(&d.nseg, sizeof(int)));
+    NCHK(hipMalloc(&d.nseg_c, sizeof(int)));
+    NCHK(hipMalloc(&d.staged, (size_t)N * dim * sizeof(float)));
+    if (max_deg > N2VB_LDS_DEG && !(a.p == 1.0 && a.q == 1.0))
+        NCHK(hipMalloc(&d.cum, (size_t)B * max_deg * sizeof(double)));
+    int bits = 1;
+    while ((1u << bits) <= (unsigned)N)
+        bits++;
+    size_t tmp_bytes = 0;
+    if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, d.keys, d.keys_s, d.vals, d.vals_s, ns_max, 0, bits, nullptr) != hipSuccess) {
+        nset_err("rocprim::radix_sort_pairs (size query) failed");
+        return -1;
+    }
+    NCHK(hipMalloc(&d.tmp, tmp_bytes));
+    N2vBatchArgs b;
+    memset(&b, 0, sizeof(b));
+    b.a = a;
+    b.total_words = (double)N * a.num_walks * a.walk_length * a.epochs;
+    b.cap = cap;
+    b.s_center = d.s_center;
+    b.s_target = d.s_target;
+    b.s_err = d.s_err;
+    b.cum_scratch = d.cum;
+    b.max_deg = max_deg;
+    b.pairs_out = d_pairs;
+    const size_t lds = N2VB_LDS_DEG * sizeof(double) + (size_t)a.walk_length * sizeof(int) + 64;
+    for (int epoch = 0; epoch < a.epochs; epoch++)
+        for (int w = 0; w < a.num_walks; w++)
+            for (int b0 = 0; b0 < N; b0 += B) {
+                b.epoch = epoch;
+                b.w = w;
+                b.b0 = b0;
+                b.b1 = b0 + B < N ? b0 + B : N;
+                const int nw = b.b1 - b.b0;
+                const int ns = nw * cap;
+                const unsigned g256 = (unsigned)((ns + 255) / 256);
+                hipLaunchKernelGGL((k_n2v_walk_grad<NR>), dim3(nw), dim3(64), lds, nullptr, b);
+                // centres: syn0[c] += Σ err · syn1neg_old[t]  → staged
+                hipLaunchKernelGGL(k_n2v_keys, dim3(g256), dim3(256), 0, nullptr, d.s_center, ns, N, d.keys, d.vals);
+                if (rocprim::radix_sort_pairs(d.tmp, tmp_bytes, d.keys, d.keys_c, d.vals, d.vals_s, (size_t)ns, 0, bits, nullptr) !=
+                    hipSuccess) {
+                    nset_err("rocprim::radix_sort_pairs failed");
+                    return -1;
+                }
+                NCHK(hipMemsetAsync(d.nseg_c, 0, sizeof(int), nullptr));
+                hipLaunchKernelGGL(k_n2v_segments, dim3(g256), dim3(256), 0, nullptr, d.keys_c, ns, N, d.seg_c, d.nseg_c);
+                hipLaunchKernelGGL((k_n2v_apply<NR>), dim3(N), dim3(64), 0, nullptr, d.keys_c, d.vals_s, d.seg_c, d.nseg_c, ns,
+                                   d.s_target, d.s_err, a.syn0, a.syn1neg, d.staged, dim);
+                // targets: syn1neg[t] += Σ err · syn0_old[c]  (syn0 is still the old one) → in place
+                hipLaunchKernelGGL(k_n2v_keys, dim3(g256), dim3(256), 0, nullptr, d.s_target, ns, N, d.keys, d.vals);
+                if (rocprim::radix_sort_pairs(d.tmp, tmp_bytes, d.keys, d.keys_s, d.vals, d.vals_s, (size_t)ns, 0, bits, nullptr) !=
+                    hipSuccess) {
+                    nset_err("rocprim::radix_sort_pairs failed");
+                    return -1;
+                }
+                NCHK(hipMemsetAsync(d.nseg, 0, sizeof(int), nullptr));
+                hipLaunchKernelGGL(k_n2v_segments, dim3(g256), dim3(256), 0, nullptr, d.keys_s, ns, N, d.seg, d.nseg);
+                hipLaunchKernelGGL((k_n2v_apply<NR>), dim3(N), dim3(64), 0, nullptr, d.keys_s, d.vals_s, d.seg, d.nseg, ns,
+                                   d.s_center, d.s_err, a.syn1neg, a.syn0, a.syn1neg, dim);
+                hipLaunchKernelGGL(k_n2v_commit, dim3(N), dim3(64), 0, nullptr, d.keys_c, d.seg_c, d.nseg_c, d.staged, a.syn0, dim);
+                NCHK(hipGetLastError());
+            }
+    NCHK(hipDeviceSynchronize());
+    return 0;
+}
+
+static int n2v_run_batched(const N2vArgs &a, int B, int max_deg, unsigned long long *d_pairs) {
+    const int nr = (a.dim + 63) / 64;
+    if (nr <= 1) return n2v_run_batched_t<1>(a, B, max_deg, d_pairs);
+    if (nr <= 2) return n2v_run_batched_t<2>(a, B, max_deg, d_pairs);
+    if (nr <= 4) return n2v_run_batched_t<4>(a, B, max_deg, d_pairs);
+    if (nr <= 8) return n2v_run_batched_t<8>(a, B, max_deg, d_pairs);
+    return n2v_run_batched_t<16>(a, B, max_deg, d_pairs);
+}

@@ -165,6 +165,7 @@ static void fn_node2vec_train(sqlite3_context *ctx, int argc, sqlite3_value **ar
     prm.neg_samples = sqlite3_value_int(argv[10]);
     prm.learning_rate = sqlite3_value_double(argv[11]);
     prm.epochs = sqlite3_value_int(argv[12]);
+    prm.batch_walks = 0;
     /* src/node2vec.c:427-464 — same checks, same messages */
     if (!ident_ok(edge_table)) { sqlite3_result_error(ctx, "node2vec_train: invalid edge_table name", -1); return; }
     if (!ident_ok(src_col)) { sqlite3_result_error(ctx, "node2vec_train: invalid src_col name", -1); return; }

@@ -20,14 +20,15 @@ class LeidenStats(C.Structure):
 
 class N2vParams(C.Structure):
     _fields_ = [("dim", C.c_int), ("p", C.c_double), ("q", C.c_double), ("num_walks", C.c_int), ("walk_length", C.c_int),
-                ("window", C.c_int), ("neg_samples", C.c_int), ("learning_rate", C.c_double), ("epochs", C.c_int)]
+                ("window", C.c_int), ("neg_samples", C.c_int), ("learning_rate", C.c_double), ("epochs", C.c_int),
+                ("batch_walks", C.c_int)]
 
 
 class N2vStats(C.Structure):
     _fields_ = [("pairs", C.c_int64), ("device_ms", C.c_double)]
 
 
-N2V_SEQUENTIAL = 0
+N2V_SEQUENTIAL, N2V_BATCHED = 0, 1
 
 GRAPH_SYMBOLS = [
     ("mn_node2vec_train", C.c_int, [C.c_int, _i32p, _i32p, C.POINTER(N2vParams), C.c_int, C.c_int,
@@ -93,14 +94,14 @@ class Graph:
 
 
 def node2vec_train(off, adj, dim, p=1.0, q=1.0, num_walks=10, walk_length=80, window=5, neg_samples=5, learning_rate=0.025,
-                   epochs=1, mode=N2V_SEQUENTIAL, device=0):
+                   epochs=1, mode=N2V_SEQUENTIAL, device=0, batch_walks=0):
     """node2vec_train's compute (src/node2vec.c:486-551) on the device → (embeddings [n][dim] f32, stats)."""
     L = _glib()
     off = np.ascontiguousarray(off, np.int32)
     adj = np.ascontiguousarray(adj if len(adj) else np.zeros(1, np.int32), np.int32)
     n = len(off) - 1
     out = np.zeros((max(n, 1), dim), np.float32)
-    prm = N2vParams(dim, p, q, num_walks, walk_length, window, neg_samples, learning_rate, epochs)
+    prm = N2vParams(dim, p, q, num_walks, walk_length, window, neg_samples, learning_rate, epochs, batch_walks)
     st = N2vStats()
     rc = L.mn_node2vec_train(n, off, adj, C.byref(prm), mode, device, out, C.byref(st))
     if rc < 0:

@@ -99,3 +99,47 @@ def test_gpu_empty_and_invalid(gpu):
     assert emb.shape == (0, 8)
     with pytest.raises(Exception):
         gpu.node2vec_train(np.array([0, 1, 2], np.int32), np.array([1, 0], np.int32), 2000)
+
+
+def _planted_graph():
+    from oracle.graph_cases import planted
+
+    s, d, _ = planted(1200, 6, 0.08, 0.002, 7)
+    return og.N2vGraph(s, d)
+
+
+def _block_quality(g, emb):
+    blk = np.arange(1200) % 6
+    E = emb[g.index_of_id[np.arange(1200)]]
+    S = E @ E.T
+    same = blk[:, None] == blk[None, :]
+    np.fill_diagonal(same, False)
+    return float(S[same].mean()), float(S[~same].mean())
+
+
+def test_batched_schedule_quality_matches_serial_on_cpu():
+    g = _planted_graph()
+    prm = (32, 1.0, 1.0, 4, 30, 4, 4, 0.025, 2)
+    ws, bs = _block_quality(g, og.node2vec_train(g, *prm)[0])
+    wb, bb = _block_quality(g, og.node2vec_train_batched(g, *prm, 18)[0])
+    assert ws - bs > 0.4 and wb - bb > 0.4 and abs((wb - bb) - (ws - bs)) < 0.15
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prm,batch", [((32, 1.0, 1.0, 4, 30, 4, 4, 0.025, 2), 18), ((32, 1.0, 1.0, 2, 20, 3, 3, 0.025, 1), 1200),
+                                       ((70, 0.5, 2.0, 2, 20, 3, 2, 0.05, 1), 7), ((130, 2.0, 0.5, 1, 12, 2, 3, 0.02, 1), 64)])
+def test_gpu_batched_bit_exact_vs_oracle_schedule(gpu, prm, batch):
+    g = _planted_graph()
+    dim, p, q, nw, wl, win, neg, lr, ep = prm
+    want, npairs = og.node2vec_train_batched(g, *prm, batch)
+    got, st = gpu.node2vec_train(g.off, g.adj, dim, p, q, nw, wl, win, neg, lr, ep, mode=gpu.N2V_BATCHED, batch_walks=batch)
+    assert st["pairs"] == npairs
+    assert np.array_equal(got.view(np.int32), want.view(np.int32))
+
+
+@pytest.mark.gpu
+def test_gpu_batched_acceptance_blocks(gpu):
+    g = _planted_graph()
+    emb, st = gpu.node2vec_train(g.off, g.adj, 32, 1.0, 1.0, 4, 30, 4, 4, 0.025, 2, mode=gpu.N2V_BATCHED)
+    w, b = _block_quality(g, emb)
+    assert w - b > 0.4  # within-block similarity far above between-block (pytests/test_node2vec.py:194-273 in spirit)
