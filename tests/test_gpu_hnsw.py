@@ -276,3 +276,35 @@ def test_sequential_insert_with_ties_matches_oracle(gpu, orc):
         assert g.insert_batch(ids, X, gpu.BUILD_SEQUENTIAL) == 0
         assert g.graph(ids) == o.graph(ids), metric
         g.close()
+
+
+def test_baseline_full_size_1Mx768(gpu, orc):
+    """BASELINE.json configs[1] at full size: 1M x 768 f32 cosine, M=16, efC=200, 10k queries, k=10, ef=128.
+    Size-independent properties (ascending, valid, distinct, idempotent, counters consistent) plus a direct
+    comparison of a query sample with the CPU oracle running on the SAME graph (bulk-exported)."""
+    n, d, nq, k, ef = 1_000_000, 768, 10_000, 10, 128
+    rng = np.random.default_rng(42)
+    X = np.empty((n, d), np.float32)
+    for a in range(0, n, 65536):
+        X[a:a + 65536] = rng.standard_normal((min(65536, n - a), d), dtype=np.float32)
+    ids = np.arange(1, n + 1, dtype=np.int64)
+    Q = np.random.default_rng(43).standard_normal((nq, d), dtype=np.float32)
+    g = gpu.HnswIndex(d, "cosine", 16, 200)
+    assert g.build(ids, X) == 0 and g.node_count == n
+    i1, d1, c1 = g.search_batch(Q, k, ef)
+    st = g.last_launch()
+    assert st["last_n_overflow"] == 0 and st["last_n_dist"] > nq * ef
+    i2, d2, c2 = g.search_batch(Q, k, ef)
+    assert np.array_equal(i1, i2) and same_bits(d1, d2)
+    assert (c1 == k).all() and (np.diff(d1, axis=1) >= 0).all() and ((i1 >= 1) & (i1 <= n)).all()
+    assert all(len(set(r.tolist())) == k for r in i1[:2000])
+    lv = g.export_nodes()[1]
+    assert lv.max() == g.max_level and 0.9 < (lv > 0).mean() * 16 < 1.1  # P(level >= 1) = 1/M
+    rows = g.export_links(0)
+    deg = (rows >= 0).sum(1)
+    assert deg.max() <= 32 and deg.min() >= 1
+    o = orc.Oracle(d, "cosine", 16, 200)
+    o.load_from_device(g, vectors=X)
+    wi, wd, wc = o.search_many(Q[:60], k, ef)
+    assert np.array_equal(i1[:60], wi) and same_bits(d1[:60], wd)
+    g.close()
