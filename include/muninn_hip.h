@@ -201,6 +201,23 @@ int mn_node2vec_train(int n_nodes, const int *off, const int *adj, const mn_n2v_
                       mn_n2v_stats *stats);
 const char *mn_node2vec_last_error(void);
 
+/* The batched schedule as a session, so that several GPUs can share one training run: every rank produces the
+ * samples of its slice of a batch's walks, the (centre, target, err) triples are exchanged (RCCL all-gather, rank
+ * order = walk order) and every replica applies the whole batch — the N-GPU embeddings are bit-identical to the
+ * 1-GPU ones.  Buffers passed to samples/apply are DEVICE pointers on the session's device. */
+typedef struct mn_n2v_session mn_n2v_session;
+mn_n2v_session *mn_n2v_begin(int n_nodes, const int *off, const int *adj, const mn_n2v_params *prm, int device);
+int mn_n2v_batch_walks(mn_n2v_session *s);  /* resolved walks per batch */
+int mn_n2v_sample_slots(mn_n2v_session *s); /* sample slots per walk = walk_length * 2*window * (1+neg) */
+/* walks of start nodes [lo, hi) (hi - lo <= batch_walks) of pass (epoch, w): fills [(hi-lo) * slots] entries;
+ * unused slots carry centre = target = -1 */
+int mn_n2v_samples(mn_n2v_session *s, int epoch, int w, int lo, int hi, int *d_center, int *d_target, float *d_err);
+/* applies ns sample slots in the given order (any concatenation of mn_n2v_samples outputs) */
+int mn_n2v_apply(mn_n2v_session *s, const int *d_center, const int *d_target, const float *d_err, int64_t ns);
+int mn_n2v_sync(mn_n2v_session *s);
+int mn_n2v_finish(mn_n2v_session *s, float *out, mn_n2v_stats *stats); /* L2 normalise, download [n][dim] */
+void mn_n2v_end(mn_n2v_session *s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -301,41 +301,23 @@ static unsigned h_xs32(unsigned *s) {
 
 #include "mn_n2v_batched.hpp"
 
-struct N2vDev {
-    int *off = nullptr, *adj = nullptr, *neg = nullptr, *walk = nullptr;
-    float *syn0 = nullptr, *syn1 = nullptr, *sig = nullptr;
-    double *cum = nullptr;
-    unsigned long long *out = nullptr;
-    ~N2vDev() {
-        (void)hipFree(off); (void)hipFree(adj); (void)hipFree(neg); (void)hipFree(walk); (void)hipFree(syn0);
-        (void)hipFree(syn1); (void)hipFree(sig); (void)hipFree(cum); (void)hipFree(out);
-    }
-};
+static int valid_params(const mn_n2v_params *prm) { // src/node2vec.c:443-464
+    return prm && prm->dim > 0 && prm->dim <= 1024 && prm->p > 0 && prm->q > 0 && prm->num_walks > 0 && prm->walk_length > 0 &&
+           prm->window > 0 && prm->neg_samples > 0 && prm->learning_rate > 0 && prm->epochs > 0;
+}
 
-extern "C" int mn_node2vec_train(int n, const int *off, const int *adj, const mn_n2v_params *prm, int mode, int device,
-                                 float *out, mn_n2v_stats *stats) {
-    if (stats)
-        memset(stats, 0, sizeof(*stats));
-    if (n == 0)
-        return 0;
-    if (!prm || prm->dim <= 0 || prm->dim > 1024 || prm->p <= 0 || prm->q <= 0 || prm->num_walks <= 0 ||
-        prm->walk_length <= 0 || prm->window <= 0 || prm->neg_samples <= 0 || prm->learning_rate <= 0 || prm->epochs <= 0) {
-        nset_err("mn_node2vec_train: invalid parameters (src/node2vec.c:443-464)");
-        return -1;
-    }
-    if (mode != MN_N2V_SEQUENTIAL && mode != MN_N2V_BATCHED) {
-        nset_err("mn_node2vec_train: mode %d not available", mode);
-        return -1;
-    }
+// uploads the graph and prepares what the reference prepares serially before its loop (sgns_create, :305-330)
+static int session_init(mn_n2v_session *S, int n, const int *off, const int *adj, const mn_n2v_params *prm, int device,
+                        bool batched) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
-        nset_err("mn_node2vec_train: HIP device %d not available (no CPU fallback)", device);
+        nset_err("node2vec: HIP device %d not available (no CPU fallback)", device);
         return -1;
     }
     NCHK(hipSetDevice(device));
+    S->device = device;
     const int dim = prm->dim;
     const size_t nd = (size_t)n * dim;
-    // inputs of the hot loop, prepared as the reference prepares them (sgns_create, :305-330)
     unsigned rng = 42; // :486
     std::vector<float> syn0(nd);
     for (size_t i = 0; i < nd; i++) // :323-325
@@ -360,36 +342,36 @@ extern "C" int mn_node2vec_train(int n, const int *off, const int *adj, const mn
         float x = (float)i / (float)N2V_SIG_SIZE * 2.0f * N2V_MAX_SIG - N2V_MAX_SIG;
         sig[i] = 1.0f / (1.0f + expf(-x));
     }
-    int max_deg = 0;
+    S->max_deg = 0;
     for (int i = 0; i < n; i++)
-        max_deg = std::max(max_deg, off[i + 1] - off[i]);
+        S->max_deg = std::max(S->max_deg, off[i + 1] - off[i]);
     const size_t ne = (size_t)off[n];
-    N2vDev d;
-    NCHK(hipMalloc(&d.off, ((size_t)n + 1) * sizeof(int)));
-    NCHK(hipMalloc(&d.adj, std::max<size_t>(1, ne) * sizeof(int)));
-    NCHK(hipMalloc(&d.neg, N2V_NEG_TABLE * sizeof(int)));
-    NCHK(hipMalloc(&d.sig, (N2V_SIG_SIZE + 1) * sizeof(float)));
-    NCHK(hipMalloc(&d.syn0, nd * sizeof(float)));
-    NCHK(hipMalloc(&d.syn1, nd * sizeof(float)));
-    NCHK(hipMalloc(&d.cum, (size_t)std::max(1, max_deg) * sizeof(double)));
-    NCHK(hipMalloc(&d.walk, (size_t)prm->walk_length * sizeof(int)));
-    NCHK(hipMalloc(&d.out, 2 * sizeof(unsigned long long)));
-    NCHK(hipMemcpy(d.off, off, ((size_t)n + 1) * sizeof(int), hipMemcpyHostToDevice));
+    NCHK(hipMalloc(&S->off, ((size_t)n + 1) * sizeof(int)));
+    NCHK(hipMalloc(&S->adj, std::max<size_t>(1, ne) * sizeof(int)));
+    NCHK(hipMalloc(&S->neg, N2V_NEG_TABLE * sizeof(int)));
+    NCHK(hipMalloc(&S->sig, (N2V_SIG_SIZE + 1) * sizeof(float)));
+    NCHK(hipMalloc(&S->syn0, nd * sizeof(float)));
+    NCHK(hipMalloc(&S->syn1, nd * sizeof(float)));
+    NCHK(hipMalloc(&S->pairs, 2 * sizeof(unsigned long long)));
+    NCHK(hipMemcpy(S->off, off, ((size_t)n + 1) * sizeof(int), hipMemcpyHostToDevice));
     if (ne)
-        NCHK(hipMemcpy(d.adj, adj, ne * sizeof(int), hipMemcpyHostToDevice));
-    NCHK(hipMemcpy(d.neg, neg.data(), N2V_NEG_TABLE * sizeof(int), hipMemcpyHostToDevice));
-    NCHK(hipMemcpy(d.sig, sig.data(), sig.size() * sizeof(float), hipMemcpyHostToDevice));
-    NCHK(hipMemcpy(d.syn0, syn0.data(), nd * sizeof(float), hipMemcpyHostToDevice));
-    NCHK(hipMemset(d.syn1, 0, nd * sizeof(float)));
-    N2vArgs a;
+        NCHK(hipMemcpy(S->adj, adj, ne * sizeof(int), hipMemcpyHostToDevice));
+    NCHK(hipMemcpy(S->neg, neg.data(), N2V_NEG_TABLE * sizeof(int), hipMemcpyHostToDevice));
+    NCHK(hipMemcpy(S->sig, sig.data(), sig.size() * sizeof(float), hipMemcpyHostToDevice));
+    NCHK(hipMemcpy(S->syn0, syn0.data(), nd * sizeof(float), hipMemcpyHostToDevice));
+    NCHK(hipMemset(S->syn1, 0, nd * sizeof(float)));
+    NCHK(hipMemset(S->pairs, 0, 2 * sizeof(unsigned long long)));
+    NCHK(hipEventCreate(&S->e0));
+    NCHK(hipEventCreate(&S->e1));
+    N2vArgs &a = S->a;
     memset(&a, 0, sizeof(a));
     a.n = n;
-    a.off = d.off;
-    a.adj = d.adj;
-    a.syn0 = d.syn0;
-    a.syn1neg = d.syn1;
-    a.neg_table = d.neg;
-    a.sig_table = d.sig;
+    a.off = S->off;
+    a.adj = S->adj;
+    a.syn0 = S->syn0;
+    a.syn1neg = S->syn1;
+    a.neg_table = S->neg;
+    a.sig_table = S->sig;
     a.dim = dim;
     a.num_walks = prm->num_walks;
     a.walk_length = prm->walk_length;
@@ -400,39 +382,150 @@ extern "C" int mn_node2vec_train(int n, const int *off, const int *adj, const mn
     a.q = prm->q;
     a.lr = prm->learning_rate;
     a.rng = rng;
-    a.cum_scratch = d.cum;
-    a.walk_scratch = d.walk;
-    a.out = d.out;
-    hipEvent_t e0, e1;
-    NCHK(hipEventCreate(&e0));
-    NCHK(hipEventCreate(&e1));
-    size_t lds = N2V_LDS_DEG * sizeof(double) + 3 * (size_t)dim * sizeof(float) + (N2V_SIG_SIZE + 1) * sizeof(float) +
-                 (size_t)std::min(prm->walk_length, N2V_LDS_WALK) * sizeof(int) + 64;
-    NCHK(hipEventRecord(e0, nullptr));
-    if (mode == MN_N2V_BATCHED) {
-        int B = prm->batch_walks;
-        if (B <= 0) // ~75 contributions per row and batch at the default walk/window/neg settings
-            B = std::min(16384, std::max(1, n / 64));
-        NCHK(hipMemset(d.out, 0, 2 * sizeof(unsigned long long)));
-        if (n2v_run_batched(a, B, max_deg, d.out) != 0)
-            return -1;
-    } else {
-        hipLaunchKernelGGL(k_n2v_seq, dim3(1), dim3(64), lds, nullptr, a);
+    a.out = S->pairs;
+    if (!batched) {
+        NCHK(hipMalloc(&S->cum, (size_t)std::max(1, S->max_deg) * sizeof(double)));
+        NCHK(hipMalloc(&S->s_center, (size_t)prm->walk_length * sizeof(int))); // walk scratch
+        a.cum_scratch = S->cum;
+        a.walk_scratch = S->s_center;
+        return 0;
     }
-    NCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_n2v_normalize, dim3(n), dim3(64), (size_t)dim * sizeof(float), nullptr, d.syn0, n, dim);
-    NCHK(hipEventRecord(e1, nullptr));
+    int B = prm->batch_walks;
+    if (B <= 0) // ~75 contributions per row and batch at the default walk/window/neg settings
+        B = std::min(16384, std::max(1, n / 64));
+    B = std::min(B, n);
+    S->B = B;
+    S->cap = prm->walk_length * 2 * prm->window * (1 + prm->neg_samples);
+    S->ns_max = (size_t)(B + 64) * S->cap; // + padding slots when a batch is split over up to 64 ranks
+    if (S->ns_max > 0x7fffffffULL) {
+        nset_err("node2vec: batch of %d walks x %d samples exceeds 2^31", B, S->cap);
+        return -1;
+    }
+    NCHK(hipMalloc(&S->s_center, S->ns_max * sizeof(int)));
+    NCHK(hipMalloc(&S->s_target, S->ns_max * sizeof(int)));
+    NCHK(hipMalloc(&S->s_err, S->ns_max * sizeof(float)));
+    NCHK(hipMalloc(&S->keys, S->ns_max * sizeof(int)));
+    NCHK(hipMalloc(&S->vals, S->ns_max * sizeof(int)));
+    NCHK(hipMalloc(&S->keys_s, S->ns_max * sizeof(int)));
+    NCHK(hipMalloc(&S->vals_s, S->ns_max * sizeof(int)));
+    NCHK(hipMalloc(&S->keys_c, S->ns_max * sizeof(int)));
+    NCHK(hipMalloc(&S->seg, ((size_t)n + 1) * sizeof(int)));
+    NCHK(hipMalloc(&S->seg_c, ((size_t)n + 1) * sizeof(int)));
+    NCHK(hipMalloc(&S->nseg, sizeof(int)));
+    NCHK(hipMalloc(&S->nseg_c, sizeof(int)));
+    NCHK(hipMalloc(&S->staged, nd * sizeof(float)));
+    if (S->max_deg > N2VB_LDS_DEG && !(a.p == 1.0 && a.q == 1.0))
+        NCHK(hipMalloc(&S->cum, (size_t)B * S->max_deg * sizeof(double)));
+    S->bits = 1;
+    while ((1u << S->bits) <= (unsigned)n)
+        S->bits++;
+    if (rocprim::radix_sort_pairs(nullptr, S->tmp_bytes, S->keys, S->keys_s, S->vals, S->vals_s, S->ns_max, 0, S->bits, nullptr) !=
+        hipSuccess) {
+        nset_err("rocprim::radix_sort_pairs (size query) failed");
+        return -1;
+    }
+    NCHK(hipMalloc(&S->tmp, S->tmp_bytes));
+    return 0;
+}
+
+extern "C" mn_n2v_session *mn_n2v_begin(int n, const int *off, const int *adj, const mn_n2v_params *prm, int device) {
+    if (n <= 0 || !valid_params(prm)) {
+        nset_err("mn_n2v_begin: invalid parameters");
+        return nullptr;
+    }
+    mn_n2v_session *S = new mn_n2v_session();
+    if (session_init(S, n, off, adj, prm, device, true) != 0) {
+        delete S;
+        return nullptr;
+    }
+    (void)hipEventRecord(S->e0, nullptr);
+    return S;
+}
+extern "C" int mn_n2v_batch_walks(mn_n2v_session *S) { return S->B; }
+extern "C" int mn_n2v_sample_slots(mn_n2v_session *S) { return S->cap; }
+extern "C" int mn_n2v_samples(mn_n2v_session *S, int epoch, int w, int lo, int hi, int *d_center, int *d_target, float *d_err) {
+    NCHK(hipSetDevice(S->device));
+    if (lo < 0 || hi > S->a.n || hi <= lo || hi - lo > S->B) {
+        nset_err("mn_n2v_samples: bad walk range [%d, %d)", lo, hi);
+        return -1;
+    }
+    return n2v_samples(S, epoch, w, lo, hi, d_center, d_target, d_err);
+}
+extern "C" int mn_n2v_apply(mn_n2v_session *S, const int *d_center, const int *d_target, const float *d_err, int64_t ns) {
+    NCHK(hipSetDevice(S->device));
+    return n2v_apply(S, d_center, d_target, d_err, ns);
+}
+extern "C" int mn_n2v_sync(mn_n2v_session *S) {
+    NCHK(hipSetDevice(S->device));
     NCHK(hipDeviceSynchronize());
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    return 0;
+}
+extern "C" int mn_n2v_finish(mn_n2v_session *S, float *out, mn_n2v_stats *stats) {
+    NCHK(hipSetDevice(S->device));
+    const int n = S->a.n, dim = S->a.dim;
+    hipLaunchKernelGGL(k_n2v_normalize, dim3(n), dim3(64), (size_t)dim * sizeof(float), nullptr, S->syn0, n, dim);
+    NCHK(hipEventRecord(S->e1, nullptr));
+    NCHK(hipDeviceSynchronize());
     unsigned long long o[2];
-    NCHK(hipMemcpy(o, d.out, sizeof(o), hipMemcpyDeviceToHost));
-    NCHK(hipMemcpy(out, d.syn0, nd * sizeof(float), hipMemcpyDeviceToHost));
+    NCHK(hipMemcpy(o, S->pairs, sizeof(o), hipMemcpyDeviceToHost));
+    NCHK(hipMemcpy(out, S->syn0, (size_t)n * dim * sizeof(float), hipMemcpyDeviceToHost));
     if (stats) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, S->e0, S->e1);
         stats->pairs = (int64_t)o[0];
         stats->device_ms = ms;
     }
     return n;
+}
+extern "C" void mn_n2v_end(mn_n2v_session *S) {
+    if (!S)
+        return;
+    (void)hipSetDevice(S->device);
+    (void)hipDeviceSynchronize();
+    delete S;
+}
+
+extern "C" int mn_node2vec_train(int n, const int *off, const int *adj, const mn_n2v_params *prm, int mode, int device,
+                                 float *out, mn_n2v_stats *stats) {
+    if (stats)
+        memset(stats, 0, sizeof(*stats));
+    if (n == 0)
+        return 0;
+    if (!valid_params(prm)) {
+        nset_err("mn_node2vec_train: invalid parameters (src/node2vec.c:443-464)");
+        return -1;
+    }
+    if (mode == MN_N2V_BATCHED) {
+        mn_n2v_session *S = mn_n2v_begin(n, off, adj, prm, device);
+        if (!S)
+            return -1;
+        int rc = 0;
+        for (int epoch = 0; epoch < prm->epochs && rc == 0; epoch++)
+            for (int w = 0; w < prm->num_walks && rc == 0; w++)
+                for (int b0 = 0; b0 < n && rc == 0; b0 += S->B) {
+                    int b1 = std::min(n, b0 + S->B);
+                    rc = n2v_samples(S, epoch, w, b0, b1, S->s_center, S->s_target, S->s_err);
+                    if (rc == 0)
+                        rc = n2v_apply(S, S->s_center, S->s_target, S->s_err, (int64_t)(b1 - b0) * S->cap);
+                }
+        if (rc == 0)
+            rc = mn_n2v_finish(S, out, stats);
+        mn_n2v_end(S);
+        return rc < 0 ? -1 : n;
+    }
+    if (mode != MN_N2V_SEQUENTIAL) {
+        nset_err("mn_node2vec_train: mode %d not available", mode);
+        return -1;
+    }
+    mn_n2v_session sess;
+    mn_n2v_session *S = &sess;
+    if (session_init(S, n, off, adj, prm, device, false) != 0)
+        return -1;
+    const int dim = prm->dim;
+    size_t lds = N2V_LDS_DEG * sizeof(double) + 3 * (size_t)dim * sizeof(float) + (N2V_SIG_SIZE + 1) * sizeof(float) +
+                 (size_t)std::min(prm->walk_length, N2V_LDS_WALK) * sizeof(int) + 64;
+    NCHK(hipEventRecord(S->e0, nullptr));
+    hipLaunchKernelGGL(k_n2v_seq, dim3(1), dim3(64), lds, nullptr, S->a);
+    NCHK(hipGetLastError());
+    return mn_n2v_finish(S, out, stats) < 0 ? -1 : n;
 }

@@ -268,109 +268,112 @@ __global__ void __launch_bounds__(64)
         dst[(size_t)k * dim + d] = staged[(size_t)k * dim + d];
 }
 
-struct N2vBatchDev {
+// ───────────────────────── session: the batched schedule as begin / samples / apply / finish ─────────────────────────
+// Single-GPU training is a loop over (samples, apply); multi-GPU training lets every rank produce the samples of
+// its slice of a batch's walks, exchanges the (centre, target, err) triples (RCCL all-gather, rank order = walk
+// order) and applies the full batch on every replica — the N-GPU result is bit-identical to the 1-GPU result.
+
+struct mn_n2v_session {
+    int device = 0;
+    N2vArgs a;
+    int B = 0, cap = 0, max_deg = 0, bits = 1;
+    size_t ns_max = 0, tmp_bytes = 0;
+    // graph + model
+    int *off = nullptr, *adj = nullptr, *neg = nullptr;
+    float *syn0 = nullptr, *syn1 = nullptr, *sig = nullptr, *staged = nullptr;
+    // batch scratch
     int *s_center = nullptr, *s_target = nullptr, *keys = nullptr, *vals = nullptr, *keys_s = nullptr, *vals_s = nullptr,
-        *seg = nullptr, *nseg = nullptr, *keys_c = nullptr, *seg_c = nullptr, *nseg_c = nullptr;
-    float *s_err = nullptr, *staged = nullptr;
+        *keys_c = nullptr, *seg = nullptr, *seg_c = nullptr, *nseg = nullptr, *nseg_c = nullptr;
+    float *s_err = nullptr;
     double *cum = nullptr;
     void *tmp = nullptr;
-    ~N2vBatchDev() {
-        (void)hipFree(s_center); (void)hipFree(s_target); (void)hipFree(keys); (void)hipFree(vals); (void)hipFree(keys_s);
-        (void)hipFree(vals_s); (void)hipFree(seg); (void)hipFree(nseg); (void)hipFree(s_err); (void)hipFree(staged);
-        (void)hipFree(cum); (void)hipFree(tmp); (void)hipFree(keys_c); (void)hipFree(seg_c); (void)hipFree(nseg_c);
+    unsigned long long *pairs = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~mn_n2v_session() {
+        (void)hipFree(off); (void)hipFree(adj); (void)hipFree(neg); (void)hipFree(syn0); (void)hipFree(syn1); (void)hipFree(sig);
+        (void)hipFree(staged); (void)hipFree(s_center); (void)hipFree(s_target); (void)hipFree(keys); (void)hipFree(vals);
+        (void)hipFree(keys_s); (void)hipFree(vals_s); (void)hipFree(keys_c); (void)hipFree(seg); (void)hipFree(seg_c);
+        (void)hipFree(nseg); (void)hipFree(nseg_c); (void)hipFree(s_err); (void)hipFree(cum); (void)hipFree(tmp); (void)hipFree(pairs);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
     }
 };
 
-template <int NR> static int n2v_run_batched_t(const N2vArgs &a, int B, int max_deg, unsigned long long *d_pairs) {
-    const int N = a.n, dim = a.dim;
-    const int cap = a.walk_length * 2 * a.window * (1 + a.neg);
-    const size_t ns_max = (size_t)B * cap;
-    if (ns_max > 0x7fffffffULL) {
-        nset_err("mn_node2vec_train: batch of %d walks x %d samples exceeds 2^31", B, cap);
-        return -1;
-    }
-    N2vBatchDev d;
-    NCHK(hipMalloc(&d.s_center, ns_max * sizeof(int)));
-    NCHK(hipMalloc(&d.s_target, ns_max * sizeof(int)));
-    NCHK(hipMalloc(&d.s_err, ns_max * sizeof(float)));
-    NCHK(hipMalloc(&d.keys, ns_max * sizeof(int)));
-    NCHK(hipMalloc(&d.vals, ns_max * sizeof(int)));
-    NCHK(hipMalloc(&d.keys_s, ns_max * sizeof(int)));
-    NCHK(hipMalloc(&d.vals_s, ns_max * sizeof(int)));
-    NCHK(hipMalloc(&d.keys_c, ns_max * sizeof(int)));
-    NCHK(hipMalloc(&d.seg, ((size_t)N + 1) * sizeof(int)));
-    NCHK(hipMalloc(&d.seg_c, ((size_t)N + 1) * sizeof(int)));
-    NCHK(hipMalloc(&d.nseg, sizeof(int)));
-    NCHK(hipMalloc(&d.nseg_c, sizeof(int)));
-    NCHK(hipMalloc(&d.staged, (size_t)N * dim * sizeof(float)));
-    if (max_deg > N2VB_LDS_DEG && !(a.p == 1.0 && a.q == 1.0))
-        NCHK(hipMalloc(&d.cum, (size_t)B * max_deg * sizeof(double)));
-    int bits = 1;
-    while ((1u << bits) <= (unsigned)N)
-        bits++;
-    size_t tmp_bytes = 0;
-    if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, d.keys, d.keys_s, d.vals, d.vals_s, ns_max, 0, bits, nullptr) != hipSuccess) {
-        nset_err("rocprim::radix_sort_pairs (size query) failed");
-        return -1;
-    }
-    NCHK(hipMalloc(&d.tmp, tmp_bytes));
+template <int NR>
+static int n2v_samples_t(mn_n2v_session *S, int epoch, int w, int lo, int hi, int *d_center, int *d_target, float *d_err) {
     N2vBatchArgs b;
     memset(&b, 0, sizeof(b));
-    b.a = a;
-    b.total_words = (double)N * a.num_walks * a.walk_length * a.epochs;
-    b.cap = cap;
-    b.s_center = d.s_center;
-    b.s_target = d.s_target;
-    b.s_err = d.s_err;
-    b.cum_scratch = d.cum;
-    b.max_deg = max_deg;
-    b.pairs_out = d_pairs;
-    const size_t lds = N2VB_LDS_DEG * sizeof(double) + (size_t)a.walk_length * sizeof(int) + 64;
-    for (int epoch = 0; epoch < a.epochs; epoch++)
-        for (int w = 0; w < a.num_walks; w++)
-            for (int b0 = 0; b0 < N; b0 += B) {
-                b.epoch = epoch;
-                b.w = w;
-                b.b0 = b0;
-                b.b1 = b0 + B < N ? b0 + B : N;
-                const int nw = b.b1 - b.b0;
-                const int ns = nw * cap;
-                const unsigned g256 = (unsigned)((ns + 255) / 256);
-                hipLaunchKernelGGL((k_n2v_walk_grad<NR>), dim3(nw), dim3(64), lds, nullptr, b);
-                // centres: syn0[c] += Σ err · syn1neg_old[t]  → staged
-                hipLaunchKernelGGL(k_n2v_keys, dim3(g256), dim3(256), 0, nullptr, d.s_center, ns, N, d.keys, d.vals);
-                if (rocprim::radix_sort_pairs(d.tmp, tmp_bytes, d.keys, d.keys_c, d.vals, d.vals_s, (size_t)ns, 0, bits, nullptr) !=
-                    hipSuccess) {
-                    nset_err("rocprim::radix_sort_pairs failed");
-                    return -1;
-                }
-                NCHK(hipMemsetAsync(d.nseg_c, 0, sizeof(int), nullptr));
-                hipLaunchKernelGGL(k_n2v_segments, dim3(g256), dim3(256), 0, nullptr, d.keys_c, ns, N, d.seg_c, d.nseg_c);
-                hipLaunchKernelGGL((k_n2v_apply<NR>), dim3(N), dim3(64), 0, nullptr, d.keys_c, d.vals_s, d.seg_c, d.nseg_c, ns,
-                                   d.s_target, d.s_err, a.syn0, a.syn1neg, d.staged, dim);
-                // targets: syn1neg[t] += Σ err · syn0_old[c]  (syn0 is still the old one) → in place
-                hipLaunchKernelGGL(k_n2v_keys, dim3(g256), dim3(256), 0, nullptr, d.s_target, ns, N, d.keys, d.vals);
-                if (rocprim::radix_sort_pairs(d.tmp, tmp_bytes, d.keys, d.keys_s, d.vals, d.vals_s, (size_t)ns, 0, bits, nullptr) !=
-                    hipSuccess) {
-                    nset_err("rocprim::radix_sort_pairs failed");
-                    return -1;
-                }
-                NCHK(hipMemsetAsync(d.nseg, 0, sizeof(int), nullptr));
-                hipLaunchKernelGGL(k_n2v_segments, dim3(g256), dim3(256), 0, nullptr, d.keys_s, ns, N, d.seg, d.nseg);
-                hipLaunchKernelGGL((k_n2v_apply<NR>), dim3(N), dim3(64), 0, nullptr, d.keys_s, d.vals_s, d.seg, d.nseg, ns,
-                                   d.s_center, d.s_err, a.syn1neg, a.syn0, a.syn1neg, dim);
-                hipLaunchKernelGGL(k_n2v_commit, dim3(N), dim3(64), 0, nullptr, d.keys_c, d.seg_c, d.nseg_c, d.staged, a.syn0, dim);
-                NCHK(hipGetLastError());
-            }
-    NCHK(hipDeviceSynchronize());
+    b.a = S->a;
+    b.total_words = (double)S->a.n * S->a.num_walks * S->a.walk_length * S->a.epochs;
+    b.cap = S->cap;
+    b.s_center = d_center;
+    b.s_target = d_target;
+    b.s_err = d_err;
+    b.cum_scratch = S->cum;
+    b.max_deg = S->max_deg;
+    b.pairs_out = S->pairs;
+    b.epoch = epoch;
+    b.w = w;
+    b.b0 = lo;
+    b.b1 = hi;
+    const size_t lds = N2VB_LDS_DEG * sizeof(double) + (size_t)S->a.walk_length * sizeof(int) + 64;
+    hipLaunchKernelGGL((k_n2v_walk_grad<NR>), dim3(hi - lo), dim3(64), lds, nullptr, b);
+    NCHK(hipGetLastError());
     return 0;
 }
 
-static int n2v_run_batched(const N2vArgs &a, int B, int max_deg, unsigned long long *d_pairs) {
-    const int nr = (a.dim + 63) / 64;
-    if (nr <= 1) return n2v_run_batched_t<1>(a, B, max_deg, d_pairs);
-    if (nr <= 2) return n2v_run_batched_t<2>(a, B, max_deg, d_pairs);
-    if (nr <= 4) return n2v_run_batched_t<4>(a, B, max_deg, d_pairs);
-    if (nr <= 8) return n2v_run_batched_t<8>(a, B, max_deg, d_pairs);
-    return n2v_run_batched_t<16>(a, B, max_deg, d_pairs);
+template <int NR>
+static int n2v_apply_t(mn_n2v_session *S, const int *d_center, const int *d_target, const float *d_err, int64_t ns64) {
+    const N2vArgs &a = S->a;
+    const int N = a.n, dim = a.dim;
+    if (ns64 <= 0)
+        return 0;
+    if ((size_t)ns64 > S->ns_max) {
+        nset_err("mn_n2v_apply: %lld samples exceed the session capacity %zu", (long long)ns64, S->ns_max);
+        return -1;
+    }
+    const int ns = (int)ns64;
+    const unsigned g256 = (unsigned)((ns + 255) / 256);
+    // centres: syn0[c] += Σ err · syn1neg_old[t]  → staged
+    hipLaunchKernelGGL(k_n2v_keys, dim3(g256), dim3(256), 0, nullptr, d_center, ns, N, S->keys, S->vals);
+    if (rocprim::radix_sort_pairs(S->tmp, S->tmp_bytes, S->keys, S->keys_c, S->vals, S->vals_s, (size_t)ns, 0, S->bits, nullptr) !=
+        hipSuccess) {
+        nset_err("rocprim::radix_sort_pairs failed");
+        return -1;
+    }
+    NCHK(hipMemsetAsync(S->nseg_c, 0, sizeof(int), nullptr));
+    hipLaunchKernelGGL(k_n2v_segments, dim3(g256), dim3(256), 0, nullptr, S->keys_c, ns, N, S->seg_c, S->nseg_c);
+    hipLaunchKernelGGL((k_n2v_apply<NR>), dim3(N), dim3(64), 0, nullptr, S->keys_c, S->vals_s, S->seg_c, S->nseg_c, ns, d_target,
+                       d_err, a.syn0, a.syn1neg, S->staged, dim);
+    // targets: syn1neg[t] += Σ err · syn0_old[c]  (syn0 is still the old one) → in place
+    hipLaunchKernelGGL(k_n2v_keys, dim3(g256), dim3(256), 0, nullptr, d_target, ns, N, S->keys, S->vals);
+    if (rocprim::radix_sort_pairs(S->tmp, S->tmp_bytes, S->keys, S->keys_s, S->vals, S->vals_s, (size_t)ns, 0, S->bits, nullptr) !=
+        hipSuccess) {
+        nset_err("rocprim::radix_sort_pairs failed");
+        return -1;
+    }
+    NCHK(hipMemsetAsync(S->nseg, 0, sizeof(int), nullptr));
+    hipLaunchKernelGGL(k_n2v_segments, dim3(g256), dim3(256), 0, nullptr, S->keys_s, ns, N, S->seg, S->nseg);
+    hipLaunchKernelGGL((k_n2v_apply<NR>), dim3(N), dim3(64), 0, nullptr, S->keys_s, S->vals_s, S->seg, S->nseg, ns, d_center, d_err,
+                       a.syn1neg, a.syn0, a.syn1neg, dim);
+    hipLaunchKernelGGL(k_n2v_commit, dim3(N), dim3(64), 0, nullptr, S->keys_c, S->seg_c, S->nseg_c, S->staged, a.syn0, dim);
+    NCHK(hipGetLastError());
+    return 0;
+}
+
+#define N2V_DISPATCH(fn, ...)                                         \
+    do {                                                              \
+        const int nr__ = (S->a.dim + 63) / 64;                        \
+        if (nr__ <= 1) return fn<1>(__VA_ARGS__);                     \
+        if (nr__ <= 2) return fn<2>(__VA_ARGS__);                     \
+        if (nr__ <= 4) return fn<4>(__VA_ARGS__);                     \
+        if (nr__ <= 8) return fn<8>(__VA_ARGS__);                     \
+        return fn<16>(__VA_ARGS__);                                   \
+    } while (0)
+
+static int n2v_samples(mn_n2v_session *S, int epoch, int w, int lo, int hi, int *c, int *t, float *e) {
+    N2V_DISPATCH(n2v_samples_t, S, epoch, w, lo, hi, c, t, e);
+}
+static int n2v_apply(mn_n2v_session *S, const int *c, const int *t, const float *e, int64_t ns) {
+    N2V_DISPATCH(n2v_apply_t, S, c, t, e, ns);
 }

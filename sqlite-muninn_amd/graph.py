@@ -34,6 +34,14 @@ GRAPH_SYMBOLS = [
     ("mn_node2vec_train", C.c_int, [C.c_int, _i32p, _i32p, C.POINTER(N2vParams), C.c_int, C.c_int,
                                     np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS"), C.POINTER(N2vStats)]),
     ("mn_node2vec_last_error", C.c_char_p, []),
+    ("mn_n2v_begin", C.c_void_p, [C.c_int, _i32p, _i32p, C.POINTER(N2vParams), C.c_int]),
+    ("mn_n2v_batch_walks", C.c_int, [C.c_void_p]),
+    ("mn_n2v_sample_slots", C.c_int, [C.c_void_p]),
+    ("mn_n2v_samples", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("mn_n2v_apply", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    ("mn_n2v_sync", C.c_int, [C.c_void_p]),
+    ("mn_n2v_finish", C.c_int, [C.c_void_p, np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS"), C.POINTER(N2vStats)]),
+    ("mn_n2v_end", None, [C.c_void_p]),
     ("mn_graph_create", C.c_void_p, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     ("mn_graph_destroy", None, [C.c_void_p]),
     ("mn_graph_last_error", C.c_char_p, []),

@@ -48,3 +48,76 @@ def max_over_ranks(seconds: float, device) -> float:
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def node2vec_train_distributed(off, adj, dim, p=1.0, q=1.0, num_walks=10, walk_length=80, window=5, neg_samples=5,
+                               learning_rate=0.025, epochs=1, batch_walks=0, device=0, group=None):
+    """Data-parallel Node2Vec (config 4): every rank holds a replica of syn0/syn1neg; the walks of each batch are
+    split over the ranks (contiguous slices, rank order = walk order); each rank computes the (centre, target, err)
+    samples of its slice on its GPU, the samples are all-gathered (RCCL over xGMI with backend "nccl"; staged through
+    the host with "gloo") and every rank applies the whole batch.  Because the gathered sample order equals the
+    single-GPU order, the embeddings are bit-identical to mn_node2vec_train(..., MN_N2V_BATCHED) on one GPU.
+    Returns (embeddings [n][dim] float32, stats)."""
+    import ctypes as C
+
+    import numpy as np
+
+    from .graph import N2vParams, N2vStats, _glib
+    from .hnsw import MuninnHipError
+
+    L = _glib()
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    off = np.ascontiguousarray(off, np.int32)
+    adj = np.ascontiguousarray(adj if len(adj) else np.zeros(1, np.int32), np.int32)
+    n = len(off) - 1
+    prm = N2vParams(dim, p, q, num_walks, walk_length, window, neg_samples, learning_rate, epochs, batch_walks)
+    S = L.mn_n2v_begin(n, off, adj, C.byref(prm), device)
+    if not S:
+        raise MuninnHipError((L.mn_node2vec_last_error() or b"").decode())
+    try:
+        B, cap = L.mn_n2v_batch_walks(S), L.mn_n2v_sample_slots(S)
+        dev = torch.device("cuda", device)
+        host_staged = dist.get_backend(group) == "gloo"
+        per_max = (B + world - 1) // world
+        lc = torch.empty(per_max * cap, dtype=torch.int32, device=dev)
+        lt = torch.empty(per_max * cap, dtype=torch.int32, device=dev)
+        le = torch.empty(per_max * cap, dtype=torch.float32, device=dev)
+
+        def gather(x, cnt):
+            if host_staged:
+                src = x[:cnt].cpu().contiguous()
+                out = torch.empty(world * cnt, dtype=x.dtype)
+                dist.all_gather(list(out.chunk(world)), src, group=group)
+                return out.to(dev)
+            out = torch.empty(world * cnt, dtype=x.dtype, device=dev)
+            dist.all_gather_into_tensor(out, x[:cnt].contiguous(), group=group)
+            return out
+
+        for epoch in range(epochs):
+            for w in range(num_walks):
+                for b0 in range(0, n, B):
+                    b1 = min(n, b0 + B)
+                    per = (b1 - b0 + world - 1) // world
+                    lo = min(b1, b0 + rank * per)
+                    hi = min(b1, lo + per)
+                    lc[:per * cap].fill_(-1)
+                    lt[:per * cap].fill_(-1)
+                    le[:per * cap].zero_()
+                    torch.cuda.synchronize(dev)
+                    if hi > lo and L.mn_n2v_samples(S, epoch, w, lo, hi, lc.data_ptr(), lt.data_ptr(), le.data_ptr()) != 0:
+                        raise MuninnHipError((L.mn_node2vec_last_error() or b"").decode())
+                    L.mn_n2v_sync(S)
+                    gc, gt, ge = gather(lc, per * cap), gather(lt, per * cap), gather(le, per * cap)
+                    torch.cuda.synchronize(dev)
+                    if L.mn_n2v_apply(S, gc.data_ptr(), gt.data_ptr(), ge.data_ptr(), world * per * cap) != 0:
+                        raise MuninnHipError((L.mn_node2vec_last_error() or b"").decode())
+                    L.mn_n2v_sync(S)
+        out = np.zeros((n, dim), np.float32)
+        st = N2vStats()
+        if L.mn_n2v_finish(S, out, C.byref(st)) < 0:
+            raise MuninnHipError((L.mn_node2vec_last_error() or b"").decode())
+        pairs = torch.tensor([st.pairs], dtype=torch.int64, device="cpu" if host_staged else dev)
+        dist.all_reduce(pairs, group=group)
+        return out, {"pairs": int(pairs.item()), "device_ms": st.device_ms, "batch_walks": B}
+    finally:
+        L.mn_n2v_end(S)

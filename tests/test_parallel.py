@@ -13,6 +13,22 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _collect(procs, q, n, timeout):
+    """q.get with fail-fast: a worker that died (import error, assertion) must not cost the whole timeout"""
+    import queue
+    import time
+
+    out, t0 = [], time.time()
+    while len(out) < n:
+        try:
+            out.append(q.get(timeout=2))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            assert not dead, f"worker exited with {dead}"
+            assert time.time() - t0 < timeout, "timeout waiting for workers"
+    return out
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -56,7 +72,7 @@ def test_sharded_topk_merge_world2():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda r: r[0])
+    res = sorted(_collect(procs, q, world, 240), key=lambda r: r[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -92,3 +108,48 @@ def test_merge_tie_rule_single_process():
         assert mi.tolist() == [[5, 7, -1]] and mc.tolist() == [2]
     finally:
         dist.destroy_process_group()
+
+
+def _n2v_worker(rank, world, port, q):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import muninn_amd
+    from oracle import orc_graph as og
+    from oracle.graph_cases import planted
+
+    s, d, _ = planted(1200, 6, 0.08, 0.002, 7)
+    g = og.N2vGraph(s, d)
+    emb, st = muninn_amd.pkg.parallel.node2vec_train_distributed(g.off, g.adj, 32, 1.0, 1.0, 2, 20, 3, 3, 0.025, 1, batch_walks=50)
+    q.put((rank, emb, st))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_node2vec_data_parallel_world2_bit_identical_to_one_gpu(gpu):
+    """Two ranks (gloo exchange, both on the one GPU of the box) train data-parallel; every replica must equal the
+    single-process MN_N2V_BATCHED result bit for bit, which itself equals the CPU restatement."""
+    from oracle import orc_graph as og
+    from oracle.graph_cases import planted
+
+    s, d, _ = planted(1200, 6, 0.08, 0.002, 7)
+    g = og.N2vGraph(s, d)
+    single, st1 = gpu.node2vec_train(g.off, g.adj, 32, 1.0, 1.0, 2, 20, 3, 3, 0.025, 1, mode=gpu.N2V_BATCHED, batch_walks=50)
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_n2v_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(_collect(procs, q, world, 300), key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, emb, st in res:
+        assert np.array_equal(emb.view(np.int32), single.view(np.int32)), rank
+        assert st["pairs"] == st1["pairs"]
