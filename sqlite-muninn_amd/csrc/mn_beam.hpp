@@ -122,6 +122,7 @@ DEVI uint2 heap_pop(WHeap &h, int lane) {
 // ───────────────────────── beam search ─────────────────────────
 
 struct WaveCtx {
+    float *tile = nullptr; // LDS staging tile for the coalesced SSE-order loads (k_beam), or null
     const float *q;  // LDS query, zero padded to ld
     float qnorm;
     int *scratch;    // LDS, 64 ints
@@ -142,7 +143,7 @@ DEVI const int *link_row(const MnDevIndex &ix, int node, int level, int &W) {
 template <int ORDER, int NCH, bool COH = false>
 DEVI int greedy_layer(const MnDevIndex &ix, WaveCtx &w, int entry, int level, int lane) {
     int cur = entry;
-    float cur_d = rows_distance<ORDER, NCH>(ix, w.q, w.qnorm, cur, 1, lane);
+    float cur_d = rows_distance<ORDER, NCH>(ix, w.q, w.qnorm, cur, 1, lane, w.tile);
     cur_d = __shfl(cur_d, 0);
     w.n_dist += 1;
     int changed = 1;
@@ -167,7 +168,7 @@ DEVI int greedy_layer(const MnDevIndex &ix, WaveCtx &w, int entry, int level, in
                 w.scratch[rank] = nb;
             __builtin_amdgcn_wave_barrier();
             int myslot = lane < n ? w.scratch[lane] : 0;
-            float d = rows_distance<ORDER, NCH>(ix, w.q, w.qnorm, myslot, n, lane);
+            float d = rows_distance<ORDER, NCH>(ix, w.q, w.qnorm, myslot, n, lane, w.tile);
             w.n_dist += n;
             unsigned long long better = __ballot(lane < n && d < cur_d);
             if (!better)
@@ -197,7 +198,7 @@ DEVI void beam_layer(const MnDevIndex &ix, WaveCtx &w, WHeap &cand, WHeap &res, 
     cand.size = 0;
     res.size = 0;
     if (!ix.deleted[entry]) { // :360-366
-        float d = rows_distance<ORDER, NCH>(ix, w.q, w.qnorm, entry, 1, lane);
+        float d = rows_distance<ORDER, NCH>(ix, w.q, w.qnorm, entry, 1, lane, w.tile);
         d = __shfl(d, 0);
         w.n_dist += 1;
         heap_push(cand, entry, d, lane);
@@ -245,7 +246,7 @@ DEVI void beam_layer(const MnDevIndex &ix, WaveCtx &w, WHeap &cand, WHeap &res, 
                 w.scratch[rank] = nb;
             __builtin_amdgcn_wave_barrier();
             int myslot = lane < n ? w.scratch[lane] : 0;
-            float d = rows_distance<ORDER, NCH>(ix, w.q, w.qnorm, myslot, n, lane);
+            float d = rows_distance<ORDER, NCH>(ix, w.q, w.qnorm, myslot, n, lane, w.tile);
             w.n_dist += n;
             // :413-425, in list order.  Once the result set is full an element can only be accepted
             // if it beats the worst AT THAT MOMENT, which never exceeds the worst now: pre-filter.

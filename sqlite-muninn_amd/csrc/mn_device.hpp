@@ -59,17 +59,22 @@ struct MnSearchArgs {
     uint2 *res_ovf;          // [nq][res_gcap]
     int res_gcap;
     unsigned long long *counters; // [0] n_dist [1] n_expanded [2] overflowed queries
+    int use_tile;                 // SSE order: stage candidate rows through the LDS tile (coalesced loads)
 };
 
 // LDS budget per wavefront (items are 8 B: f32 distance bits, int32 slot)
-#define MN_CAND_LDS 512
+#ifndef MN_CAND_LDS
+#define MN_CAND_LDS 256
+#endif
+#ifndef MN_RES_LDS
 #define MN_RES_LDS 256
+#endif
 
 // host-callable launchers (mn_kernels.hip)
 void mn_launch_norms(const MnDevIndex &ix, int first_slot, int n, float *norms_out, hipStream_t st);
 void mn_launch_dist_batch(int metric, int order, const float *d_query, const float *d_rows, long long n, int dim, int ld,
                           float *d_out, hipStream_t st);
-size_t mn_search_lds_bytes(int ld);
+size_t mn_search_lds_bytes(int ld, bool tile);
 int mn_launch_search(const MnDevIndex &ix, const MnSearchArgs &a, bool build, hipStream_t st);
 void mn_launch_bruteforce(const MnDevIndex &ix, const float *d_queries, long long nq, int k, long long *d_out_ids,
                           float *d_scratch, hipStream_t st);

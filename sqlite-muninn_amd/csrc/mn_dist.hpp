@@ -53,13 +53,74 @@ DEVI float wave_row_generic(const float *__restrict__ row, const float *q_lds, i
 
 // SSE order: the 4 lanes (lane&3 = j) of a row group walk accumulator j; every lane of the group
 // returns the finished sum.  `row` may point to global or LDS memory.
+DEVI float quad_xor1(float v) { // lanes (0,1) and (2,3) of each quad exchange
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+}
+DEVI float quad_xor2(float v) { // lanes (0,2) and (1,3) of each quad exchange
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
+}
+
 template <bool L2>
 DEVI float sse_row(const float *__restrict__ row, const float *q_lds, int dim, int lane) {
     const int j = lane & 3;
-    const int steps = dim >> 2;
+    const int steps = dim >> 2; // chain positions (one per group of 4 elements)
     float s = 0.0f;
-#pragma unroll 8
-    for (int c = 0; c < steps; c++) {
+    int c = 0;
+#ifdef MN_SSE_QUAD // measured slower on gfx950 (VALU-bound transpose: 38.1 vs 31.5 ms per 10k queries); kept for reference
+    // Blocks of 4 chain positions: quad lane q fetches the float4 of position 4t+q (the quad reads 64
+    // contiguous bytes of the row), forms its four products, and a 4x4 transpose inside the quad (two
+    // DPP exchange rounds) hands accumulator j its terms of positions 4t..4t+3, added in that order.
+    const bool b0 = j & 1, b1 = j & 2;
+    const int blocks = steps >> 2;
+#pragma unroll 4
+    for (int t = 0; t < blocks; t++) {
+        const float4 b = *reinterpret_cast<const float4 *>(row + 16 * t + 4 * j);
+        const float4 a = *reinterpret_cast<const float4 *>(q_lds + 16 * t + 4 * j);
+        float p0, p1, p2, p3;
+        if (L2) {
+            float d0 = __fsub_rn(a.x, b.x), d1 = __fsub_rn(a.y, b.y), d2 = __fsub_rn(a.z, b.z), d3 = __fsub_rn(a.w, b.w);
+            p0 = __fmul_rn(d0, d0);
+            p1 = __fmul_rn(d1, d1);
+            p2 = __fmul_rn(d2, d2);
+            p3 = __fmul_rn(d3, d3);
+        } else {
+            p0 = __fmul_rn(a.x, b.x);
+            p1 = __fmul_rn(a.y, b.y);
+            p2 = __fmul_rn(a.z, b.z);
+            p3 = __fmul_rn(a.w, b.w);
+        }
+        // round 1: exchange across lane bit 0 — register pairs (0,1) and (2,3)
+        float r0 = quad_xor1(b0 ? p0 : p1), r1 = quad_xor1(b0 ? p2 : p3);
+        if (b0) {
+            p0 = r0;
+            p2 = r1;
+        } else {
+            p1 = r0;
+            p3 = r1;
+        }
+        // round 2: exchange across lane bit 1 — register pairs (0,2) and (1,3)
+        r0 = quad_xor2(b1 ? p0 : p2);
+        r1 = quad_xor2(b1 ? p1 : p3);
+        if (b1) {
+            p0 = r0;
+            p1 = r1;
+        } else {
+            p2 = r0;
+            p3 = r1;
+        }
+        // now p_u = term of accumulator j at chain position 4t+u
+        s = __fadd_rn(s, p0);
+        s = __fadd_rn(s, p1);
+        s = __fadd_rn(s, p2);
+        s = __fadd_rn(s, p3);
+    }
+    c = blocks << 2;
+#endif
+#ifndef MN_SSE_UNROLL
+#define MN_SSE_UNROLL 16
+#endif
+#pragma unroll MN_SSE_UNROLL
+    for (; c < steps; c++) {
         float b = row[4 * c + j];
         float a = q_lds[4 * c + j];
         float p;
@@ -87,12 +148,104 @@ DEVI float sse_row(const float *__restrict__ row, const float *q_lds, int dim, i
     return sum;
 }
 
+// SSE order with coalesced loads: 16 rows at a time, 128 elements of each per stage.  A wave-instruction
+// fetches two rows' 512-B pieces as float4 per lane (full 128-B lines), the pieces are laid down in an
+// LDS tile [16][128+4] and lane (r, j) then walks accumulator j of row r through the tile in the
+// reference's order — same bits as sse_row, HBM access shape of the wave-order kernel.
+#define MN_TILE_ROW 132 // floats per tile row: 128 + 4 pad → conflict-free b32 column reads
+#define MN_TILE_FLOATS (16 * MN_TILE_ROW)
+
+template <bool L2>
+DEVI float sse_rows_tiled(const MnDevIndex &ix, const float *q_lds, float *tile, int myslot, int n, int lane) {
+    float mine = 0.0f;
+    const int j = lane & 3, r = lane >> 2;
+    const int steps = ix.dim >> 2;
+    const int half = lane >> 5, l32 = lane & 31;
+    for (int t = 0; t < n; t += 16) {
+        float s = 0.0f;
+        const int nh = (ix.ld + 127) >> 7;
+        // row base pointers of the two rows each load instruction serves (lanes 0-31 / 32-63)
+        const float *rowp[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            int rr = t + 2 * i + half;
+            int sl = __shfl(myslot, rr < n ? rr : n - 1);
+            rowp[i] = ix.vectors + (size_t)sl * ix.ld + (l32 << 2);
+        }
+        float4 vn[8]; // software pipeline: stage h+1 is in flight while stage h is consumed from LDS
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            vn[i] = (l32 << 2) < ix.ld ? *reinterpret_cast<const float4 *>(rowp[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int h = 0; h < nh; h++) {
+            float4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                v[i] = vn[i];
+            const int en = ((h + 1) << 7) + (l32 << 2);
+            if (h + 1 < nh) {
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    vn[i] = en < ix.ld ? *reinterpret_cast<const float4 *>(rowp[i] + ((h + 1) << 7))
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                *reinterpret_cast<float4 *>(tile + (2 * i + half) * MN_TILE_ROW + (l32 << 2)) = v[i];
+            __builtin_amdgcn_wave_barrier();
+            const int c0 = h << 5; // chain positions of this stage: c0 .. c0+31
+            const int cn = steps - c0 < 32 ? steps - c0 : 32;
+            const float *trow = tile + r * MN_TILE_ROW + j;
+            const float *qrow = q_lds + (h << 7) + j;
+#pragma unroll 8
+            for (int c = 0; c < cn; c++) {
+                float b = trow[4 * c];
+                float a = qrow[4 * c];
+                float p;
+                if (L2) {
+                    float d = __fsub_rn(a, b);
+                    p = __fmul_rn(d, d);
+                } else {
+                    p = __fmul_rn(a, b);
+                }
+                s = __fadd_rn(s, p);
+            }
+        }
+        const int g = lane & ~3;
+        float s0 = __shfl(s, g), s1 = __shfl(s, g + 1), s2 = __shfl(s, g + 2), s3 = __shfl(s, g + 3);
+        float sum = __fadd_rn(__fadd_rn(__fadd_rn(s0, s1), s2), s3);
+        if (steps * 4 < ix.dim) { // scalar tail (src/vec_math.c:91-94)
+            int rr = t + r;
+            int sl = __shfl(myslot, rr < n ? rr : n - 1);
+            const float *row = ix.vectors + (size_t)sl * ix.ld;
+            for (int i = steps * 4; i < ix.dim; i++) {
+                float a = q_lds[i], b = row[i], p;
+                if (L2) {
+                    float d = __fsub_rn(a, b);
+                    p = __fmul_rn(d, d);
+                } else {
+                    p = __fmul_rn(a, b);
+                }
+                sum = __fadd_rn(sum, p);
+            }
+        }
+        float got = __shfl(sum, ((lane - t) & 15) << 2);
+        if (lane >= t && lane < t + 16)
+            mine = got;
+    }
+    return mine;
+}
+
 // Raw accumulation (dot or Σd²) of `n` rows (slot per lane, lanes < n valid) against q_lds.
 // Returns, in lane i < n, the value for row i.
 template <int ORDER, int NCH, bool L2>
-DEVI float rows_accumulate(const MnDevIndex &ix, const float *q_lds, int myslot, int n, int lane) {
+DEVI float rows_accumulate(const MnDevIndex &ix, const float *q_lds, int myslot, int n, int lane, float *tile = nullptr) {
     float mine = 0.0f;
     if (ORDER == MN_ORDER_SSE_V) {
+#ifdef MN_SSE_TILE_PATH // opt-in: same bits, same speed as the strided walk on gfx950 (both sit at the gather ceiling)
+        if (tile)
+            return sse_rows_tiled<L2>(ix, q_lds, tile, myslot, n, lane);
+#endif
         for (int t = 0; t < n; t += 16) {
             int r = t + (lane >> 2);
             int s = __shfl(myslot, r < n ? r : n - 1);
@@ -162,11 +315,12 @@ DEVI float rows_accumulate(const MnDevIndex &ix, const float *q_lds, int myslot,
 
 // distances of rows myslot[0..n) to the query in q_lds (qnorm = |q|² for cosine)
 template <int ORDER, int NCH>
-DEVI float rows_distance(const MnDevIndex &ix, const float *q_lds, float qnorm, int myslot, int n, int lane) {
+DEVI float rows_distance(const MnDevIndex &ix, const float *q_lds, float qnorm, int myslot, int n, int lane,
+                         float *tile = nullptr) {
     if (ix.metric == 0) {
-        return rows_accumulate<ORDER, NCH, true>(ix, q_lds, myslot, n, lane);
+        return rows_accumulate<ORDER, NCH, true>(ix, q_lds, myslot, n, lane, tile);
     }
-    float dot = rows_accumulate<ORDER, NCH, false>(ix, q_lds, myslot, n, lane);
+    float dot = rows_accumulate<ORDER, NCH, false>(ix, q_lds, myslot, n, lane, tile);
     if (ix.metric == 2)
         return -dot; // src/vec_math.c:142
     float nb = (lane < n) ? ix.norms[myslot] : 1.0f;

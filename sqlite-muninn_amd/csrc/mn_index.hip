@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -475,6 +476,14 @@ static int prepare_search_ws(mn_index *x, int64_t nq, int ef, MnSearchArgs &a) {
     a.counters = x->ws_counters.p;
     a.bitmap_up = nullptr;
     a.bmu_words = 0;
+    {
+#ifdef MN_SSE_TILE_PATH
+        const char *e = getenv("MN_SSE_TILE"); // tuning knob of the opt-in tiled SSE path
+        a.use_tile = e ? atoi(e) : 1;
+#else
+        a.use_tile = 0;
+#endif
+    }
     return 0;
 }
 

@@ -18,6 +18,7 @@
 //                  exact order (separate mul/add, ((t0+t1)+t2)+t3, scalar tail)
 // Build with -ffp-contract=off; the WAVE path uses explicit fmaf, the SSE path explicit *_rn ops.
 #include "mn_device.hpp"
+#include <cstdlib>
 
 #include "mn_dist.hpp"
 
@@ -154,6 +155,7 @@ __global__ void __launch_bounds__(64) k_beam(MnDevIndex ix, MnSearchArgs a) {
     uint2 *res_l = cand_l + MN_CAND_LDS;
     int *scratch = reinterpret_cast<int *>(res_l + MN_RES_LDS);
     float *q = reinterpret_cast<float *>(scratch + 64);
+    float *tile = q + ix.ld; // SSE order only (mn_search_lds_bytes)
 
     int qslot = -1;
     const float *qsrc;
@@ -170,6 +172,7 @@ __global__ void __launch_bounds__(64) k_beam(MnDevIndex ix, MnSearchArgs a) {
 
     WaveCtx w;
     w.q = q;
+    w.tile = (ORDER == MN_ORDER_SSE_V && a.use_tile) ? tile : nullptr;
     w.scratch = scratch;
     w.n_dist = 0;
     w.n_exp = 0;
@@ -252,14 +255,20 @@ __global__ void __launch_bounds__(64) k_beam(MnDevIndex ix, MnSearchArgs a) {
     }
 }
 
-size_t mn_search_lds_bytes(int ld) {
-    return (size_t)(MN_CAND_LDS + MN_RES_LDS) * sizeof(uint2) + 64 * sizeof(int) + (size_t)ld * sizeof(float);
+size_t mn_search_lds_bytes(int ld, bool tile) {
+    size_t b = (size_t)(MN_CAND_LDS + MN_RES_LDS) * sizeof(uint2) + 64 * sizeof(int) + (size_t)ld * sizeof(float);
+    if (tile)
+        b += MN_TILE_FLOATS * sizeof(float);
+    // tuning knob: extra (unused) LDS per wavefront lowers the waves resident per CU
+    if (const char *pad = getenv("MN_LDS_PAD_BYTES"))
+        b += (size_t)atoi(pad);
+    return b;
 }
 
 template <int ORDER, int NCH>
 static void launch_beam(const MnDevIndex &ix, const MnSearchArgs &a, bool build, hipStream_t st) {
     dim3 grid((unsigned)a.nq), block(64);
-    size_t lds = mn_search_lds_bytes(ix.ld);
+    size_t lds = mn_search_lds_bytes(ix.ld, ORDER == MN_ORDER_SSE_V && a.use_tile);
     if (build)
         hipLaunchKernelGGL((k_beam<ORDER, NCH, true>), grid, block, lds, st, ix, a);
     else
