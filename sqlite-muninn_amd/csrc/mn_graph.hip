@@ -53,6 +53,8 @@ template <bool COH> DEVI double ld_d(const double *p) {
 }
 
 // Returns the community node v should move to (== its current one if no strictly positive gain).
+// ec/ew/el: staging for the node's edges (community, weight, eligible) in list order — LDS for degree
+// <= LEI_CAP, global scratch otherwise; both 16-byte aligned, capacity rounded up to a multiple of 4.
 template <bool COH>
 DEVI int best_move(const DevGraph &g, int v, const int *label, const double *sum_tot, const double *kdeg, double m,
                    double resolution, int use_both, const int *elig_part, int *ec, double *ew, unsigned char *el, int lane,
@@ -60,52 +62,72 @@ DEVI int best_move(const DevGraph &g, int v, const int *label, const double *sum
     const int o0 = g.off_out[v], d_out = g.off_out[v + 1] - o0;
     const int i0 = use_both ? g.off_in[v] : 0, d_in = use_both ? g.off_in[v + 1] - i0 : 0;
     const int d = d_out + d_in;
+    const int d4 = (d + 3) & ~3;
     const int old = ld_i<COH>(label + v);
     const int mypart = elig_part ? elig_part[v] : 0;
     __builtin_amdgcn_wave_barrier();
-    for (int e = lane; e < d; e += 64) {
-        int t;
-        double w;
-        if (e < d_out) {
-            t = g.tgt_out[o0 + e];
-            w = g.w_out ? g.w_out[o0 + e] : 1.0;
-        } else {
-            t = g.tgt_in[i0 + (e - d_out)];
-            w = g.w_in ? g.w_in[i0 + (e - d_out)] : 1.0;
+    for (int e = lane; e < d4; e += 64) {
+        int c = -2; // padding never matches a community
+        double w = 0.0;
+        unsigned char ok = 0;
+        if (e < d) {
+            int t;
+            if (e < d_out) {
+                t = g.tgt_out[o0 + e];
+                w = g.w_out ? g.w_out[o0 + e] : 1.0;
+            } else {
+                t = g.tgt_in[i0 + (e - d_out)];
+                w = g.w_in ? g.w_in[i0 + (e - d_out)] : 1.0;
+            }
+            c = ld_i<COH>(label + t);
+            ok = (!elig_part || elig_part[t] == mypart) ? 1 : 0;
         }
-        ec[e] = ld_i<COH>(label + t);
+        ec[e] = c;
         ew[e] = w;
-        el[e] = (!elig_part || elig_part[t] == mypart) ? 1 : 0;
+        el[e] = ok;
     }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
     const double k_v = kdeg[v];
+    const int4 *ec4 = reinterpret_cast<const int4 *>(ec);
+    const double2 *ew2 = reinterpret_cast<const double2 *>(ew);
+    const uchar4 *el4 = reinterpret_cast<const uchar4 *>(el);
     double k_v_to_old = 0.0; // weight_to_community(v, old), :163 — list order
-    for (int j = 0; j < d; j++)
-        if (ec[j] == old)
-            k_v_to_old += ew[j];
+    for (int q = 0; q < (d4 >> 2); q++) {
+        const int4 cj = ec4[q];
+        const double2 wa = ew2[2 * q], wb = ew2[2 * q + 1];
+        if (cj.x == old) k_v_to_old += wa.x;
+        if (cj.y == old) k_v_to_old += wa.y;
+        if (cj.z == old) k_v_to_old += wb.x;
+        if (cj.w == old) k_v_to_old += wb.y;
+    }
     const double st_old = ld_d<COH>(sum_tot + old);
     double best_gain = 0.0;
     int best = old;
     for (int base = 0; base < d; base += 64) {
         const int e = base + lane;
-        bool cand = e < d && el[e] && ec[e] != old;
-        const int c = e < d ? ec[e] : -1;
-        if (cand)
-            for (int j = 0; j < e; j++)
-                if (el[j] && ec[j] == c) {
-                    cand = false; // seen earlier in the list (:173-199)
-                    break;
-                }
+        const int c = e < d ? ec[e] : -3;
+        bool cand = e < d && el[e] && c != old;
+        // one pass over the list: the in-order weight sum of community c (weight_to_community, :206) and
+        // "an eligible earlier edge already carries c" (the dedup scan of :173-199)
+        double sacc = 0.0;
+        bool dup = false;
+        for (int q = 0; q < (d4 >> 2); q++) {
+            const int4 cj = ec4[q];
+            const double2 wa = ew2[2 * q], wb = ew2[2 * q + 1];
+            const uchar4 ej = el4[q];
+            const int j = q << 2;
+            if (cj.x == c) { sacc += wa.x; dup |= (j < e) && ej.x; }
+            if (cj.y == c) { sacc += wa.y; dup |= (j + 1 < e) && ej.y; }
+            if (cj.z == c) { sacc += wb.x; dup |= (j + 2 < e) && ej.z; }
+            if (cj.w == c) { sacc += wb.y; dup |= (j + 3 < e) && ej.w; }
+        }
+        cand = cand && !dup;
         double gain = -1.0, dk = 0.0;
         if (cand) {
-            double s = 0.0; // weight_to_community(v, c), :206
-            for (int j = 0; j < d; j++)
-                if (ec[j] == c)
-                    s += ew[j];
             const double st_c = ld_d<COH>(sum_tot + c);
-            dk = s - k_v_to_old;
-            gain = (s - k_v_to_old) / m + resolution * k_v * (st_old - k_v - st_c) / (2.0 * m * m); // :209-210
+            dk = sacc - k_v_to_old;
+            gain = (sacc - k_v_to_old) / m + resolution * k_v * (st_old - k_v - st_c) / (2.0 * m * m); // :209-210
             if (!(gain > 0.0))
                 gain = -1.0; // also drops NaN: `gain > best_gain` is false for it
         }
@@ -157,37 +179,28 @@ struct LeiArgs {
 #define LEI_FX 1048576.0
 DEVI unsigned long long fx_up(double k) { return (unsigned long long)ceil(k * LEI_FX); }
 
-DEVI void pick_scratch(const LeiArgs &a, int v, int slot, int *lds_c, double *lds_w, unsigned char *lds_e, int *&ec,
-                       double *&ew, unsigned char *&el) {
-    int d = a.g.off_out[v + 1] - a.g.off_out[v] + (a.use_both ? a.g.off_in[v + 1] - a.g.off_in[v] : 0);
-    if (d <= LEI_CAP) {
-        ec = lds_c;
-        ew = lds_w;
-        el = lds_e;
-    } else {
-        ec = a.scratch_c + (size_t)slot * a.max_deg;
-        ew = a.scratch_w + (size_t)slot * a.max_deg;
-        el = a.scratch_e + (size_t)slot * a.max_deg;
-    }
+DEVI int node_degree(const LeiArgs &a, int v) {
+    return a.g.off_out[v + 1] - a.g.off_out[v] + (a.use_both ? a.g.off_in[v + 1] - a.g.off_in[v] : 0);
 }
 
 __global__ void __launch_bounds__(64) k_leiden_seq(LeiArgs a) {
-    __shared__ double lds_w[LEI_CAP];
-    __shared__ int lds_c[LEI_CAP];
-    __shared__ unsigned char lds_e[LEI_CAP];
+    __shared__ __align__(16) double lds_w[LEI_CAP];
+    __shared__ __align__(16) int lds_c[LEI_CAP];
+    __shared__ __align__(16) unsigned char lds_e[LEI_CAP];
     const int lane = threadIdx.x;
     int total = 0, improved = 1, sweeps = 0;
     while (improved && sweeps < a.max_sweeps) { // :154-229
         improved = 0;
         sweeps++;
         for (int v = 0; v < a.g.n; v++) {
-            int *ec;
-            double *ew;
-            unsigned char *el;
-            pick_scratch(a, v, 0, lds_c, lds_w, lds_e, ec, ew, el);
             const int old = ld_i<true>(a.label + v);
-            const int best = best_move<true>(a.g, v, a.label, a.sum_tot, a.kdeg, a.m, a.resolution, a.use_both, a.elig_part,
-                                             ec, ew, el, lane);
+            int best; // two call sites: LDS staging keeps its address space (a runtime-selected pointer would be FLAT)
+            if (node_degree(a, v) <= LEI_CAP)
+                best = best_move<true>(a.g, v, a.label, a.sum_tot, a.kdeg, a.m, a.resolution, a.use_both, a.elig_part, lds_c,
+                                       lds_w, lds_e, lane);
+            else
+                best = best_move<true>(a.g, v, a.label, a.sum_tot, a.kdeg, a.m, a.resolution, a.use_both, a.elig_part,
+                                       a.scratch_c, a.scratch_w, a.scratch_e, lane);
             if (best != old) { // :220-227
                 if (lane == 0) {
                     const double k_v = a.kdeg[v];
@@ -210,19 +223,22 @@ __global__ void __launch_bounds__(64) k_leiden_seq(LeiArgs a) {
 }
 
 __global__ void __launch_bounds__(64) k_leiden_eval(LeiArgs a) {
-    __shared__ double lds_w[LEI_CAP];
-    __shared__ int lds_c[LEI_CAP];
-    __shared__ unsigned char lds_e[LEI_CAP];
+    __shared__ __align__(16) double lds_w[LEI_CAP];
+    __shared__ __align__(16) int lds_c[LEI_CAP];
+    __shared__ __align__(16) unsigned char lds_e[LEI_CAP];
     const int v = a.b0 + blockIdx.x;
     if (v >= a.b1)
         return;
-    int *ec;
-    double *ew;
-    unsigned char *el;
-    pick_scratch(a, v, blockIdx.x, lds_c, lds_w, lds_e, ec, ew, el);
     double dk = 0.0;
-    const int best = best_move<false>(a.g, v, a.label, a.sum_tot, a.kdeg, a.m, a.resolution, a.use_both, a.elig_part, ec, ew,
-                                      el, threadIdx.x, &dk);
+    int best;
+    if (node_degree(a, v) <= LEI_CAP) {
+        best = best_move<false>(a.g, v, a.label, a.sum_tot, a.kdeg, a.m, a.resolution, a.use_both, a.elig_part, lds_c, lds_w,
+                                lds_e, threadIdx.x, &dk);
+    } else {
+        const size_t o = (size_t)blockIdx.x * a.max_deg;
+        best = best_move<false>(a.g, v, a.label, a.sum_tot, a.kdeg, a.m, a.resolution, a.use_both, a.elig_part, a.scratch_c + o,
+                                a.scratch_w + o, a.scratch_e + o, threadIdx.x, &dk);
+    }
     if (threadIdx.x == 0) {
         a.dec[v - a.b0] = best;
         a.dk[v - a.b0] = dk;
@@ -594,7 +610,7 @@ extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int
     hipStream_t st = g->stream;
     DevGraph dg = {N, g->off_out, g->tgt_out, g->w_out, g->off_in, g->tgt_in, g->w_in};
     LeiDev d;
-    const int max_deg = use_both ? g->max_deg_both : g->max_deg_out;
+    const int max_deg = ((use_both ? g->max_deg_both : g->max_deg_out) + 7) & ~3; // int4-aligned scratch stride
     const int nslots = mode == MN_LEIDEN_SEQUENTIAL ? 1 : batch;
     GCHK(hipMalloc(&d.label, (size_t)N * sizeof(int)));
     GCHK(hipMalloc(&d.refined, (size_t)N * sizeof(int)));

@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(64) k_n2v_seq(N2vArgs a) {
     float *neu = vc + a.dim;                                      // [dim]
     float *sig = neu + a.dim;                                     // [1001]
     int *walk_l = reinterpret_cast<int *>(sig + N2V_SIG_SIZE + 1);
-    int *walk = a.walk_length <= N2V_LDS_WALK ? walk_l : a.walk_scratch;
+    int *walk = walk_l; // LDS (walk_length <= N2V_LDS_WALK is enforced by the host)
     for (int i = lane; i <= N2V_SIG_SIZE; i += 64)
         sig[i] = a.sig_table[i];
     __builtin_amdgcn_s_waitcnt(0);
@@ -512,6 +512,10 @@ extern "C" int mn_node2vec_train(int n, const int *off, const int *adj, const mn
             rc = mn_n2v_finish(S, out, stats);
         mn_n2v_end(S);
         return rc < 0 ? -1 : n;
+    }
+    if (prm->walk_length > N2V_LDS_WALK) {
+        nset_err("mn_node2vec_train: walk_length %d exceeds %d", prm->walk_length, N2V_LDS_WALK);
+        return -1;
     }
     if (mode != MN_N2V_SEQUENTIAL) {
         nset_err("mn_node2vec_train: mode %d not available", mode);

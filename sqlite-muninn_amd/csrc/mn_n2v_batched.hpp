@@ -211,7 +211,9 @@ __global__ void k_n2v_keys(const int *dest, int n_samples, int n_nodes, int *key
     vals[i] = (int)i;
 }
 
-__global__ void k_n2v_segments(const int *keys_sorted, int n_samples, int n_nodes, int *seg_start, int *n_seg) {
+// first sorted position of every destination row that has samples (seg_start preset to -1): no atomics,
+// the row id itself is the segment index
+__global__ void k_n2v_segments(const int *keys_sorted, int n_samples, int n_nodes, int *seg_start) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)n_samples)
         return;
@@ -219,19 +221,19 @@ __global__ void k_n2v_segments(const int *keys_sorted, int n_samples, int n_node
     if (k >= n_nodes)
         return;
     if (i == 0 || keys_sorted[i - 1] != k)
-        seg_start[atomicAdd(n_seg, 1)] = (int)i;
+        seg_start[k] = (int)i;
 }
 
 // dest row += Σ err · src row over the segment, in sorted (= sample) order
 template <int NR>
 __global__ void __launch_bounds__(64)
-    k_n2v_apply(const int *keys_sorted, const int *vals_sorted, const int *seg_start, const int *n_seg, int n_samples,
-                const int *other, const float *s_err, const float *dst_old, const float *src_mat, float *dst_out, int dim) {
-    if ((int)blockIdx.x >= *n_seg)
+    k_n2v_apply(const int *keys_sorted, const int *vals_sorted, const int *seg_start, int n_samples, const int *other,
+                const float *s_err, const float *dst_old, const float *src_mat, float *dst_out, int dim) {
+    const int k = blockIdx.x; // destination row
+    int j = seg_start[k];
+    if (j < 0)
         return;
     const int lane = threadIdx.x;
-    int j = seg_start[blockIdx.x];
-    const int k = keys_sorted[j];
     float acc[NR];
     const float *row = dst_old + (size_t)k * dim;
 #pragma unroll
@@ -260,10 +262,10 @@ __global__ void __launch_bounds__(64)
 }
 
 __global__ void __launch_bounds__(64)
-    k_n2v_commit(const int *keys_sorted, const int *seg_start, const int *n_seg, const float *staged, float *dst, int dim) {
-    if ((int)blockIdx.x >= *n_seg)
+    k_n2v_commit(const int *seg_start, const float *staged, float *dst, int dim) {
+    const int k = blockIdx.x;
+    if (seg_start[k] < 0)
         return;
-    const int k = keys_sorted[seg_start[blockIdx.x]];
     for (int d = threadIdx.x; d < dim; d += 64)
         dst[(size_t)k * dim + d] = staged[(size_t)k * dim + d];
 }
@@ -341,10 +343,10 @@ static int n2v_apply_t(mn_n2v_session *S, const int *d_center, const int *d_targ
         nset_err("rocprim::radix_sort_pairs failed");
         return -1;
     }
-    NCHK(hipMemsetAsync(S->nseg_c, 0, sizeof(int), nullptr));
-    hipLaunchKernelGGL(k_n2v_segments, dim3(g256), dim3(256), 0, nullptr, S->keys_c, ns, N, S->seg_c, S->nseg_c);
-    hipLaunchKernelGGL((k_n2v_apply<NR>), dim3(N), dim3(64), 0, nullptr, S->keys_c, S->vals_s, S->seg_c, S->nseg_c, ns, d_target,
-                       d_err, a.syn0, a.syn1neg, S->staged, dim);
+    NCHK(hipMemsetAsync(S->seg_c, 0xFF, (size_t)N * sizeof(int), nullptr));
+    hipLaunchKernelGGL(k_n2v_segments, dim3(g256), dim3(256), 0, nullptr, S->keys_c, ns, N, S->seg_c);
+    hipLaunchKernelGGL((k_n2v_apply<NR>), dim3(N), dim3(64), 0, nullptr, S->keys_c, S->vals_s, S->seg_c, ns, d_target, d_err,
+                       a.syn0, a.syn1neg, S->staged, dim);
     // targets: syn1neg[t] += Σ err · syn0_old[c]  (syn0 is still the old one) → in place
     hipLaunchKernelGGL(k_n2v_keys, dim3(g256), dim3(256), 0, nullptr, d_target, ns, N, S->keys, S->vals);
     if (rocprim::radix_sort_pairs(S->tmp, S->tmp_bytes, S->keys, S->keys_s, S->vals, S->vals_s, (size_t)ns, 0, S->bits, nullptr) !=
@@ -352,11 +354,11 @@ static int n2v_apply_t(mn_n2v_session *S, const int *d_center, const int *d_targ
         nset_err("rocprim::radix_sort_pairs failed");
         return -1;
     }
-    NCHK(hipMemsetAsync(S->nseg, 0, sizeof(int), nullptr));
-    hipLaunchKernelGGL(k_n2v_segments, dim3(g256), dim3(256), 0, nullptr, S->keys_s, ns, N, S->seg, S->nseg);
-    hipLaunchKernelGGL((k_n2v_apply<NR>), dim3(N), dim3(64), 0, nullptr, S->keys_s, S->vals_s, S->seg, S->nseg, ns, d_center, d_err,
+    NCHK(hipMemsetAsync(S->seg, 0xFF, (size_t)N * sizeof(int), nullptr));
+    hipLaunchKernelGGL(k_n2v_segments, dim3(g256), dim3(256), 0, nullptr, S->keys_s, ns, N, S->seg);
+    hipLaunchKernelGGL((k_n2v_apply<NR>), dim3(N), dim3(64), 0, nullptr, S->keys_s, S->vals_s, S->seg, ns, d_center, d_err,
                        a.syn1neg, a.syn0, a.syn1neg, dim);
-    hipLaunchKernelGGL(k_n2v_commit, dim3(N), dim3(64), 0, nullptr, S->keys_c, S->seg_c, S->nseg_c, S->staged, a.syn0, dim);
+    hipLaunchKernelGGL(k_n2v_commit, dim3(N), dim3(64), 0, nullptr, S->seg_c, S->staged, a.syn0, dim);
     NCHK(hipGetLastError());
     return 0;
 }
