@@ -32,6 +32,28 @@ typedef struct {
     float *vecbuf;
 } CurHnsw;
 
+/* live hnsw_index tables of this process, so that hnsw_search_batch can reach an index by name */
+static VtabHnsw *g_live[256];
+
+static void live_add(VtabHnsw *v) {
+    for (int i = 0; i < 256; i++)
+        if (!g_live[i]) {
+            g_live[i] = v;
+            return;
+        }
+}
+static void live_remove(VtabHnsw *v) {
+    for (int i = 0; i < 256; i++)
+        if (g_live[i] == v)
+            g_live[i] = 0;
+}
+static VtabHnsw *live_find(sqlite3 *db, const char *name) {
+    for (int i = 0; i < 256; i++)
+        if (g_live[i] && g_live[i]->db == db && !strcmp(g_live[i]->name, name))
+            return g_live[i];
+    return 0;
+}
+
 enum { COL_VECTOR = 0, COL_DISTANCE = 1, COL_K = 2, COL_EF = 3 };
 enum { PLAN_SCAN = 0, PLAN_KNN = 1, PLAN_POINT = 2 };
 
@@ -283,6 +305,7 @@ static VtabHnsw *new_vtab(sqlite3 *db, const char *name, const Params *p, mn_ind
     v->metric = p->metric;
     v->m = p->m;
     v->efc = p->efc;
+    live_add(v);
     return v;
 }
 
@@ -345,6 +368,7 @@ static int x_connect(sqlite3 *db, void *aux, int argc, const char *const *argv, 
     }
     rc = load_from_shadow(v);
     if (rc != SQLITE_OK) {
+        live_remove(v);
         mn_hnsw_destroy(ix);
         sqlite3_free(v->name);
         sqlite3_free(v);
@@ -358,6 +382,7 @@ static int x_connect(sqlite3 *db, void *aux, int argc, const char *const *argv, 
 
 static int x_disconnect(sqlite3_vtab *vt) {
     VtabHnsw *v = (VtabHnsw *)vt;
+    live_remove(v);
     mn_hnsw_destroy(v->index);
     sqlite3_free(v->name);
     sqlite3_free(v);
@@ -568,9 +593,182 @@ static sqlite3_module hnsw_module = {
     .xUpdate = x_update,
 };
 
+/* ───────────────────────── hnsw_search_batch: many queries, one launch ─────────────────────────
+ * The reference's SQL surface answers one query per xFilter (src/hnsw_vtab.c:586-606).  This ADDITIVE
+ * eponymous table-valued function exposes the batched device search without touching hnsw_index:
+ *   SELECT query_idx, id, distance FROM hnsw_search_batch
+ *    WHERE tbl = 'vec' AND queries = :blob AND k = 10 [AND ef_search = 128];
+ * `queries` is nq * dimensions little-endian f32; rows come out grouped by query_idx, ascending distance. */
+typedef struct {
+    sqlite3_vtab base;
+    sqlite3 *db;
+} BatchVtab;
+typedef struct {
+    sqlite3_vtab_cursor base;
+    int64_t *ids;
+    float *dists;
+    int *counts;
+    int nq, k, qi, ri;
+} BatchCur;
+enum { BC_QIDX = 0, BC_ID, BC_DIST, BC_TBL, BC_QUERIES, BC_K, BC_EF };
+
+static int b_connect(sqlite3 *db, void *aux, int argc, const char *const *argv, sqlite3_vtab **out, char **err) {
+    (void)aux; (void)argc; (void)argv; (void)err;
+    int rc = sqlite3_declare_vtab(db, "CREATE TABLE x(query_idx INTEGER, id INTEGER, distance REAL, tbl TEXT HIDDEN,"
+                                      " queries BLOB HIDDEN, k INTEGER HIDDEN, ef_search INTEGER HIDDEN)");
+    if (rc != SQLITE_OK)
+        return rc;
+    BatchVtab *v = (BatchVtab *)sqlite3_malloc((int)sizeof(BatchVtab));
+    if (!v)
+        return SQLITE_NOMEM;
+    memset(v, 0, sizeof(*v));
+    v->db = db;
+    *out = &v->base;
+    return SQLITE_OK;
+}
+static int b_disconnect(sqlite3_vtab *v) {
+    sqlite3_free(v);
+    return SQLITE_OK;
+}
+static int b_best_index(sqlite3_vtab *v, sqlite3_index_info *ii) {
+    (void)v;
+    int which[4] = {-1, -1, -1, -1};
+    for (int i = 0; i < ii->nConstraint; i++) {
+        if (!ii->aConstraint[i].usable || ii->aConstraint[i].op != SQLITE_INDEX_CONSTRAINT_EQ)
+            continue;
+        int col = ii->aConstraint[i].iColumn;
+        if (col >= BC_TBL && col <= BC_EF)
+            which[col - BC_TBL] = i;
+    }
+    int arg = 1, mask = 0;
+    for (int j = 0; j < 4; j++)
+        if (which[j] >= 0) {
+            ii->aConstraintUsage[which[j]].argvIndex = arg++;
+            ii->aConstraintUsage[which[j]].omit = 1;
+            mask |= 1 << j;
+        }
+    ii->idxNum = mask;
+    ii->estimatedCost = (mask & 0x7) == 0x7 ? 100.0 : 1e12;
+    return SQLITE_OK;
+}
+static int b_open(sqlite3_vtab *v, sqlite3_vtab_cursor **out) {
+    (void)v;
+    BatchCur *c = (BatchCur *)calloc(1, sizeof(BatchCur));
+    if (!c)
+        return SQLITE_NOMEM;
+    *out = &c->base;
+    return SQLITE_OK;
+}
+static void b_clear(BatchCur *c) {
+    free(c->ids);
+    free(c->dists);
+    free(c->counts);
+    c->ids = 0;
+    c->dists = 0;
+    c->counts = 0;
+    c->nq = 0;
+}
+static int b_close(sqlite3_vtab_cursor *cur) {
+    b_clear((BatchCur *)cur);
+    free(cur);
+    return SQLITE_OK;
+}
+static void b_skip_empty(BatchCur *c) {
+    while (c->qi < c->nq && c->ri >= c->counts[c->qi]) {
+        c->qi++;
+        c->ri = 0;
+    }
+}
+static int b_filter(sqlite3_vtab_cursor *cur, int idxNum, const char *idxStr, int argc, sqlite3_value **argv) {
+    (void)idxStr;
+    BatchCur *c = (BatchCur *)cur;
+    BatchVtab *bv = (BatchVtab *)cur->pVtab;
+    b_clear(c);
+    c->qi = c->ri = 0;
+    if ((idxNum & 0x7) != 0x7 || argc < 3)
+        return SQLITE_OK;
+    const char *tbl = (const char *)sqlite3_value_text(argv[0]);
+    const float *q = (const float *)sqlite3_value_blob(argv[1]);
+    int qbytes = sqlite3_value_bytes(argv[1]);
+    int k = sqlite3_value_int(argv[2]);
+    int ef = (idxNum & 0x8) && argc >= 4 ? sqlite3_value_int(argv[3]) : 2 * k;
+    VtabHnsw *v = tbl ? live_find(bv->db, tbl) : 0;
+    if (!v && tbl) { /* not connected yet on this connection: touching the table connects it */
+        char *sql = sqlite3_mprintf("SELECT rowid FROM \"%w\" WHERE rowid = -1", tbl);
+        sqlite3_exec(bv->db, sql, 0, 0, 0);
+        sqlite3_free(sql);
+        v = live_find(bv->db, tbl);
+    }
+    if (!v) {
+        bv->base.zErrMsg = sqlite3_mprintf("hnsw_search_batch: no hnsw_index table named '%s'", tbl ? tbl : "");
+        return SQLITE_ERROR;
+    }
+    int row = v->dim * (int)sizeof(float);
+    if (k <= 0 || qbytes <= 0 || qbytes % row != 0) {
+        bv->base.zErrMsg = sqlite3_mprintf("hnsw_search_batch: queries must be a multiple of %d bytes (%d-dim f32), got %d", row, v->dim, qbytes);
+        return SQLITE_ERROR;
+    }
+    c->nq = qbytes / row;
+    c->k = k;
+    c->ids = (int64_t *)malloc((size_t)c->nq * k * sizeof(int64_t));
+    c->dists = (float *)malloc((size_t)c->nq * k * sizeof(float));
+    c->counts = (int *)malloc((size_t)c->nq * sizeof(int));
+    if (!c->ids || !c->dists || !c->counts)
+        return SQLITE_NOMEM;
+    if (mn_hnsw_search_batch(v->index, q, c->nq, k, ef, c->ids, c->dists, c->counts) != 0) {
+        bv->base.zErrMsg = sqlite3_mprintf("hnsw_search_batch: %s", mn_last_error());
+        return SQLITE_ERROR;
+    }
+    b_skip_empty(c);
+    return SQLITE_OK;
+}
+static int b_next(sqlite3_vtab_cursor *cur) {
+    BatchCur *c = (BatchCur *)cur;
+    c->ri++;
+    b_skip_empty(c);
+    return SQLITE_OK;
+}
+static int b_eof(sqlite3_vtab_cursor *cur) {
+    BatchCur *c = (BatchCur *)cur;
+    return c->qi >= c->nq;
+}
+static int b_column(sqlite3_vtab_cursor *cur, sqlite3_context *ctx, int col) {
+    BatchCur *c = (BatchCur *)cur;
+    size_t at = (size_t)c->qi * c->k + c->ri;
+    switch (col) {
+    case BC_QIDX: sqlite3_result_int(ctx, c->qi); break;
+    case BC_ID: sqlite3_result_int64(ctx, c->ids[at]); break;
+    case BC_DIST: sqlite3_result_double(ctx, (double)c->dists[at]); break;
+    default: sqlite3_result_null(ctx); break;
+    }
+    return SQLITE_OK;
+}
+static int b_rowid(sqlite3_vtab_cursor *cur, sqlite3_int64 *out) {
+    BatchCur *c = (BatchCur *)cur;
+    *out = (sqlite3_int64)c->qi * c->k + c->ri;
+    return SQLITE_OK;
+}
+static sqlite3_module batch_module = {
+    .iVersion = 0,
+    .xCreate = 0,
+    .xConnect = b_connect,
+    .xBestIndex = b_best_index,
+    .xDisconnect = b_disconnect,
+    .xDestroy = b_disconnect,
+    .xOpen = b_open,
+    .xClose = b_close,
+    .xFilter = b_filter,
+    .xNext = b_next,
+    .xEof = b_eof,
+    .xColumn = b_column,
+    .xRowid = b_rowid,
+};
+
 int mn_register_hnsw_module(sqlite3 *db) {
     int rc = sqlite3_create_module(db, "hnsw_index", &hnsw_module, 0); /* src/hnsw_vtab.c:805-807 */
     if (rc == SQLITE_OK)
         rc = sqlite3_create_module(db, "hnsw0", &hnsw_module, 0); /* alias named by BASELINE.json */
+    if (rc == SQLITE_OK)
+        rc = sqlite3_create_module(db, "hnsw_search_batch", &batch_module, 0); /* additive batch surface */
     return rc;
 }

@@ -294,3 +294,26 @@ def test_graph_leiden_sql_matches_reference(conn, gpu):
         got = np.array([r[1] for r in rows], np.int32)  # rows come out in first-seen node order
         assert np.array_equal(got, z[f"{name}_community"]), name
         assert np.array([rows[0][2]], np.float64).view(np.int64)[0] == z[f"{name}_q"][0]
+
+
+@gpu_mark
+def test_hnsw_search_batch_tvf_equals_per_query_results(conn, gpu):
+    """Additive batch surface: one launch for many queries must return exactly what the per-query MATCH returns."""
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((400, 16), dtype=np.float32)
+    Q = rng.standard_normal((25, 16), dtype=np.float32)
+    conn.execute("CREATE VIRTUAL TABLE bv USING hnsw_index(dimensions=16, metric='l2', m=8, ef_construction=60)")
+    with conn:
+        for i in range(len(X)):
+            conn.execute("INSERT INTO bv (rowid, vector) VALUES (?, ?)", (i + 1, X[i].tobytes()))
+    rows = conn.execute("SELECT query_idx, id, distance FROM hnsw_search_batch WHERE tbl='bv' AND queries=? AND k=5 AND ef_search=40",
+                        (Q.tobytes(),)).fetchall()
+    assert len(rows) == 25 * 5
+    for qi in range(25):
+        one = conn.execute("SELECT rowid, distance FROM bv WHERE vector MATCH ? AND k = 5 AND ef_search = 40", (Q[qi].tobytes(),)).fetchall()
+        got = [(r[1], r[2]) for r in rows if r[0] == qi]
+        assert got == one
+    with pytest.raises(Exception, match="multiple of"):
+        conn.execute("SELECT * FROM hnsw_search_batch WHERE tbl='bv' AND queries=? AND k=5", (b"123",)).fetchall()
+    with pytest.raises(Exception, match="no hnsw_index table"):
+        conn.execute("SELECT * FROM hnsw_search_batch WHERE tbl='nope' AND queries=? AND k=5", (Q.tobytes(),)).fetchall()
