@@ -225,6 +225,18 @@ def main():
         g.dev_download(gd, d_ds)
         parity = {"queries": nc, "ids_identical": bool(np.array_equal(oi, out_ids[:nc])),
                   "dists_bit_identical": bool(np.array_equal(od.view(np.int32), gd[:nc].view(np.int32)))}
+        if args.order == "wave":
+            # the fast order is checked bit-for-bit against its own CPU restatement above; here the same graph is
+            # searched in the REFERENCE's summation order and id-set mismatches are counted (north_star: bit-exact
+            # id sets, distances within 1e-5 relative)
+            nr = min(nc, 500)
+            o2 = orc.Oracle(D, args.metric, M, EFC, order=orc.ORDER_SSE)
+            o2.load_from_device(g, vectors=X)
+            ri, rd, rc = o2.search_many(Q[:nr], K, EF)
+            same = [set(ri[i].tolist()) == set(out_ids[i].tolist()) for i in range(nr)]
+            rel = np.abs(rd - gd[:nr]) / np.maximum(np.abs(rd), 1.0)
+            parity["vs_reference_order"] = {"queries": nr, "id_sets_identical": int(sum(same)),
+                                            "max_rel_distance_diff": float(rel.max())}
         cpu = {"value": nc / cpu_s, "unit": "queries/s", "cores": 1, "kind": "port",
                "sample": f"{nc} of the {NQ} queries (same graph, k={K}, ef={EF}), oracle/mn_oracle.c single thread, "
                          f"bitmap visited set; {cpu_s:.1f}s of CPU work"}

@@ -459,7 +459,7 @@ extern "C" int mn_hnsw_set_order(mn_index *x, int order) {
 
 // ───────────────────────── search ─────────────────────────
 
-static int prepare_search_ws(mn_index *x, int64_t nq, int ef, MnSearchArgs &a) {
+static int prepare_search_ws(mn_index *x, int64_t nq, int ef, MnSearchArgs &a, bool zero_counters = true) {
     hipStream_t st = x->stream;
     a.bm0_words = ((int64_t)x->n_slots + 31) / 32;
     a.cand_gcap = 16 * ef + 1024;
@@ -469,7 +469,8 @@ static int prepare_search_ws(mn_index *x, int64_t nq, int ef, MnSearchArgs &a) {
     if (x->ws_res.reserve((size_t)nq * a.res_gcap, false, st)) return -1;
     if (x->ws_counters.reserve(4, false, st)) return -1;
     HIPCHK(hipMemsetAsync(x->ws_bm0.p, 0, (size_t)nq * a.bm0_words * sizeof(unsigned), st));
-    HIPCHK(hipMemsetAsync(x->ws_counters.p, 0, 4 * sizeof(unsigned long long), st));
+    if (zero_counters)
+        HIPCHK(hipMemsetAsync(x->ws_counters.p, 0, 4 * sizeof(unsigned long long), st));
     a.bitmap0 = x->ws_bm0.p;
     a.cand_ovf = x->ws_cand.p;
     a.res_ovf = x->ws_res.p;
@@ -523,21 +524,30 @@ extern "C" int mn_hnsw_search_batch_dev(mn_index *x, const float *d_queries, int
     }
     if (push_links(x) || sync_meta(x))
         return -1;
-    MnSearchArgs a;
-    memset(&a, 0, sizeof(a));
-    if (prepare_search_ws(x, nq, ef, a))
-        return -1;
-    a.queries = d_queries;
-    a.nq = nq;
-    a.k = k;
-    a.ef = ef;
-    a.entry_slot = ht_find(x, x->entry_id);
-    a.max_level = x->max_level;
-    a.out_ids = (long long *)d_ids;
-    a.out_dists = d_dists;
-    a.out_counts = d_counts;
+    // per-query workspace (visited bitmap + heap spill) is bounded to ~8 GiB: larger batches run as chunks
+    const size_t per_q = (size_t)(((int64_t)x->n_slots + 31) / 32) * 4 + (size_t)(16 * ef + 1024) * 8 +
+                         (size_t)(ef > MN_RES_LDS ? ef : 8) * 8;
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(nq, (int64_t)((8ull << 30) / per_q)));
+    const int entry_slot = ht_find(x, x->entry_id);
+    MnDevIndex v = dev_view(x);
     HIPCHK(hipEventRecord(x->ev0, st));
-    mn_launch_search(dev_view(x), a, false, st);
+    for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
+        const int64_t m = std::min<int64_t>(chunk, nq - q0);
+        MnSearchArgs a;
+        memset(&a, 0, sizeof(a));
+        if (prepare_search_ws(x, m, ef, a, q0 == 0))
+            return -1;
+        a.queries = d_queries + (size_t)q0 * x->dim;
+        a.nq = m;
+        a.k = k;
+        a.ef = ef;
+        a.entry_slot = entry_slot;
+        a.max_level = x->max_level;
+        a.out_ids = (long long *)d_ids + (size_t)q0 * k;
+        a.out_dists = d_dists + (size_t)q0 * k;
+        a.out_counts = d_counts + q0;
+        mn_launch_search(v, a, false, st);
+    }
     HIPCHK(hipEventRecord(x->ev1, st));
     HIPCHK(hipGetLastError());
     return 0;
