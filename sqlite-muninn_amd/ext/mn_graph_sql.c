@@ -14,6 +14,19 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* Which device schedule the SQL functions use.  MUNINN_GRAPH_MODE=exact → the reference's sequential
+ * semantics (results bit-identical to the reference, latency-bound single wavefront); =fast → the
+ * batch-synchronous schedules; unset/auto → exact for small inputs (where the reference's own tests
+ * live), fast beyond.   */
+static int graph_mode_fast(long long work, long long small_limit) {
+    const char *e = getenv("MUNINN_GRAPH_MODE");
+    if (e && !strcmp(e, "exact"))
+        return 0;
+    if (e && !strcmp(e, "fast"))
+        return 1;
+    return work > small_limit;
+}
+
 /* ───────────────────────── shared: identifiers, string→index map ───────────────────────── */
 
 static int ident_ok(const char *s) { /* id_validate, src/id_validate.c:17-28 */
@@ -238,7 +251,10 @@ static void fn_node2vec_train(sqlite3_context *ctx, int argc, sqlite3_value **ar
     double *wdummy;
     lists_to_csr(adj, n, 0, &off, &tgt, &wdummy);
     float *emb = (float *)malloc((size_t)n * (size_t)prm.dim * sizeof(float));
-    int got = emb ? mn_node2vec_train(n, off, tgt, &prm, MN_N2V_SEQUENTIAL, 0, emb, 0) : -1;
+    /* pairs ≈ n · walks · length · 2·window · epochs; the serial stream handles ~0.4 M pairs/s */
+    long long work = (long long)n * prm.num_walks * prm.walk_length * 2 * prm.window * prm.epochs;
+    int mode = graph_mode_fast(work, 4000000LL) && n >= 512 ? MN_N2V_BATCHED : MN_N2V_SEQUENTIAL;
+    int got = emb ? mn_node2vec_train(n, off, tgt, &prm, mode, 0, emb, 0) : -1;
     free(off);
     free(tgt);
     nm_free(&nm);
@@ -483,7 +499,8 @@ static int lei_filter(sqlite3_vtab_cursor *cur, int idxNum, const char *idxStr, 
         return SQLITE_ERROR;
     }
     c->community = (int *)malloc((size_t)n * sizeof(int));
-    rc = mn_graph_leiden(g, resolution, !strcmp(direction, "both"), MN_LEIDEN_SEQUENTIAL, 0, c->community, &c->Q);
+    rc = mn_graph_leiden(g, resolution, !strcmp(direction, "both"),
+                         graph_mode_fast(n, 2000) ? MN_LEIDEN_BATCHED : MN_LEIDEN_SEQUENTIAL, 0, c->community, &c->Q);
     mn_graph_destroy(g);
     if (rc != 0) {
         vt->base.zErrMsg = sqlite3_mprintf("graph_leiden: %s", mn_graph_last_error());

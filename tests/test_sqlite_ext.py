@@ -317,3 +317,26 @@ def test_hnsw_search_batch_tvf_equals_per_query_results(conn, gpu):
         conn.execute("SELECT * FROM hnsw_search_batch WHERE tbl='bv' AND queries=? AND k=5", (b"123",)).fetchall()
     with pytest.raises(Exception, match="no hnsw_index table"):
         conn.execute("SELECT * FROM hnsw_search_batch WHERE tbl='nope' AND queries=? AND k=5", (Q.tobytes(),)).fetchall()
+
+
+@gpu_mark
+def test_graph_leiden_sql_fast_mode_matches_oracle_schedule(conn, gpu, monkeypatch):
+    """MUNINN_GRAPH_MODE=fast → batch-synchronous schedule; must equal the CPU restatement with the same batch."""
+    from oracle import orc_graph as og
+    from oracle.graph_cases import leiden_cases
+
+    s, d, w, res = leiden_cases()["er2000"]
+    conn.execute("CREATE TABLE gf (src TEXT, dst TEXT)")
+    conn.executemany("INSERT INTO gf VALUES (?,?)", [(str(int(a)), str(int(b))) for a, b in zip(s, d)])
+    monkeypatch.setenv("MUNINN_GRAPH_MODE", "fast")
+    rows = conn.execute("SELECT node, community_id, modularity FROM graph_leiden WHERE edge_table='gf' AND src_col='src' AND dst_col='dst'").fetchall()
+    csr = og.Csr(s, d, None, "both")
+    avg = (len(csr.tgt_out) + len(csr.tgt_in)) // csr.n
+    batch = min(65536, max(256, csr.n // max(8, 2 * avg)))
+    oc, oq, _ = og.leiden(csr, res, batch)
+    assert np.array_equal(np.array([r[1] for r in rows], np.int32), oc)
+    assert rows[0][2] == oq
+    monkeypatch.setenv("MUNINN_GRAPH_MODE", "exact")
+    rows2 = conn.execute("SELECT community_id FROM graph_leiden WHERE edge_table='gf' AND src_col='src' AND dst_col='dst'").fetchall()
+    z = np.load(os.path.join(ROOT, "tests", "golden", "leiden.npz"))
+    assert np.array_equal(np.array([r[0] for r in rows2], np.int32), z["er2000_community"])
