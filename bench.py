@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--num-vectors", dest="n", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--nq", type=int, default=10_000)
     ap.add_argument("--k", type=int, default=10)
@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--cpu-queries", type=int, default=4000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ef-sweep", default="", help="comma list of extra ef values to report (q/s, recall)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend (nccl = RCCL over xGMI; gloo only to rehearse the N>1 path on one GPU)")
+    ap.add_argument("--device", type=int, default=-1, help="HIP device ordinal (default: LOCAL_RANK)")
     ap.add_argument("--mode", default="replica", choices=["replica", "sharded"],
                     help="N>1: replica = same index on every GPU, queries sharded (no collective); sharded = config 3: "
                          "rowid mod N shards, same queries everywhere, RCCL all-gather + merge of per-shard top-k")
@@ -95,8 +98,12 @@ def main():
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dev_ord = args.device if args.device >= 0 else local_rank
+        torch.cuda.set_device(dev_ord)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_ord))
+        else:
+            dist.init_process_group("gloo")
 
     import muninn_amd
 
@@ -121,7 +128,8 @@ def main():
         Q = gen_vectors(NQ, D, 43 + rank, args.dataset)
 
     # ---- build on the device (reported, not the timed step) ----
-    g = pkg.HnswIndex(D, args.metric, M, EFC, order=order, device=local_rank)
+    dev_ord = args.device if args.device >= 0 else local_rank
+    g = pkg.HnswIndex(D, args.metric, M, EFC, order=order, device=dev_ord)
     t0 = time.perf_counter()
     if g.build(ids, X, 16, 8192) != 0:
         raise SystemExit("build failed: " + pkg.hnsw._err())
@@ -151,11 +159,11 @@ def main():
             torch.cuda.synchronize()
         g.sync()
 
-    def run_steps(nsteps, ef, collect=False):
+    def run_steps(nsteps, ef, collect=False, merge=True):
         kms, nd, ne = [], 0, 0
         for _ in range(nsteps):
             g.search_batch_dev(dq, NQ, K, ef, d_ids, d_ds, d_cnt)
-            if sharded:  # the one exchange step of the sharded index: per-shard top-k → global top-k
+            if sharded and merge:  # the one exchange step of the sharded index: per-shard top-k → global top-k
                 g.sync()
                 pkg.parallel.allgather_merge_topk(t_ids, t_ds, t_cnt, K)
             if collect:  # per-launch HIP-event time on the kernel's own stream (syncs that launch)
@@ -175,7 +183,7 @@ def main():
     if dist is not None:
         import torch
 
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -209,7 +217,7 @@ def main():
     #      graph and the SAME queries; also a full-size parity check of the returned ids ----
     cpu = None
     parity = None
-    if rank == 0 and not args.no_cpu_baseline and args.cpu_queries > 0:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_queries > 0:  # N=1 only (contract)
         from oracle import orc
 
         o = orc.Oracle(D, args.metric, M, EFC, order=orc.ORDER_SSE if args.order == "sse" else orc.ORDER_WAVE)
@@ -218,7 +226,7 @@ def main():
         tc = time.perf_counter()
         oi, od, oc = o.search_many(Q[:nc], K, EF)
         cpu_s = time.perf_counter() - tc
-        run_steps(1, EF)
+        run_steps(1, EF, merge=False)  # rank 0 only: no collective here
         g.sync()
         g.dev_download(out_ids, d_ids)
         gd = np.empty((NQ, K), np.float32)

@@ -22,12 +22,17 @@ def allgather_merge_topk(ids: torch.Tensor, dists: torch.Tensor, counts: torch.T
     (ascending by distance).  Returns the merged global top-k (ids, dists, counts) on every rank."""
     world = dist.get_world_size(group)
     nq = ids.shape[0]
-    gi = [torch.empty_like(ids) for _ in range(world)]
-    gd = [torch.empty_like(dists) for _ in range(world)]
-    gc = [torch.empty_like(counts) for _ in range(world)]
-    dist.all_gather(gi, ids.contiguous(), group=group)
-    dist.all_gather(gd, dists.contiguous(), group=group)
-    dist.all_gather(gc, counts.contiguous(), group=group)
+    dev = ids.device
+    staged = dist.get_backend(group) == "gloo" and dev.type != "cpu"  # gloo rehearsal on a GPU box: stage via host
+    src = [t.cpu().contiguous() if staged else t.contiguous() for t in (ids, dists, counts)]
+    gi = [torch.empty_like(src[0]) for _ in range(world)]
+    gd = [torch.empty_like(src[1]) for _ in range(world)]
+    gc = [torch.empty_like(src[2]) for _ in range(world)]
+    dist.all_gather(gi, src[0], group=group)
+    dist.all_gather(gd, src[1], group=group)
+    dist.all_gather(gc, src[2], group=group)
+    if staged:
+        gi, gd, gc = [t.to(dev) for t in gi], [t.to(dev) for t in gd], [t.to(dev) for t in gc]
     ai = torch.stack(gi, 1).reshape(nq, world * k)            # [nq, world*k], shard-major
     ad = torch.stack(gd, 1).reshape(nq, world * k)
     ac = torch.stack(gc, 1)                                    # [nq, world]
