@@ -26,7 +26,9 @@ def mn():
     """The product package (sqlite-muninn_amd) over libmuninn_hip.so."""
     import muninn_amd
 
-    return muninn_amd.pkg
+    pkg = muninn_amd.pkg
+    pkg.build()  # no-op unless libmuninn_hip.so is missing or older than its sources (hipcc cross-compiles gfx950)
+    return pkg
 
 
 @pytest.fixture(scope="session")
