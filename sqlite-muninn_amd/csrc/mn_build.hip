@@ -15,6 +15,7 @@
 // No float atomics, no order-dependent results: every target is owned by one wavefront and its
 // sources are sorted by batch index.
 #include "mn_dist.hpp"
+#include "mn_prune.hpp"
 
 DEVI int *row_ptr(const MnDevIndex &ix, int node, int level) {
     if (level == 0)
@@ -71,22 +72,6 @@ __global__ void k_link_scatter(MnLinkArgs a, int max_tuples) {
     a.bins[a.binoff[t] + p] = a.t_src[i];
 }
 
-// MN(t, nn) = |list ∩ N(nn)| (src/hnsw_algo.c:460-475); list in LDS, nn's row read from HBM
-DEVI int mutual_count(const MnDevIndex &ix, const int *list, int nc, int nn, int level, int lane) {
-    if (ix.levels[nn] < level)
-        return 0;
-    const int W = level == 0 ? ix.W0 : ix.WU;
-    const int *row = row_ptr(ix, nn, level);
-    int mine = lane < W ? row[lane] : -1;
-    int c = 0;
-    for (int i = 0; i < nc; i++) {
-        int a = list[i];
-        if (__ballot(mine >= 0 && mine == a))
-            c++;
-    }
-    return c;
-}
-
 template <int ORDER, int NCH>
 __global__ void __launch_bounds__(64) k_link_reverse(MnDevIndex ix, MnLinkArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -96,10 +81,10 @@ __global__ void __launch_bounds__(64) k_link_reverse(MnDevIndex ix, MnLinkArgs a
     const int t = a.touched[blockIdx.x];
     const int W = a.level == 0 ? ix.W0 : ix.WU;
     const int M_max = a.M_max;
-    int *list = reinterpret_cast<int *>(smem); // [64]
-    float *nd = reinterpret_cast<float *>(list + 64); // [64]
-    int *mn = reinterpret_cast<int *>(nd + 64);       // [64]
-    float *q = reinterpret_cast<float *>(mn + 64);    // [ld]
+    int *list = reinterpret_cast<int *>(smem);         // [128]
+    float *nd = reinterpret_cast<float *>(list + 128); // [128]
+    int *mn = reinterpret_cast<int *>(nd + 128);       // [128]
+    float *q = reinterpret_cast<float *>(mn + 128);    // [ld]
 
     const float *tv = ix.vectors + (size_t)t * ix.ld;
     for (int i = lane; i < ix.ld; i += 64)
@@ -141,62 +126,7 @@ __global__ void __launch_bounds__(64) k_link_reverse(MnDevIndex ix, MnLinkArgs a
         if (nc <= M_max)
             continue;
         // ── prune to M_max (:601-646) ──
-        int myslot = lane < nc ? list[lane] : 0;
-        bool dead = lane < nc && ix.deleted[myslot];
-        float d = rows_distance<ORDER, NCH>(ix, q, tnorm, myslot, nc, lane);
-        if (dead)
-            d = 1e30f; // :610-612
-        // distinct & ordered? then selection sort == ascending sort; else emulate serially
-        bool clash = false;
-        for (int i = 0; i < nc; i++) {
-            float o = __shfl(d, i);
-            if (lane < nc && i != lane && !(o < d) && !(d < o))
-                clash = true; // equal or unordered (NaN)
-        }
-        if (!__ballot(clash)) {
-            int rank = 0;
-            for (int i = 0; i < nc; i++) {
-                float o = __shfl(d, i);
-                if (o < d)
-                    rank++;
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (lane < nc && rank < M_max)
-                list[rank] = myslot;
-            __builtin_amdgcn_wave_barrier();
-        } else {
-            // tie path: mutual-neighbour counts, then the reference's selection sort verbatim
-            nd[lane] = d;
-            int cnt_mn = 0;
-            for (int j = 0; j < nc; j++) {
-                int nn = list[j];
-                int c = (ix.deleted[nn]) ? -1 : mutual_count(ix, list, nc, nn, a.level, lane);
-                if (lane == j)
-                    cnt_mn = c;
-            }
-            mn[lane] = cnt_mn;
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0) {
-                for (int x = 0; x < M_max && x < nc; x++) { // :620-639
-                    int bi = x;
-                    for (int y = x + 1; y < nc; y++)
-                        if (nd[y] < nd[bi] || (nd[y] == nd[bi] && mn[y] > mn[bi]))
-                            bi = y;
-                    if (bi != x) {
-                        float td = nd[x];
-                        nd[x] = nd[bi];
-                        nd[bi] = td;
-                        int tm = mn[x];
-                        mn[x] = mn[bi];
-                        mn[bi] = tm;
-                        int ti = list[x];
-                        list[x] = list[bi];
-                        list[bi] = ti;
-                    }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
+        prune_row<ORDER, NCH, false>(ix, q, tnorm, list, nd, mn, nc, M_max, a.level, lane);
         nc = M_max;
     }
     // stage the finished row
@@ -232,7 +162,7 @@ static int pick_nch_b(int ld) {
 
 template <int ORDER, int NCH>
 static void launch_reverse(const MnDevIndex &ix, const MnLinkArgs &a, int max_tuples, hipStream_t st) {
-    size_t lds = 64 * 3 * sizeof(int) + (size_t)ix.ld * sizeof(float);
+    size_t lds = 128 * 3 * sizeof(int) + (size_t)ix.ld * sizeof(float);
     hipLaunchKernelGGL((k_link_reverse<ORDER, NCH>), dim3(max_tuples), dim3(64), lds, st, ix, a);
 }
 

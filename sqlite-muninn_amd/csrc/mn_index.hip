@@ -392,8 +392,8 @@ extern "C" mn_index *mn_hnsw_create_on(int dim, int metric, int M, int ef_constr
         set_err("mn_hnsw_create: bad parameters");
         return nullptr;
     }
-    if (2 * M + 1 > 64) {
-        set_err("mn_hnsw_create: M=%d not supported on device (2M+1 must fit one 64-lane wavefront)", M);
+    if (2 * M > 64) {
+        set_err("mn_hnsw_create: M=%d not supported on device (a level-0 row of 2M links must fit one 64-lane wavefront)", M);
         return nullptr;
     }
     int ndev = 0;

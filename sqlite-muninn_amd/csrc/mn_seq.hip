@@ -8,6 +8,7 @@
 // neighbour distances per expansion / prune, heap sifts, the row scans.  Latency-bound by design
 // (≈1 ms per insert); the batch-synchronous schedule (mn_build.hip) is the throughput path.
 #include "mn_beam.hpp"
+#include "mn_prune.hpp"
 
 struct MnSeqArgs {
     const int *slots; // nodes to insert, in order
@@ -31,22 +32,6 @@ DEVI int *seq_row(const MnDevIndex &ix, int node, int level) {
     return ix.links_up + ((size_t)ix.up_off[node] + (level - 1)) * ix.WU;
 }
 
-// |list ∩ N(nn)| against nn's live row (src/hnsw_algo.c:460-475)
-DEVI int seq_mutual(const MnDevIndex &ix, const int *list, int nc, int nn, int level, int lane) {
-    if (ix.levels[nn] < level)
-        return 0;
-    const int W = level == 0 ? ix.W0 : ix.WU;
-    const int *row = seq_row(ix, nn, level);
-    int mine = lane < W ? ld_link<true>(row + lane) : -1;
-    int c = 0;
-    for (int i = 0; i < nc; i++) {
-        int a = list[i];
-        if (__ballot(mine >= 0 && mine == a))
-            c++;
-    }
-    return c;
-}
-
 template <int ORDER, int NCH>
 __global__ void __launch_bounds__(64) k_insert_seq(MnDevIndex ix, MnSeqArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -55,10 +40,10 @@ __global__ void __launch_bounds__(64) k_insert_seq(MnDevIndex ix, MnSeqArgs a) {
     uint2 *res_l = cand_l + MN_CAND_LDS;
     int *scratch = reinterpret_cast<int *>(res_l + MN_RES_LDS); // [64]
     int *selbuf = scratch + 64;                                 // [64]
-    int *list = selbuf + 64;                                    // [64]
-    float *nd = reinterpret_cast<float *>(list + 64);           // [64]
-    int *mn = reinterpret_cast<int *>(nd + 64);                 // [64]
-    float *q = reinterpret_cast<float *>(mn + 64);              // [ld]
+    int *list = selbuf + 64;                                    // [128]
+    float *nd = reinterpret_cast<float *>(list + 128);          // [128]
+    int *mn = reinterpret_cast<int *>(nd + 128);                // [128]
+    float *q = reinterpret_cast<float *>(mn + 128);             // [ld]
     float *tv = q + ix.ld;                                      // [ld]
 
     WaveCtx w;
@@ -150,61 +135,10 @@ __global__ void __launch_bounds__(64) k_insert_seq(MnDevIndex ix, MnSeqArgs a) {
                 __builtin_amdgcn_s_waitcnt(0);
                 __builtin_amdgcn_wave_barrier();
                 const float tnorm = ix.metric == 1 ? ix.norms[t] : 0.0f;
-                int myslot = lane < nc ? list[lane] : 0;
-                const bool dead = lane < nc && ix.deleted[myslot];
-                float d = rows_distance<ORDER, NCH>(ix, tv, tnorm, myslot, nc, lane);
+                prune_row<ORDER, NCH, true>(ix, tv, tnorm, list, nd, mn, nc, W, l, lane);
                 w.n_dist += nc;
-                if (dead)
-                    d = 1e30f;
-                bool clash = false;
-                for (int x = 0; x < nc; x++) {
-                    float o = __shfl(d, x);
-                    if (lane < nc && x != lane && !(o < d) && !(d < o))
-                        clash = true;
-                }
-                if (!__ballot(clash)) {
-                    int rank = 0;
-                    for (int x = 0; x < nc; x++) {
-                        float o = __shfl(d, x);
-                        if (o < d)
-                            rank++;
-                    }
-                    if (lane < nc && rank < W)
-                        st_link(trow + rank, myslot);
-                } else {
-                    nd[lane] = d;
-                    int cm = 0;
-                    for (int j = 0; j < nc; j++) {
-                        int nn = list[j];
-                        int c = ix.deleted[nn] ? -1 : seq_mutual(ix, list, nc, nn, l, lane);
-                        if (lane == j)
-                            cm = c;
-                    }
-                    mn[lane] = cm;
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane == 0) {
-                        for (int x = 0; x < W && x < nc; x++) { // :620-639
-                            int bi = x;
-                            for (int y = x + 1; y < nc; y++)
-                                if (nd[y] < nd[bi] || (nd[y] == nd[bi] && mn[y] > mn[bi]))
-                                    bi = y;
-                            if (bi != x) {
-                                float td = nd[x];
-                                nd[x] = nd[bi];
-                                nd[bi] = td;
-                                int tm = mn[x];
-                                mn[x] = mn[bi];
-                                mn[bi] = tm;
-                                int ti = list[x];
-                                list[x] = list[bi];
-                                list[bi] = ti;
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane < W)
-                        st_link(trow + lane, list[lane]);
-                }
+                if (lane < W)
+                    st_link(trow + lane, list[lane]);
                 __builtin_amdgcn_wave_barrier();
             }
             if (count > 0) // :651-652
@@ -253,7 +187,7 @@ void mn_launch_insert_seq(const MnDevIndex &ix, const int *d_slots, int n, int e
     a.res_ovf = res_ovf;
     a.res_gcap = res_gcap;
     a.counters = counters;
-    size_t lds = (size_t)(MN_CAND_LDS + MN_RES_LDS) * sizeof(uint2) + 5 * 64 * sizeof(int) + 2 * (size_t)ix.ld * sizeof(float);
+    size_t lds = (size_t)(MN_CAND_LDS + MN_RES_LDS) * sizeof(uint2) + (2 * 64 + 3 * 128) * sizeof(int) + 2 * (size_t)ix.ld * sizeof(float);
 #define MN_SQ(O, N) hipLaunchKernelGGL((k_insert_seq<O, N>), dim3(1), dim3(64), lds, st, ix, a)
     if (ix.order == MN_ORDER_SSE_V) {
         MN_SQ(MN_ORDER_SSE_V, 0);

@@ -278,6 +278,46 @@ def test_sequential_insert_with_ties_matches_oracle(gpu, orc):
         g.close()
 
 
+@pytest.mark.parametrize("dups", [False, True])
+def test_m32_level0_rows_fill_the_wavefront(gpu, orc, dups):
+    """M=32: a level-0 row is 64 links = one wavefront, and the MN-RU prune sees 65 entries (two per lane)."""
+    dim, n, M, efc = 12, 1800, 32, 100
+    X = gauss(n, dim, 51)
+    if dups:
+        X = X[np.random.default_rng(52).integers(0, 90, n)]
+    ids = np.arange(1, n + 1, dtype=np.int64)
+    Q = gauss(40, dim, 53)
+    for metric in ("l2", "cosine"):
+        o = orc.Oracle(dim, metric, M, efc)
+        o.insert_many(ids, X)
+        g = gpu.HnswIndex(dim, metric, M, efc)
+        assert g.insert_batch(ids, X, gpu.BUILD_SEQUENTIAL) == 0
+        assert g.graph(ids) == o.graph(ids), metric
+        assert max(len(v) for (_, l), v in o.graph(ids)["nbrs"].items() if l == 0) == 2 * M  # rows did fill
+        wi, wd, wc = o.search_many(Q, 10, 80)
+        gi, gd, gc = g.search_batch(Q, 10, 80)
+        assert np.array_equal(gi, wi) and same_bits(gd, wd)
+        g.close()
+        ob = orc.Oracle(dim, metric, M, efc)
+        gb = gpu.HnswIndex(dim, metric, M, efc)
+        pos = 0
+        for b in (1, 2, 7, 90, 400, 1300):
+            assert ob.insert_batch(ids[pos:pos + b], X[pos:pos + b]) == 0
+            assert gb.insert_batch(ids[pos:pos + b], X[pos:pos + b], gpu.BUILD_BATCHED) == 0
+            pos += b
+        assert pos == n
+        assert gb.graph(ids) == ob.graph(ids), metric
+        for d in [int(x) for x in ids[::37]]:
+            assert gb.delete(d) == ob.delete(d)
+        assert gb.graph(ids) == ob.graph(ids), metric
+        gb.close()
+
+
+def test_m33_is_refused(gpu):
+    with pytest.raises(Exception):
+        gpu.HnswIndex(8, "l2", 33, 50)
+
+
 def test_baseline_full_size_1Mx768(gpu, orc):
     """BASELINE.json configs[1] at full size: 1M x 768 f32 cosine, M=16, efC=200, 10k queries, k=10, ef=128.
     Size-independent properties (ascending, valid, distinct, idempotent, counters consistent) plus a direct
