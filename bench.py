@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--dataset", default="gaussian", choices=["gaussian", "clustered", "lowrank"])
     ap.add_argument("--recall-queries", type=int, default=500)
     ap.add_argument("--cpu-queries", type=int, default=4000)
+    ap.add_argument("--ref-queries", type=int, default=1500,
+                    help="queries timed through the compiled reference (oracle/_ref) when it is present")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ef-sweep", default="", help="comma list of extra ef values to report (q/s, recall)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -248,6 +250,28 @@ def main():
         cpu = {"value": nc / cpu_s, "unit": "queries/s", "cores": 1, "kind": "port",
                "sample": f"{nc} of the {NQ} queries (same graph, k={K}, ef={EF}), oracle/mn_oracle.c single thread, "
                          f"bitmap visited set; {cpu_s:.1f}s of CPU work"}
+        if orc.have_ref() and args.ref_queries > 0:
+            # the reference's own compiled hnsw_search (oracle/_ref, built from /root/reference/src in the build
+            # container) on the same graph, loaded through the reference's own shadow-table load API
+            r = orc.Ref(D, args.metric, M, EFC)
+            r.load_from_device(g, vectors=X)
+            nr = min(args.ref_queries, nc)
+            tr = time.perf_counter()
+            ri, rd, rc = r.search_many(Q[:nr], K, EF)
+            ref_s = time.perf_counter() - tr
+            parity["vs_reference_binary"] = {
+                "queries": nr,
+                "id_sets_identical": int(sum(set(ri[i].tolist()) == set(out_ids[i].tolist()) for i in range(nr))),
+                "ids_identical": bool(np.array_equal(ri, out_ids[:nr])),
+                "dists_bit_identical": bool(np.array_equal(rd.view(np.int32), gd[:nr].view(np.int32))),
+                "max_rel_distance_diff": float((np.abs(rd - gd[:nr]) / np.maximum(np.abs(rd), 1.0)).max())}
+            cpu = {"value": nr / ref_s, "unit": "queries/s", "cores": 1, "kind": "reference",
+                   "sample": f"{nr} of the {NQ} queries (same graph, k={K}, ef={EF}) through the reference's own "
+                             f"hnsw_search (src/hnsw_algo.c, gcc -O2, linear visited set), single thread; "
+                             f"{ref_s:.1f}s of CPU work",
+                   "port": {"value": nc / cpu_s, "unit": "queries/s", "cores": 1,
+                            "sample": f"{nc} queries, oracle/mn_oracle.c (bitmap visited set), {cpu_s:.1f}s"}}
+            del r
 
     # HBM traffic per launch from the committed PMC passes (profiles/traffic.json), when this exact workload was profiled
     traffic = None

@@ -24,6 +24,7 @@ VISITED_BITMAP, VISITED_LINEAR = 0, 1
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 _i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
 
 
 def build(target: str = "oracle") -> None:
@@ -264,6 +265,8 @@ def ref_lib():
         R.ref_dist_batch.argtypes = [C.c_int, _f32p, _f32p, C.c_int64, C.c_int, _f32p]
         R.ref_insert_many.argtypes = [C.c_void_p, _i64p, _f32p, C.c_int]
         R.ref_search_many.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _i64p, _f32p, _i32p]
+        R.ref_load_nodes.argtypes = [C.c_void_p, C.c_int64, _i64p, _f32p, _i32p, _u8p, C.c_int64, C.c_int]
+        R.ref_load_edges.argtypes = [C.c_void_p, C.c_int64, _i64p, _i64p, _i32p]
         R.vec_parse_metric.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
         R.pq_init.argtypes = [C.c_void_p, C.c_int]
         R.pq_push.argtypes = [C.c_void_p, C.c_int64, C.c_float]
@@ -291,6 +294,24 @@ class Ref(_IndexBase):
 
     def insert(self, id, vec):
         return self.R.hnsw_insert(self.h, int(id), np.ascontiguousarray(vec, np.float32))
+
+    def load_from_device(self, g, vectors=None):
+        """Load a device-built graph into the reference's own structures through the reference's own load
+        API (ref_access.c: ref_load_nodes/ref_load_edges), so its hnsw_search can be timed on that graph."""
+        ids, lv, dl = g.export_nodes()
+        if vectors is None:
+            vectors = g.export_vectors()
+        vectors = np.ascontiguousarray(vectors, np.float32)
+        lv = np.ascontiguousarray(lv, np.int32)
+        dl = np.ascontiguousarray(dl, np.uint8)
+        assert self.R.ref_load_nodes(self.h, len(ids), ids, vectors, lv, dl, int(g.entry_point), int(g.max_level)) == 0
+        for l in range(int(lv.max()) + 1 if len(lv) else 0):
+            rows = g.export_links(l)
+            r, c = np.nonzero(rows >= 0)  # row-major: keeps each list's order
+            src = np.ascontiguousarray(ids[r])
+            dst = np.ascontiguousarray(ids[rows[r, c]])
+            lev = np.full(len(src), l, np.int32)
+            self.R.ref_load_edges(self.h, len(src), src, dst, lev)
 
     def insert_many(self, ids, vecs):
         ids = np.ascontiguousarray(ids, np.int64)

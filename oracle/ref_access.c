@@ -69,3 +69,33 @@ int ref_search_many(HnswIndex *idx, const float *queries, int nq, int k, int ef,
     }
     return 0;
 }
+
+/* Bulk load of an existing graph into a reference index, through the reference's own load API
+ * (the functions src/hnsw_algo.h:98-104 exports for its shadow-table loader; call sequence as in
+ * src/hnsw_vtab.c:297-338).  Lets bench.py time the reference's hnsw_search on the very graph the
+ * GPU built, without paying the reference's multi-hour 1M-vector build. */
+int ref_load_nodes(HnswIndex *idx, int64_t n, const int64_t *ids, const float *vecs, const int *levels,
+                   const unsigned char *deleted, int64_t entry_point, int max_level) {
+    for (int64_t i = 0; i < n; i++) {
+        if ((int64_t)idx->node_count * 10 > (int64_t)idx->node_capacity * 7)
+            ht_resize(idx);
+        HnswNode *nd = node_create(ids[i], vecs + (size_t)i * idx->dim, idx->dim, levels[i]);
+        if (!nd)
+            return -1;
+        nd->deleted = deleted ? deleted[i] : 0;
+        ht_insert(idx->nodes, idx->node_capacity, nd);
+        if (!nd->deleted)
+            idx->node_count++;
+    }
+    idx->entry_point = entry_point;
+    idx->max_level = max_level;
+    return 0;
+}
+int ref_load_edges(HnswIndex *idx, int64_t n_edges, const int64_t *src, const int64_t *dst, const int *level) {
+    for (int64_t e = 0; e < n_edges; e++) {
+        HnswNode *nd = ht_find(idx->nodes, idx->node_capacity, src[e]);
+        if (nd && level[e] <= nd->level)
+            node_add_neighbor(nd, level[e], dst[e]);
+    }
+    return 0;
+}

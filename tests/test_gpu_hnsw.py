@@ -313,6 +313,28 @@ def test_m32_level0_rows_fill_the_wavefront(gpu, orc, dups):
         gb.close()
 
 
+def test_reference_binary_searches_device_built_graph(gpu, orc):
+    """bench.py's cpu_baseline kind "reference": a GPU-built graph loaded into the compiled reference through the
+    reference's own load API gives the same graph and bit-identical search results (SSE order)."""
+    if not orc.have_ref():
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    n, dim, M, efc = 3000, 24, 8, 60
+    X = gauss(n, dim, 61)
+    ids = np.arange(10, 10 + n, dtype=np.int64)
+    g = gpu.HnswIndex(dim, "cosine", M, efc)
+    assert g.insert_batch(ids, X, gpu.BUILD_BATCHED) == 0
+    for d in (17, 300, 2999):
+        assert g.delete(d) == 0
+    r = orc.Ref(dim, "cosine", M, efc)
+    r.load_from_device(g, vectors=X)
+    assert r.graph(ids)["nbrs"] == g.graph(ids)["nbrs"]
+    Q = gauss(64, dim, 62)
+    ri, rd, rc = r.search_many(Q, 10, 64)
+    gi, gd, gc = g.search_batch(Q, 10, 64)
+    assert np.array_equal(gi, ri) and same_bits(gd, rd)
+    g.close()
+
+
 def test_m33_is_refused(gpu):
     with pytest.raises(Exception):
         gpu.HnswIndex(8, "l2", 33, 50)
