@@ -124,6 +124,13 @@ int mn_hnsw_export_vectors(mn_index *idx, float *out);                          
  * rows of nodes whose level < `level` are all -1.  *width = 2M at level 0, M above. */
 int mn_hnsw_export_links(mn_index *idx, int level, int *out, int *width);
 
+/* The set of nodes the reference's xUpdate would have re-persisted (src/hnsw_vtab.c:755-768: the new
+ * node and every neighbour it linked to), accumulated on the device over all inserts since the last
+ * call, so the SQL layer can write shadow tables once per transaction instead of once per row.
+ * Fills ids[0..count) in slot order and clears the set; if count > cap nothing is cleared and the
+ * count is returned so the caller can retry with room.  -1 on error. */
+int64_t mn_hnsw_take_dirty(mn_index *idx, int64_t *ids, int64_t cap);
+
 /* All edges of the given nodes with the distance persist_node stores next to each one
  * (src/hnsw_vtab.c:268-279: dist_func(node, neighbour), 0.0 when the neighbour is soft-deleted).
  * Fills parallel arrays (source id, target id, level, distance) up to `cap`; returns the number of

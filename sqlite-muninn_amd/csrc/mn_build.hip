@@ -36,6 +36,8 @@ __global__ void k_link_forward(MnDevIndex ix, MnLinkArgs a, int max_tuples) {
     int *row = row_ptr(ix, s, a.level);
     for (int i = 0; i < W; i++)
         row[i] = i < n ? sel[i] : -1;
+    for (int i = 0; i < n; i++)
+        ix.dirty[sel[i]] = 1; // every neighbour of a new node is re-persisted (src/hnsw_vtab.c:761-768)
     for (int i = 0; i < n; i++) {
         int t = sel[i];
         if (ix.levels[t] < a.level) // src/hnsw_algo.c:590

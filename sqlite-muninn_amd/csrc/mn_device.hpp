@@ -7,7 +7,7 @@
 //   links0   [cap][W0]   int32 neighbour slots at layer 0, list order preserved, -1 padded; W0 = 2M
 //   links_up [rows][WU]  int32, layers ≥ 1; node's layer l lives in row up_off[slot] + (l-1); WU = M
 //   up_off   [cap]       int32 first pool row of the node, -1 when level == 0
-//   levels   [cap] int8, deleted [cap] u8, ids [cap] int64
+//   levels   [cap] int8, deleted [cap] u8, ids [cap] int64, dirty [cap] u8 (nodes to re-persist)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -24,6 +24,7 @@ struct MnDevIndex {
     const int *up_off;
     const signed char *levels;
     const unsigned char *deleted;
+    unsigned char *dirty; // [cap] set by the insert kernels on every node whose rows they (re)wrote: the persist set
     const long long *ids;
     int dim, ld, metric, order;
     int W0, WU;

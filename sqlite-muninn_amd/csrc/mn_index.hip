@@ -89,7 +89,7 @@ struct mn_index {
     DevBuf<float> d_vectors, d_norms;
     DevBuf<int> d_links0, d_links_up, d_up_off;
     DevBuf<signed char> d_levels;
-    DevBuf<unsigned char> d_deleted;
+    DevBuf<unsigned char> d_deleted, d_dirty;
     DevBuf<long long> d_ids;
     // host mirror of the link rows (pulled on demand for delete / inspection / load)
     std::vector<int> h_links0, h_links_up;
@@ -190,6 +190,7 @@ static MnDevIndex dev_view(mn_index *x) {
     v.up_off = x->d_up_off.p;
     v.levels = x->d_levels.p;
     v.deleted = x->d_deleted.p;
+    v.dirty = x->d_dirty.p;
     v.ids = x->d_ids.p;
     v.dim = x->dim;
     v.ld = x->ld;
@@ -243,6 +244,7 @@ static int sync_meta(mn_index *x) {
     if (x->d_up_off.reserve(ns, true, st)) return -1;
     if (x->d_levels.reserve(ns, true, st)) return -1;
     if (x->d_deleted.reserve(ns, true, st)) return -1;
+    if (x->d_dirty.reserve(ns, true, st, 0)) return -1;
     if (x->d_ids.reserve(ns, true, st)) return -1;
     int a = x->meta_uploaded, n = x->n_slots - a;
     if (n > 0) {
@@ -431,7 +433,7 @@ extern "C" void mn_hnsw_destroy(mn_index *x) {
     if (x->stream)
         (void)hipStreamSynchronize(x->stream);
     x->d_vectors.release(); x->d_norms.release(); x->d_links0.release(); x->d_links_up.release();
-    x->d_up_off.release(); x->d_levels.release(); x->d_deleted.release(); x->d_ids.release();
+    x->d_up_off.release(); x->d_levels.release(); x->d_deleted.release(); x->d_dirty.release(); x->d_ids.release();
     x->ws_bm0.release(); x->ws_bmu.release(); x->ws_cand.release(); x->ws_res.release(); x->ws_q.release();
     x->ws_outd.release(); x->ws_outi.release(); x->ws_outc.release(); x->ws_qslots.release(); x->ws_sel.release();
     x->ws_nsel.release(); x->ws_upidx.release(); x->lk_target.release(); x->lk_src.release(); x->lk_counters.release();
@@ -778,6 +780,7 @@ static int insert_impl(mn_index *x, const int64_t *ids, const float *vectors, in
         return -1;
     if (upload_vectors(x, first, vectors, (int)n))
         return -1;
+    HIPCHK(hipMemsetAsync(x->d_dirty.p + first, 1, (size_t)n, x->stream)); // new nodes are always persisted
     size_t pos = 0;
     if (x->entry_id == -1) { // :544-548 first node just becomes the entry point
         x->entry_id = ids[0];
@@ -788,6 +791,30 @@ static int insert_impl(mn_index *x, const int64_t *ids, const float *vectors, in
     if (mode == MN_BUILD_SEQUENTIAL)
         return run_sequential(x, rest);
     return run_batch(x, rest);
+}
+
+// The persist set of src/hnsw_vtab.c:755-768, accumulated over any number of inserts: every new node and
+// every node that was a neighbour of a new node when it was linked.  Reading it clears it.
+extern "C" int64_t mn_hnsw_take_dirty(mn_index *x, int64_t *ids, int64_t cap) {
+    if (use_device(x))
+        return -1;
+    if (x->n_slots == 0 || !x->d_dirty.p)
+        return 0;
+    const size_t n = std::min((size_t)x->n_slots, x->d_dirty.cap);
+    std::vector<unsigned char> h(n);
+    HIPCHK(hipStreamSynchronize(x->stream));
+    HIPCHK(hipMemcpy(h.data(), x->d_dirty.p, n, hipMemcpyDeviceToHost));
+    int64_t cnt = 0;
+    for (size_t s = 0; s < n; s++)
+        cnt += h[s] != 0;
+    if (cnt > cap)
+        return cnt; // nothing cleared: call again with room for cnt ids
+    int64_t o = 0;
+    for (size_t s = 0; s < n; s++)
+        if (h[s])
+            ids[o++] = x->ids[s];
+    HIPCHK(hipMemset(x->d_dirty.p, 0, n));
+    return cnt;
 }
 
 extern "C" int mn_hnsw_insert(mn_index *x, int64_t id, const float *vector) {

@@ -108,8 +108,10 @@ __global__ void __launch_bounds__(64) k_insert_seq(MnDevIndex ix, MnSeqArgs a) {
             int *srow = seq_row(ix, s, l);
             for (int i = 0; i < nsel; i++) { // :582-648
                 const int t = selbuf[i];
-                if (lane == 0)
+                if (lane == 0) {
                     st_link(srow + i, t); // node_add_neighbor(new_node, l, selected[i])
+                    ix.dirty[t] = 1;      // every neighbour of the new node is re-persisted (src/hnsw_vtab.c:761-768)
+                }
                 if (ix.levels[t] < l)      // :590
                     continue;
                 int *trow = seq_row(ix, t, l);

@@ -8,6 +8,20 @@
  * xUpdate contract (:686-784).  What differs is underneath: the index lives in HBM and every
  * hnsw_* call is the C-ABI of include/muninn_hip.h (k_insert_seq keeps the reference's
  * one-at-a-time insert semantics, so the persisted graph is the one the reference would persist).
+ *
+ * Persistence.  The reference rewrites the shadow rows of the new node and of each of
+ * its neighbours inside every xUpdate (src/hnsw_vtab.c:755-776), which costs more than the insert
+ * itself.  Here xUpdate validates and queues the row; the queue is applied to the device index in one
+ * call and the shadow tables are written once from the device's accumulated persist set
+ * (mn_hnsw_take_dirty).  MUNINN_HNSW_MODE (read when the table is connected) says when:
+ *   exact    (default) after every row — shadow tables are current after each INSERT, as the reference's;
+ *   deferred at xSync, or earlier whenever something reads the table (xFilter, DELETE, hnsw_search_batch)
+ *            or the queue is full.  Rows are applied in arrival order with the reference's one-at-a-time
+ *            semantics: the index, the rowids handed out and the COMMITTED shadow tables are identical to
+ *            exact mode; only a direct SELECT on "{t}_nodes"/"{t}_edges" inside the open transaction
+ *            sees them late;
+ *   fast     as deferred, but the queue is built with the batch-synchronous schedule (DESIGN.md §4:
+ *            a different, equally good graph; orders of magnitude faster for bulk loads).
  */
 #include "../../include/muninn_hip.h"
 #include "mn_sqlite_abi.h"
@@ -21,7 +35,19 @@ typedef struct {
     char *name;
     mn_index *index;
     int dim, metric, m, efc;
+    /* rows accepted by xUpdate that are not in the device index yet */
+    sqlite3_int64 *pend_ids;
+    float *pend_vecs;
+    int n_pend, cap_pend;
+    sqlite3_int64 *pset_key; /* open-addressing set of the queued rowids */
+    unsigned char *pset_used;
+    int pset_cap;
+    int mode; /* MUNINN_HNSW_MODE */
 } VtabHnsw;
+
+enum { MODE_EXACT = 0, MODE_DEFERRED = 1, MODE_FAST = 2 };
+#define MN_PEND_MAX_BYTES ((size_t)256 << 20) /* queue is applied when its vectors reach this size ... */
+#define MN_PEND_MAX_ROWS 65536                /* ... or this many rows (fast mode: 16x both) */
 
 typedef struct {
     sqlite3_vtab_cursor base;
@@ -183,80 +209,201 @@ static int node_is_live(VtabHnsw *v, sqlite3_int64 id) { /* hnsw_get_node != NUL
     return mn_hnsw_node_level(v->index, id) >= 0 && mn_hnsw_node_deleted(v->index, id) == 0;
 }
 
-/* persist_node for the new node and for every neighbour it linked to (src/hnsw_vtab.c:237-283,
- * :755-768), in one device round trip: mn_hnsw_edges_of returns all their edges with the
- * per-edge distance the reference stores. */
-static int persist_after_insert(VtabHnsw *v, sqlite3_int64 id, const float *vec) {
-    int level = mn_hnsw_node_level(v->index, id);
-    int cap_ids = 1 + (level + 1) * 2 * v->m;
-    sqlite3_int64 *ids = (sqlite3_int64 *)malloc((size_t)cap_ids * sizeof(sqlite3_int64));
-    if (!ids)
-        return SQLITE_NOMEM;
-    int n = 0;
-    ids[n++] = id;
-    for (int l = 0; l <= level; l++) {
-        int64_t nb[128];
-        int c = mn_hnsw_neighbors(v->index, id, l, nb, 128);
-        for (int i = 0; i < c && i < 128; i++) {
-            int seen = 0;
-            for (int j = 0; j < n; j++)
-                if (ids[j] == nb[i])
-                    seen = 1;
-            if (!seen && n < cap_ids && node_is_live(v, nb[i]))
-                ids[n++] = nb[i];
+/* ── queue of accepted rows ── */
+static unsigned long long pset_hash(sqlite3_int64 id) {
+    unsigned long long h = (unsigned long long)id * 0x9E3779B97F4A7C15ull;
+    return h ^ (h >> 29);
+}
+static int pset_has(const VtabHnsw *v, sqlite3_int64 id) {
+    if (!v->n_pend)
+        return 0;
+    for (unsigned long long i = pset_hash(id);; i++) {
+        int p = (int)(i & (unsigned long long)(v->pset_cap - 1));
+        if (!v->pset_used[p])
+            return 0;
+        if (v->pset_key[p] == id)
+            return 1;
+    }
+}
+static void pset_put(VtabHnsw *v, sqlite3_int64 id) {
+    for (unsigned long long i = pset_hash(id);; i++) {
+        int p = (int)(i & (unsigned long long)(v->pset_cap - 1));
+        if (!v->pset_used[p]) {
+            v->pset_used[p] = 1;
+            v->pset_key[p] = id;
+            return;
         }
     }
-    int64_t cap = (int64_t)n * 4 * v->m + 64;
-    int64_t *src = 0, *dst = 0;
-    int *lvl = 0;
-    float *dist = 0;
-    int64_t ne;
+}
+static void pend_clear(VtabHnsw *v) {
+    v->n_pend = 0;
+    if (v->pset_used)
+        memset(v->pset_used, 0, (size_t)v->pset_cap);
+}
+static void pend_free(VtabHnsw *v) {
+    free(v->pend_ids);
+    free(v->pend_vecs);
+    free(v->pset_key);
+    free(v->pset_used);
+    v->pend_ids = 0;
+    v->pend_vecs = 0;
+    v->pset_key = 0;
+    v->pset_used = 0;
+    v->n_pend = v->cap_pend = v->pset_cap = 0;
+}
+static int pend_add(VtabHnsw *v, sqlite3_int64 id, const float *vec) {
+    if (v->n_pend == v->cap_pend) {
+        int nc = v->cap_pend ? v->cap_pend * 2 : 256;
+        sqlite3_int64 *ni = (sqlite3_int64 *)realloc(v->pend_ids, (size_t)nc * sizeof(sqlite3_int64));
+        if (!ni)
+            return SQLITE_NOMEM;
+        v->pend_ids = ni;
+        float *nv = (float *)realloc(v->pend_vecs, (size_t)nc * v->dim * sizeof(float));
+        if (!nv)
+            return SQLITE_NOMEM;
+        v->pend_vecs = nv;
+        v->cap_pend = nc;
+    }
+    if ((v->n_pend + 1) * 2 > v->pset_cap) { /* keep the set at most half full */
+        int nc = v->pset_cap ? v->pset_cap * 2 : 1024;
+        sqlite3_int64 *nk = (sqlite3_int64 *)malloc((size_t)nc * sizeof(sqlite3_int64));
+        unsigned char *nu = (unsigned char *)calloc((size_t)nc, 1);
+        if (!nk || !nu) {
+            free(nk);
+            free(nu);
+            return SQLITE_NOMEM;
+        }
+        free(v->pset_key);
+        free(v->pset_used);
+        v->pset_key = nk;
+        v->pset_used = nu;
+        v->pset_cap = nc;
+        for (int i = 0; i < v->n_pend; i++)
+            pset_put(v, v->pend_ids[i]);
+    }
+    v->pend_ids[v->n_pend] = id;
+    memcpy(v->pend_vecs + (size_t)v->n_pend * v->dim, vec, (size_t)v->dim * sizeof(float));
+    v->n_pend++;
+    pset_put(v, id);
+    return SQLITE_OK;
+}
+
+/* Shadow rows for everything the device marked since the last call: persist_node (src/hnsw_vtab.c:237-283)
+ * for every new node and every node that was a neighbour of a new node when it was linked (:755-768),
+ * once per node instead of once per insert that touched it.  new_ids/new_vecs = the queue just applied. */
+static int persist_marked(VtabHnsw *v, const sqlite3_int64 *new_ids, const float *new_vecs, int n_new) {
+    sqlite3_stmt *st = 0;
+    char *sql = sqlite3_mprintf("INSERT OR REPLACE INTO \"%w_nodes\" (id, vector, level, deleted) VALUES (?, ?, ?, 0)", v->name);
+    int rc = sqlite3_prepare_v2(v->db, sql, -1, &st, 0);
+    sqlite3_free(sql);
+    if (rc != SQLITE_OK)
+        return rc;
+    for (int i = 0; i < n_new && rc == SQLITE_OK; i++) {
+        sqlite3_bind_int64(st, 1, new_ids[i]);
+        sqlite3_bind_blob(st, 2, new_vecs + (size_t)i * v->dim, v->dim * (int)sizeof(float), SQLITE_STATIC);
+        sqlite3_bind_int(st, 3, mn_hnsw_node_level(v->index, new_ids[i]));
+        rc = sqlite3_step(st) == SQLITE_DONE ? SQLITE_OK : SQLITE_ERROR;
+        sqlite3_reset(st);
+    }
+    sqlite3_finalize(st);
+    if (rc != SQLITE_OK)
+        return rc;
+
+    int64_t cap = (int64_t)n_new * (1 + v->m) + 1024, nd;
+    int64_t *marked = 0;
     for (;;) {
-        src = (int64_t *)malloc((size_t)cap * sizeof(int64_t));
-        dst = (int64_t *)malloc((size_t)cap * sizeof(int64_t));
-        lvl = (int *)malloc((size_t)cap * sizeof(int));
-        dist = (float *)malloc((size_t)cap * sizeof(float));
-        ne = mn_hnsw_edges_of(v->index, (const int64_t *)ids, n, src, dst, lvl, dist, cap);
-        if (ne <= cap)
+        marked = (int64_t *)malloc((size_t)cap * sizeof(int64_t));
+        if (!marked)
+            return SQLITE_NOMEM;
+        nd = mn_hnsw_take_dirty(v->index, marked, cap);
+        if (nd <= cap)
             break;
-        free(src); free(dst); free(lvl); free(dist);
-        cap = ne;
+        free(marked);
+        cap = nd;
     }
-    int rc = SQLITE_OK;
-    if (ne < 0) {
-        rc = SQLITE_ERROR;
-    } else {
-        sqlite3_stmt *st = 0;
-        char *sql = sqlite3_mprintf("INSERT OR REPLACE INTO \"%w_nodes\" (id, vector, level, deleted) VALUES (?, ?, ?, 0)", v->name);
-        rc = sqlite3_prepare_v2(v->db, sql, -1, &st, 0);
-        sqlite3_free(sql);
-        if (rc == SQLITE_OK) {
-            sqlite3_bind_int64(st, 1, id);
-            sqlite3_bind_blob(st, 2, vec, v->dim * (int)sizeof(float), SQLITE_STATIC);
-            sqlite3_bind_int(st, 3, level);
-            rc = sqlite3_step(st) == SQLITE_DONE ? SQLITE_OK : SQLITE_ERROR;
-            sqlite3_finalize(st);
+    if (nd < 0) {
+        free(marked);
+        return SQLITE_ERROR;
+    }
+    /* old edges of the pre-existing marked nodes (new nodes have none yet) */
+    sql = sqlite3_mprintf("DELETE FROM \"%w_edges\" WHERE source_id = ?", v->name);
+    rc = sqlite3_prepare_v2(v->db, sql, -1, &st, 0);
+    sqlite3_free(sql);
+    if (rc != SQLITE_OK) {
+        free(marked);
+        return rc;
+    }
+    for (int64_t i = 0; i < nd; i++) {
+        if (pset_has(v, marked[i]))
+            continue;
+        sqlite3_bind_int64(st, 1, marked[i]);
+        sqlite3_step(st);
+        sqlite3_reset(st);
+    }
+    sqlite3_finalize(st);
+
+    sql = sqlite3_mprintf("INSERT INTO \"%w_edges\" (source_id, target_id, level, distance) VALUES (?, ?, ?, ?)", v->name);
+    rc = sqlite3_prepare_v2(v->db, sql, -1, &st, 0);
+    sqlite3_free(sql);
+    if (rc != SQLITE_OK) {
+        free(marked);
+        return rc;
+    }
+    const int CHUNK = 8192; /* nodes per device round trip */
+    int64_t ecap = (int64_t)CHUNK * 3 * v->m + 64;
+    int64_t *src = (int64_t *)malloc((size_t)ecap * sizeof(int64_t));
+    int64_t *dst = (int64_t *)malloc((size_t)ecap * sizeof(int64_t));
+    int *lvl = (int *)malloc((size_t)ecap * sizeof(int));
+    float *dist = (float *)malloc((size_t)ecap * sizeof(float));
+    for (int64_t pos = 0; pos < nd && rc == SQLITE_OK; pos += CHUNK) {
+        int n = (int)(nd - pos < CHUNK ? nd - pos : CHUNK);
+        int64_t ne = -1;
+        if (src && dst && lvl && dist)
+            ne = mn_hnsw_edges_of(v->index, marked + pos, n, src, dst, lvl, dist, ecap);
+        if (ne > ecap) { /* more edges than the guess: grow and ask again */
+            free(src); free(dst); free(lvl); free(dist);
+            ecap = ne;
+            src = (int64_t *)malloc((size_t)ecap * sizeof(int64_t));
+            dst = (int64_t *)malloc((size_t)ecap * sizeof(int64_t));
+            lvl = (int *)malloc((size_t)ecap * sizeof(int));
+            dist = (float *)malloc((size_t)ecap * sizeof(float));
+            pos -= CHUNK;
+            continue;
         }
-        for (int i = 0; i < n && rc == SQLITE_OK; i++)
-            rc = run_sql(v->db, sqlite3_mprintf("DELETE FROM \"%w_edges\" WHERE source_id = %lld", v->name, (long long)ids[i]));
-        if (rc == SQLITE_OK) {
-            sql = sqlite3_mprintf("INSERT INTO \"%w_edges\" (source_id, target_id, level, distance) VALUES (?, ?, ?, ?)", v->name);
-            rc = sqlite3_prepare_v2(v->db, sql, -1, &st, 0);
-            sqlite3_free(sql);
-            if (rc == SQLITE_OK) {
-                for (int64_t e = 0; e < ne; e++) {
-                    sqlite3_bind_int64(st, 1, src[e]);
-                    sqlite3_bind_int64(st, 2, dst[e]);
-                    sqlite3_bind_int(st, 3, lvl[e]);
-                    sqlite3_bind_double(st, 4, (double)dist[e]);
-                    sqlite3_step(st);
-                    sqlite3_reset(st);
-                }
-                sqlite3_finalize(st);
-            }
+        if (ne < 0) {
+            rc = SQLITE_ERROR;
+            break;
+        }
+        for (int64_t e = 0; e < ne; e++) {
+            sqlite3_bind_int64(st, 1, src[e]);
+            sqlite3_bind_int64(st, 2, dst[e]);
+            sqlite3_bind_int(st, 3, lvl[e]);
+            sqlite3_bind_double(st, 4, (double)dist[e]);
+            sqlite3_step(st);
+            sqlite3_reset(st);
         }
     }
-    free(src); free(dst); free(lvl); free(dist); free(ids);
+    sqlite3_finalize(st);
+    free(src); free(dst); free(lvl); free(dist); free(marked);
+    if (rc == SQLITE_OK)
+        rc = write_config(v);
+    return rc;
+}
+
+/* apply the queue to the device index (arrival order) and write the shadow tables */
+static int flush_pending(VtabHnsw *v) {
+    if (v->n_pend == 0)
+        return SQLITE_OK;
+    int r = v->mode == MODE_FAST ? mn_hnsw_build(v->index, (const int64_t *)v->pend_ids, v->pend_vecs, v->n_pend, 0, 0)
+                          : mn_hnsw_insert_batch(v->index, (const int64_t *)v->pend_ids, v->pend_vecs, v->n_pend, MN_BUILD_SEQUENTIAL);
+    if (r != 0) {
+        sqlite3_free(v->base.zErrMsg);
+        v->base.zErrMsg = sqlite3_mprintf("hnsw_index: insert failed (%s)", mn_last_error());
+        pend_clear(v);
+        return SQLITE_ERROR;
+    }
+    int rc = persist_marked(v, v->pend_ids, v->pend_vecs, v->n_pend);
+    pend_clear(v);
     return rc;
 }
 
@@ -305,6 +452,8 @@ static VtabHnsw *new_vtab(sqlite3 *db, const char *name, const Params *p, mn_ind
     v->metric = p->metric;
     v->m = p->m;
     v->efc = p->efc;
+    const char *mode = getenv("MUNINN_HNSW_MODE");
+    v->mode = mode && !strcmp(mode, "fast") ? MODE_FAST : mode && !strcmp(mode, "deferred") ? MODE_DEFERRED : MODE_EXACT;
     live_add(v);
     return v;
 }
@@ -383,6 +532,7 @@ static int x_connect(sqlite3 *db, void *aux, int argc, const char *const *argv, 
 static int x_disconnect(sqlite3_vtab *vt) {
     VtabHnsw *v = (VtabHnsw *)vt;
     live_remove(v);
+    pend_free(v);
     mn_hnsw_destroy(v->index);
     sqlite3_free(v->name);
     sqlite3_free(v);
@@ -467,6 +617,11 @@ static int x_filter(sqlite3_vtab_cursor *cur, int idxNum, const char *idxStr, in
     c->n_hits = c->pos = 0;
     c->is_point = 0;
     c->eof = 1;
+    if (idxNum != PLAN_SCAN) { /* rows queued in this transaction must be visible to the read */
+        int frc = flush_pending(v);
+        if (frc != SQLITE_OK)
+            return frc;
+    }
     if (idxNum == PLAN_KNN) {
         const float *q = (const float *)sqlite3_value_blob(argv[0]);
         int qbytes = sqlite3_value_bytes(argv[0]);
@@ -531,6 +686,11 @@ static int x_update(sqlite3_vtab *vt, int argc, sqlite3_value **argv, sqlite3_in
     VtabHnsw *v = (VtabHnsw *)vt;
     if (argc == 1) { /* DELETE */
         sqlite3_int64 id = sqlite3_value_int64(argv[0]);
+        /* hnsw_delete edits neighbour lists that the reference leaves un-persisted (:702-706): what earlier
+         * inserts marked must be written before those edits, as the reference wrote it at insert time */
+        int frc = flush_pending(v);
+        if (frc != SQLITE_OK)
+            return frc;
         if (!node_is_live(v, id)) {
             v->base.zErrMsg = sqlite3_mprintf("hnsw_index: rowid %lld not found", (long long)id);
             return SQLITE_ERROR;
@@ -546,8 +706,8 @@ static int x_update(sqlite3_vtab *vt, int argc, sqlite3_value **argv, sqlite3_in
     if (argc > 1 && sqlite3_value_type(argv[0]) == SQLITE_NULL) { /* INSERT */
         sqlite3_int64 id;
         if (sqlite3_value_type(argv[1]) == SQLITE_NULL) {
-            id = mn_hnsw_node_count(v->index) + 1; /* :722-727 */
-            while (node_is_live(v, id))
+            id = mn_hnsw_node_count(v->index) + v->n_pend + 1; /* :722-727 */
+            while (node_is_live(v, id) || pset_has(v, id))
                 id++;
         } else {
             id = sqlite3_value_int64(argv[1]);
@@ -563,17 +723,39 @@ static int x_update(sqlite3_vtab *vt, int argc, sqlite3_value **argv, sqlite3_in
             v->base.zErrMsg = sqlite3_mprintf("hnsw_index: expected %d-dim vector (%d bytes), got %d bytes", v->dim, want, bytes);
             return SQLITE_ERROR;
         }
-        if (mn_hnsw_insert(v->index, id, vec) != 0) {
+        /* hnsw_insert refuses an id that is in the table, soft-deleted or not (src/hnsw_algo.c:522-524) */
+        if (mn_hnsw_node_level(v->index, id) >= 0 || pset_has(v, id)) {
             v->base.zErrMsg = sqlite3_mprintf("hnsw_index: insert failed (duplicate rowid %lld?)", (long long)id);
             return SQLITE_ERROR;
         }
-        persist_after_insert(v, id, vec);
-        write_config(v);
+        int arc = pend_add(v, id, vec);
+        if (arc != SQLITE_OK)
+            return arc;
         *rowid = id;
+        const int scale = v->mode == MODE_FAST ? 16 : 1;
+        if (v->mode == MODE_EXACT || v->n_pend >= MN_PEND_MAX_ROWS * scale ||
+            (size_t)v->n_pend * v->dim * sizeof(float) >= MN_PEND_MAX_BYTES * (size_t)scale)
+            return flush_pending(v);
         return SQLITE_OK;
     }
     v->base.zErrMsg = sqlite3_mprintf("hnsw_index: UPDATE not supported, use DELETE + INSERT");
     return SQLITE_ERROR;
+}
+
+/* Transaction hooks exist only to learn when the statement/transaction ends (the reference's module has
+ * none, src/hnsw_vtab.c:788-803): xSync applies and persists the queue, xRollback drops it. */
+static int x_begin(sqlite3_vtab *vt) {
+    (void)vt;
+    return SQLITE_OK;
+}
+static int x_sync(sqlite3_vtab *vt) { return flush_pending((VtabHnsw *)vt); }
+static int x_commit(sqlite3_vtab *vt) {
+    (void)vt;
+    return SQLITE_OK;
+}
+static int x_rollback(sqlite3_vtab *vt) {
+    pend_clear((VtabHnsw *)vt);
+    return SQLITE_OK;
 }
 
 static sqlite3_module hnsw_module = {
@@ -591,6 +773,10 @@ static sqlite3_module hnsw_module = {
     .xColumn = x_column,
     .xRowid = x_rowid,
     .xUpdate = x_update,
+    .xBegin = x_begin,
+    .xSync = x_sync,
+    .xCommit = x_commit,
+    .xRollback = x_rollback,
 };
 
 /* ───────────────────────── hnsw_search_batch: many queries, one launch ─────────────────────────
@@ -701,6 +887,10 @@ static int b_filter(sqlite3_vtab_cursor *cur, int idxNum, const char *idxStr, in
     }
     if (!v) {
         bv->base.zErrMsg = sqlite3_mprintf("hnsw_search_batch: no hnsw_index table named '%s'", tbl ? tbl : "");
+        return SQLITE_ERROR;
+    }
+    if (flush_pending(v) != SQLITE_OK) {
+        bv->base.zErrMsg = sqlite3_mprintf("hnsw_search_batch: %s", v->base.zErrMsg ? v->base.zErrMsg : "pending inserts failed");
         return SQLITE_ERROR;
     }
     int row = v->dim * (int)sizeof(float);

@@ -71,6 +71,7 @@ SYMBOLS = [
     ("mn_hnsw_export_nodes", C.c_int, [C.c_void_p, _i64p, _i32p, _i32p]),
     ("mn_hnsw_export_vectors", C.c_int, [C.c_void_p, _f32p]),
     ("mn_hnsw_export_links", C.c_int, [C.c_void_p, C.c_int, _i32p, C.POINTER(C.c_int)]),
+    ("mn_hnsw_take_dirty", C.c_int64, [C.c_void_p, _i64p, C.c_int64]),
     ("mn_hnsw_edges_of", C.c_int64, [C.c_void_p, _i64p, C.c_int, _i64p, _i64p, _i32p, _f32p, C.c_int64]),
     ("mn_hnsw_last_launch", C.c_int, [C.c_void_p, C.POINTER(LaunchStats)]),
     ("mn_dev_malloc", C.c_void_p, [C.c_void_p, C.c_size_t]),
@@ -270,6 +271,18 @@ class HnswIndex:
             raise MuninnHipError(_err())
         assert w.value == M0
         return out
+
+    def take_dirty(self):
+        """ids the reference's xUpdate would have re-persisted since the last call (src/hnsw_vtab.c:755-768)."""
+        cap = 1024
+        while True:
+            out = np.empty(cap, np.int64)
+            n = self.L.mn_hnsw_take_dirty(self.h, out, cap)
+            if n < 0:
+                raise MuninnHipError(_err())
+            if n <= cap:
+                return out[:n]
+            cap = int(n)
 
     def edges_of(self, ids):
         ids = np.ascontiguousarray(ids, np.int64)

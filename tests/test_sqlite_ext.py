@@ -183,13 +183,15 @@ def test_persistence_across_reopen(ext_built, gpu, tmp_path):
 
 
 @gpu_mark
-def test_shadow_tables_identical_to_reference(ext_built, gpu, tmp_path):
+@pytest.mark.parametrize("mode", ["exact", "deferred"])
+def test_shadow_tables_identical_to_reference(ext_built, gpu, tmp_path, monkeypatch, mode):
     """tests/golden/vtab_shadow.npz holds what the REFERENCE's extension wrote for a seeded input
     (oracle/gen_golden.py: vtab_shadow).  The same inserts through ours must leave identical _config,
     _nodes and _edges rows, including the per-edge REAL distance; and the database file the reference
     wrote (tests/golden/ref_written.db) must open here and answer the recorded queries identically."""
     import shutil
 
+    monkeypatch.setenv("MUNINN_HNSW_MODE", mode)
     G = os.path.join(ROOT, "tests", "golden")
     z = np.load(os.path.join(G, "vtab_shadow.npz"))
     X = np.random.default_rng(5).standard_normal((300, 12), dtype=np.float32)
@@ -340,3 +342,88 @@ def test_graph_leiden_sql_fast_mode_matches_oracle_schedule(conn, gpu, monkeypat
     rows2 = conn.execute("SELECT community_id FROM graph_leiden WHERE edge_table='gf' AND src_col='src' AND dst_col='dst'").fetchall()
     z = np.load(os.path.join(ROOT, "tests", "golden", "leiden.npz"))
     assert np.array_equal(np.array([r[0] for r in rows2], np.int32), z["er2000_community"])
+
+
+# ───────────────────────── deferred inserts / bulk persistence ─────────────────────────
+
+@gpu_mark
+@pytest.mark.parametrize("mode", ["exact", "deferred"])
+def test_mixed_transaction_ops_match_reference(ext_built, gpu, monkeypatch, mode):
+    """Inserts (explicit and automatic rowids), deletes and a search interleaved inside transactions, then
+    autocommit inserts: the rowids handed out, the answers and the final _config/_nodes/_edges rows are those of
+    the reference's extension for the same SQL (tests/golden/vtab_mixed.npz, oracle/gen_golden.py:vtab_mixed) —
+    in exact mode (persist per row) and in deferred mode (rows queued by xUpdate, persisted once per flush)."""
+    from oracle.gen_golden import vtab_mixed_ops
+
+    monkeypatch.setenv("MUNINN_HNSW_MODE", mode)
+    conn = sqlite3.connect(":memory:")
+    conn.enable_load_extension(True)
+    conn.load_extension(ext_built)
+    z = np.load(os.path.join(ROOT, "tests", "golden", "vtab_mixed.npz"))
+    got = vtab_mixed_ops(conn, z["X"], z["Q"])
+    conn.close()
+    assert got["log"].tolist() == z["log"].tolist()
+    assert got["config"].tolist() == z["config"].tolist()
+    assert np.array_equal(got["nodes"], z["nodes"])
+    assert np.array_equal(got["edges_int"], z["edges_int"])
+    assert np.array_equal(got["edges_dist"], z["edges_dist"])
+    assert np.array_equal(got["res_ids"], z["res_ids"]) and np.array_equal(got["res_dist"], z["res_dist"])
+
+
+@gpu_mark
+def test_queued_rows_rollback_duplicates_and_visibility(conn, gpu, monkeypatch):
+    monkeypatch.setenv("MUNINN_HNSW_MODE", "deferred")
+    conn.execute("CREATE VIRTUAL TABLE q USING hnsw_index(dimensions=2, metric='l2', m=4)")
+    conn.isolation_level = None  # explicit transactions
+    conn.execute("BEGIN")
+    conn.execute("INSERT INTO q (rowid, vector) VALUES (1, ?)", (vec([0, 0]),))
+    conn.execute("INSERT INTO q (rowid, vector) VALUES (2, ?)", (vec([1, 0]),))
+    with pytest.raises(Exception, match=r"insert failed \(duplicate rowid 2\?\)"):
+        conn.execute("INSERT INTO q (rowid, vector) VALUES (2, ?)", (vec([5, 5]),))  # reported by the INSERT itself
+    # queued rows are visible to reads of the same transaction
+    assert [r[0] for r in conn.execute("SELECT rowid FROM q WHERE vector MATCH ? AND k = 2", (vec([0.9, 0]),))] == [2, 1]
+    assert conn.execute("SELECT count(*) FROM q_nodes").fetchone()[0] == 2
+    conn.execute("INSERT INTO q (rowid, vector) VALUES (3, ?)", (vec([0, 1]),))
+    conn.execute("ROLLBACK")  # row 3 was only queued: it never reaches the index
+    assert conn.execute("SELECT count(*) FROM q_nodes").fetchone()[0] == 0
+    assert conn.execute("SELECT rowid FROM q WHERE rowid = 3").fetchall() == []
+    conn.execute("BEGIN")
+    conn.execute("INSERT INTO q (rowid, vector) VALUES (3, ?)", (vec([0, 1]),))
+    conn.execute("COMMIT")
+    assert conn.execute("SELECT rowid FROM q WHERE rowid = 3").fetchall() == [(3,)]
+    assert conn.execute("SELECT count(*) FROM q_edges WHERE source_id = 3").fetchone()[0] >= 1
+
+
+@gpu_mark
+def test_fast_mode_bulk_load_and_reopen(ext_built, gpu, tmp_path, monkeypatch):
+    """MUNINN_HNSW_MODE=fast: one transaction of 6000 rows → batch-synchronous device build, shadow tables written
+    once; recall equals the exact-mode table's within 0.02 and the file reopens (in exact mode) with the same answers."""
+    monkeypatch.setenv("MUNINN_HNSW_MODE", "fast")
+    rng = np.random.default_rng(17)
+    n, dim = 6000, 24
+    base = rng.standard_normal((n, 6), dtype=np.float32) @ rng.standard_normal((6, dim), dtype=np.float32)
+    X = (base + 0.05 * rng.standard_normal((n, dim), dtype=np.float32)).astype(np.float32)
+    Q = X[rng.choice(n, 40, replace=False)] + 0.01
+    db = str(tmp_path / "fast.db")
+    c = sqlite3.connect(db)
+    c.enable_load_extension(True)
+    c.load_extension(ext_built)
+    c.execute("CREATE VIRTUAL TABLE f USING hnsw_index(dimensions=24, metric='l2', m=8, ef_construction=80)")
+    with c:
+        c.executemany("INSERT INTO f (rowid, vector) VALUES (?, ?)", [(i + 1, X[i].tobytes()) for i in range(n)])
+    assert c.execute("SELECT count(*) FROM f_nodes").fetchone()[0] == n
+    truth = [set((np.argsort(((X - q) ** 2).sum(1))[:10] + 1).tolist()) for q in Q]
+    ans = [c.execute("SELECT rowid, distance FROM f WHERE vector MATCH ? AND k = 10 AND ef_search = 80", (q.tobytes(),)).fetchall() for q in Q]
+    recall = np.mean([len(truth[i] & {r[0] for r in ans[i]}) / 10 for i in range(len(Q))])
+    assert recall > 0.9, recall
+    ne = c.execute("SELECT count(*) FROM f_edges").fetchone()[0]
+    assert n * 4 < ne <= n * 20  # <= 2M per node at level 0 plus the upper layers
+    c.close()
+    monkeypatch.setenv("MUNINN_HNSW_MODE", "exact")
+    c = sqlite3.connect(db)
+    c.enable_load_extension(True)
+    c.load_extension(ext_built)
+    again = [c.execute("SELECT rowid FROM f WHERE vector MATCH ? AND k = 10 AND ef_search = 80", (q.tobytes(),)).fetchall() for q in Q]
+    recall2 = np.mean([len(truth[i] & {r[0] for r in again[i]}) / 10 for i in range(len(Q))])
+    assert abs(recall2 - recall) < 0.03
+    c.close()
