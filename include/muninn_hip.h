@@ -215,12 +215,16 @@ const char *mn_node2vec_last_error(void);
 typedef struct mn_n2v_session mn_n2v_session;
 mn_n2v_session *mn_n2v_begin(int n_nodes, const int *off, const int *adj, const mn_n2v_params *prm, int device);
 int mn_n2v_batch_walks(mn_n2v_session *s);  /* resolved walks per batch */
-int mn_n2v_sample_slots(mn_n2v_session *s); /* sample slots per walk = walk_length * 2*window * (1+neg) */
-/* walks of start nodes [lo, hi) (hi - lo <= batch_walks) of pass (epoch, w): fills [(hi-lo) * slots] entries;
- * unused slots carry centre = target = -1 */
-int mn_n2v_samples(mn_n2v_session *s, int epoch, int w, int lo, int hi, int *d_center, int *d_target, float *d_err);
-/* applies ns sample slots in the given order (any concatenation of mn_n2v_samples outputs) */
-int mn_n2v_apply(mn_n2v_session *s, const int *d_center, const int *d_target, const float *d_err, int64_t ns);
+int mn_n2v_sample_slots(mn_n2v_session *s);   /* sample slots per walk = walk_length * 2*window * (1+neg) */
+int mn_n2v_position_slots(mn_n2v_session *s); /* position slots per walk = walk_length */
+/* walks of start nodes [lo, hi) (hi - lo <= batch_walks) of pass (epoch, w).  Per walk: `sample_slots` (centre,
+ * target, err) triples — the target-side updates, unused slots carry -1 — and `position_slots` (centre, neu1e[dim])
+ * entries — the centre-side update of each walk position (src/node2vec.c:347,:383-391), -1 past the walk's end. */
+int mn_n2v_samples(mn_n2v_session *s, int epoch, int w, int lo, int hi, int *d_center, int *d_target, float *d_err,
+                   int *d_pos_center, float *d_pos_neu);
+/* applies ns sample slots and np position slots in the given order (any concatenation of mn_n2v_samples outputs) */
+int mn_n2v_apply(mn_n2v_session *s, const int *d_center, const int *d_target, const float *d_err, int64_t ns,
+                 const int *d_pos_center, const float *d_pos_neu, int64_t np);
 int mn_n2v_sync(mn_n2v_session *s);
 int mn_n2v_finish(mn_n2v_session *s, float *out, mn_n2v_stats *stats); /* L2 normalise, download [n][dim] */
 void mn_n2v_end(mn_n2v_session *s);

@@ -648,8 +648,10 @@ int orc_node2vec_train(const orc_n2v_graph *g, const orc_n2v_params *p, float *o
  *  (2) every sample's error is computed against the matrices as they stood at batch start:
  *      err = (label - sigmoid_lut(dot)) * lr_walk, dot in wave order (lane L folds d ≡ L mod 64 with fmaf,
  *      xor butterfly 32..1);
- *  (3) syn0[c] += Σ err·syn1neg_old[t] over the batch's samples with centre c, in sample order (fmaf);
- *      syn1neg[t] += Σ err·syn0_old[c] likewise.
+ *  (3) centre side, as the reference's neu1e (src/node2vec.c:347,:383-391) but once per walk position: the
+ *      position's neu1e = Σ err·syn1neg_old[t] over all its samples in sample order (fmaf from 0), then
+ *      syn0[c] = syn0[c] + neu1e, positions applied in (walk, position) order;
+ *      target side: syn1neg[t] += Σ err·syn0_old[c] over the batch's samples with target t, in sample order (fmaf).
  * Final L2 normalisation as the reference (:540-551). */
 static unsigned n2v_walk_seed(int epoch, int w, int n) {
     unsigned s = 42u ^ ((unsigned)epoch * 0x9E3779B9u) ^ ((unsigned)w * 0x85EBCA6Bu) ^ ((unsigned)n * 0xC2B2AE35u);
@@ -695,6 +697,7 @@ int orc_node2vec_train_batched(const orc_n2v_graph *g, const orc_n2v_params *p, 
     float *old1 = (float *)malloc((size_t)N * dim * sizeof(float));
     int *neg_table = (int *)malloc(N2V_NEG_TABLE * sizeof(int));
     int *walk = (int *)malloc((size_t)p->walk_length * sizeof(int));
+    float *neu = (float *)malloc((size_t)dim * sizeof(float));
     for (int i = 0; i < N * dim; i++)
         syn0[i] = ((float)n2v_rand(&rng) - 0.5f) / (float)dim;
     orc_n2v_neg_table(g, neg_table);
@@ -722,6 +725,7 @@ int orc_node2vec_train_batched(const orc_n2v_graph *g, const orc_n2v_params *p, 
                             cs = 0;
                         if (ce >= wlen)
                             ce = wlen - 1;
+                        memset(neu, 0, (size_t)dim * sizeof(float));
                         for (int c = cs; c <= ce; c++) {
                             if (c == pos)
                                 continue;
@@ -745,20 +749,23 @@ int orc_node2vec_train_batched(const orc_n2v_graph *g, const orc_n2v_params *p, 
                                 smp[ns].target = target;
                                 smp[ns].err = err;
                                 ns++;
+                                const float *t1 = old1 + (size_t)target * dim;
+                                for (int d = 0; d < dim; d++) /* the position's neu1e (src/node2vec.c:383-385) */
+                                    neu[d] = fmaf(err, t1[d], neu[d]);
                             }
                         }
+                        /* centre side, once per position, positions in (walk, pos) order */
+                        float *dc = syn0 + (size_t)walk[pos] * dim;
+                        for (int d = 0; d < dim; d++)
+                            dc[d] = dc[d] + neu[d];
                     }
                 }
-                /* (3) per-destination accumulation in sample order */
+                /* (3) target side: per-destination accumulation in sample order, from the old centres */
                 for (size_t i = 0; i < ns; i++) {
-                    float *dc = syn0 + (size_t)smp[i].center * dim;
-                    const float *st1 = old1 + (size_t)smp[i].target * dim;
                     float *dt = syn1 + (size_t)smp[i].target * dim;
                     const float *sc0 = old0 + (size_t)smp[i].center * dim;
-                    for (int d = 0; d < dim; d++) {
-                        dc[d] = fmaf(smp[i].err, st1[d], dc[d]);
+                    for (int d = 0; d < dim; d++)
                         dt[d] = fmaf(smp[i].err, sc0[d], dt[d]);
-                    }
                 }
             }
     for (int i = 0; i < N; i++) {
@@ -778,6 +785,7 @@ int orc_node2vec_train_batched(const orc_n2v_graph *g, const orc_n2v_params *p, 
     free(old1);
     free(neg_table);
     free(walk);
+    free(neu);
     free(smp);
     return N;
 }

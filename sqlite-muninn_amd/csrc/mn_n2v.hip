@@ -404,6 +404,9 @@ static int session_init(mn_n2v_session *S, int n, const int *off, const int *adj
     NCHK(hipMalloc(&S->s_center, S->ns_max * sizeof(int)));
     NCHK(hipMalloc(&S->s_target, S->ns_max * sizeof(int)));
     NCHK(hipMalloc(&S->s_err, S->ns_max * sizeof(float)));
+    S->np_max = (size_t)(B + 64) * prm->walk_length;
+    NCHK(hipMalloc(&S->p_center, S->np_max * sizeof(int)));
+    NCHK(hipMalloc(&S->p_neu, S->np_max * dim * sizeof(float)));
     NCHK(hipMalloc(&S->keys, S->ns_max * sizeof(int)));
     NCHK(hipMalloc(&S->vals, S->ns_max * sizeof(int)));
     NCHK(hipMalloc(&S->keys_s, S->ns_max * sizeof(int)));
@@ -443,17 +446,20 @@ extern "C" mn_n2v_session *mn_n2v_begin(int n, const int *off, const int *adj, c
 }
 extern "C" int mn_n2v_batch_walks(mn_n2v_session *S) { return S->B; }
 extern "C" int mn_n2v_sample_slots(mn_n2v_session *S) { return S->cap; }
-extern "C" int mn_n2v_samples(mn_n2v_session *S, int epoch, int w, int lo, int hi, int *d_center, int *d_target, float *d_err) {
+extern "C" int mn_n2v_position_slots(mn_n2v_session *S) { return S->a.walk_length; }
+extern "C" int mn_n2v_samples(mn_n2v_session *S, int epoch, int w, int lo, int hi, int *d_center, int *d_target, float *d_err,
+                              int *d_pcenter, float *d_pneu) {
     NCHK(hipSetDevice(S->device));
     if (lo < 0 || hi > S->a.n || hi <= lo || hi - lo > S->B) {
         nset_err("mn_n2v_samples: bad walk range [%d, %d)", lo, hi);
         return -1;
     }
-    return n2v_samples(S, epoch, w, lo, hi, d_center, d_target, d_err);
+    return n2v_samples(S, epoch, w, lo, hi, d_center, d_target, d_err, d_pcenter, d_pneu);
 }
-extern "C" int mn_n2v_apply(mn_n2v_session *S, const int *d_center, const int *d_target, const float *d_err, int64_t ns) {
+extern "C" int mn_n2v_apply(mn_n2v_session *S, const int *d_center, const int *d_target, const float *d_err, int64_t ns,
+                            const int *d_pcenter, const float *d_pneu, int64_t np) {
     NCHK(hipSetDevice(S->device));
-    return n2v_apply(S, d_center, d_target, d_err, ns);
+    return n2v_apply(S, d_center, d_target, d_err, ns, d_pcenter, d_pneu, np);
 }
 extern "C" int mn_n2v_sync(mn_n2v_session *S) {
     NCHK(hipSetDevice(S->device));
@@ -504,9 +510,10 @@ extern "C" int mn_node2vec_train(int n, const int *off, const int *adj, const mn
             for (int w = 0; w < prm->num_walks && rc == 0; w++)
                 for (int b0 = 0; b0 < n && rc == 0; b0 += S->B) {
                     int b1 = std::min(n, b0 + S->B);
-                    rc = n2v_samples(S, epoch, w, b0, b1, S->s_center, S->s_target, S->s_err);
+                    rc = n2v_samples(S, epoch, w, b0, b1, S->s_center, S->s_target, S->s_err, S->p_center, S->p_neu);
                     if (rc == 0)
-                        rc = n2v_apply(S, S->s_center, S->s_target, S->s_err, (int64_t)(b1 - b0) * S->cap);
+                        rc = n2v_apply(S, S->s_center, S->s_target, S->s_err, (int64_t)(b1 - b0) * S->cap, S->p_center, S->p_neu,
+                                       (int64_t)(b1 - b0) * prm->walk_length);
                 }
         if (rc == 0)
             rc = mn_n2v_finish(S, out, stats);

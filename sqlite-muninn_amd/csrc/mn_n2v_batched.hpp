@@ -4,12 +4,17 @@
 // oracle/mn_graph_oracle.c orc_node2vec_train_batched restates it):
 //   k_n2v_walk_grad  one wavefront per walk: its own xorshift32 stream (seeded from epoch, w, n) draws the
 //                    biased walk and then the negatives of its pairs in pair order; every sample's error is
-//                    taken against the matrices frozen at batch start (centre row in registers, target rows
-//                    as coalesced 256-B loads, lane-strided fmaf + xor butterfly, the reference's sigmoid LUT)
-//   sort             rocPRIM stable radix sort of sample indices by destination row (plumbing)
-//   k_n2v_apply      one wavefront per destination row: row += Σ err · source_row in sample order (fmaf);
-//                    centres into a staging matrix first (targets read the old centres), targets in place,
+//                    taken against the matrices frozen at batch start (centre row in registers, the target
+//                    rows of one pair fetched together, lane-strided fmaf + xor butterfly, the reference's
+//                    sigmoid LUT).  While a target row is in registers its contribution err·row is folded
+//                    into the position's neu1e (src/node2vec.c:347,:383-385), written once per position.
+//   sort             rocPRIM stable radix sort by destination row (plumbing): positions by centre,
+//                    samples by target
+//   k_n2v_apply_centers  one wavefront per centre row: staged = row + Σ neu1e of its positions, in walk order
+//   k_n2v_apply      one wavefront per target row: row += Σ err · centre_row(old) in sample order (fmaf);
 //                    then k_n2v_commit copies the staged centre rows back
+// HBM traffic per pair: (1+neg) target rows for the dots + (1+neg) centre rows for the target updates; the
+// centre-side update costs one row per walk position instead of (1+neg) rows per pair.
 // No float atomics anywhere: embeddings are bit-reproducible and equal the CPU restatement's.
 #pragma once
 #include <cstring>
@@ -24,6 +29,8 @@ struct N2vBatchArgs {
     int cap; // sample slots per walk
     int *s_center, *s_target;
     float *s_err;
+    int *p_center; // [walks][walk_length] centre of each walk position, -1 past the walk's end
+    float *p_neu;  // [walks][walk_length][dim] Σ err · target_row(old) over the position's samples
     double *cum_scratch; // [walks][max_deg], used when a node has more than N2VB_LDS_DEG neighbours
     int max_deg;
     unsigned long long *pairs_out;
@@ -119,6 +126,66 @@ DEVI int gen_walk(const N2vArgs &a, int n, unsigned &rng, int *walk, double *cum
     return a.walk_length;
 }
 
+// Samples s0 .. s0+nd-1 of one (centre, context) pair (src/node2vec.c:353-386): draw the targets (the stream is
+// consumed in sample order), fetch all their rows at once, then score them in order.  FULL (nd == PF) is the
+// branch-free path: a rejected negative (== centre or context, :361-363) still has its row fetched, but leaves no
+// sample and no contribution.  The sample slot is written before it is known to be kept; a rejected one is
+// overwritten by the next sample or by the walk's -1 tail fill.
+template <int NR, int PF, bool FULL>
+DEVI void n2v_score_chunk(const N2vArgs &a, const N2vBatchArgs &b, unsigned &rng, int s0, int nd, int center, int context,
+                          const float (&vc)[NR], float (&neu)[NR], float lr, size_t base, int &ns, int lane) {
+    const int dim = a.dim;
+    int tg[PF];
+    bool ok[PF];
+#pragma unroll
+    for (int i = 0; i < PF; i++) {
+        tg[i] = context;
+        ok[i] = false;
+        if (FULL || i < nd) {
+            if (i == 0 && s0 == 0) {
+                ok[i] = true; // the positive sample
+            } else {
+                tg[i] = a.neg_table[xs32(rng) % N2V_NEG_TABLE];
+                ok[i] = tg[i] != center && tg[i] != context;
+            }
+        }
+    }
+    float tr[PF][NR];
+#pragma unroll
+    for (int i = 0; i < PF; i++)
+        if (FULL || i < nd) {
+            const float *rowt = a.syn1neg + (size_t)tg[i] * dim;
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                int d = lane + 64 * r;
+                tr[i][r] = d < dim ? rowt[d] : 0.0f;
+            }
+        }
+#pragma unroll
+    for (int i = 0; i < PF; i++)
+        if (FULL || i < nd) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int r = 0; r < NR; r++)
+                if (lane + 64 * r < dim)
+                    acc = fmaf(vc[r], tr[i][r], acc);
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1)
+                acc = __fadd_rn(acc, __shfl_xor(acc, m));
+            const float label = (i == 0 && s0 == 0) ? 1.0f : 0.0f;
+            const float err = __fmul_rn(__fsub_rn(label, fast_sigmoid(a.sig_table, acc)), lr);
+            if (lane == 0) {
+                b.s_center[base + ns] = center;
+                b.s_target[base + ns] = tg[i];
+                b.s_err[base + ns] = err;
+            }
+            ns += ok[i] ? 1 : 0;
+#pragma unroll
+            for (int r = 0; r < NR; r++)
+                neu[r] = ok[i] ? fmaf(err, tr[i][r], neu[r]) : neu[r];
+        }
+}
+
 template <int NR> // NR = ceil(dim / 64) register slots per lane
 __global__ void __launch_bounds__(64) k_n2v_walk_grad(N2vBatchArgs b) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -140,6 +207,14 @@ __global__ void __launch_bounds__(64) k_n2v_walk_grad(N2vBatchArgs b) {
     __builtin_amdgcn_wave_barrier();
     const int dim = a.dim;
     const size_t base = (size_t)blockIdx.x * b.cap;
+    const size_t pbase = (size_t)blockIdx.x * a.walk_length;
+#ifdef MN_N2V_PF // timing experiments only
+    constexpr int PF = MN_N2V_PF;
+#else
+    // target rows in flight per wavefront.  Measured on MI355X (1M nodes, dim 128, device time of one pass):
+    // PF 1: 1.72 s, 2: 1.52 s, 3: 1.51 s, 4: 1.62 s, 6: 2.24 s
+    constexpr int PF = NR <= 4 ? 3 : 2;
+#endif
     int ns = 0;
     unsigned long long pairs = 0;
     for (int pos = 0; pos < wlen; pos++) {
@@ -149,55 +224,45 @@ __global__ void __launch_bounds__(64) k_n2v_walk_grad(N2vBatchArgs b) {
             cs = 0;
         if (ce >= wlen)
             ce = wlen - 1;
-        float vc[NR];
+        float vc[NR], neu[NR];
         const float *rowc = a.syn0 + (size_t)center * dim;
 #pragma unroll
         for (int r = 0; r < NR; r++) {
             int d = lane + 64 * r;
             vc[r] = d < dim ? rowc[d] : 0.0f;
+            neu[r] = 0.0f;
         }
         for (int c = cs; c <= ce; c++) {
             if (c == pos)
                 continue;
             const int context = walk[c];
             pairs++;
-            for (int s = 0; s <= a.neg; s++) {
-                int target;
-                float label;
-                if (s == 0) {
-                    target = context;
-                    label = 1.0f;
-                } else {
-                    target = a.neg_table[xs32(rng) % N2V_NEG_TABLE];
-                    if (target == center || target == context)
-                        continue;
-                    label = 0.0f;
-                }
-                const float *rowt = a.syn1neg + (size_t)target * dim;
-                float acc = 0.0f;
-#pragma unroll
-                for (int r = 0; r < NR; r++) {
-                    int d = lane + 64 * r;
-                    if (d < dim)
-                        acc = fmaf(vc[r], rowt[d], acc);
-                }
-#pragma unroll
-                for (int m = 32; m >= 1; m >>= 1)
-                    acc = __fadd_rn(acc, __shfl_xor(acc, m));
-                const float err = __fmul_rn(__fsub_rn(label, fast_sigmoid(a.sig_table, acc)), lr);
-                if (lane == 0) {
-                    b.s_center[base + ns] = center;
-                    b.s_target[base + ns] = target;
-                    b.s_err[base + ns] = err;
-                }
-                ns++;
+            for (int s0 = 0; s0 <= a.neg; s0 += PF) {
+                const int nd = a.neg + 1 - s0 < PF ? a.neg + 1 - s0 : PF;
+                if (nd == PF)
+                    n2v_score_chunk<NR, PF, true>(a, b, rng, s0, nd, center, context, vc, neu, lr, base, ns, lane);
+                else
+                    n2v_score_chunk<NR, PF, false>(a, b, rng, s0, nd, center, context, vc, neu, lr, base, ns, lane);
             }
         }
+        if (lane == 0)
+            b.p_center[pbase + pos] = center;
+#ifndef MN_N2V_NO_PNEU // timing experiments only
+        float *pn = b.p_neu + (pbase + pos) * dim;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            int d = lane + 64 * r;
+            if (d < dim)
+                pn[d] = neu[r];
+        }
+#endif
     }
     for (int i = ns + lane; i < b.cap; i += 64) {
         b.s_center[base + i] = -1;
         b.s_target[base + i] = -1;
     }
+    for (int i = wlen + lane; i < a.walk_length; i += 64)
+        b.p_center[pbase + i] = -1;
     if (lane == 0)
         atomicAdd(b.pairs_out, pairs);
 }
@@ -224,7 +289,8 @@ __global__ void k_n2v_segments(const int *keys_sorted, int n_samples, int n_node
         seg_start[k] = (int)i;
 }
 
-// dest row += Σ err · src row over the segment, in sorted (= sample) order
+// target row += Σ err · centre row (old) over the row's samples, in sorted (= sample) order.  Sample metadata is
+// fetched 64 at a time (one per lane) and the source rows of 4 samples are in flight while the fmaf chain runs.
 template <int NR>
 __global__ void __launch_bounds__(64)
     k_n2v_apply(const int *keys_sorted, const int *vals_sorted, const int *seg_start, int n_samples, const int *other,
@@ -241,15 +307,85 @@ __global__ void __launch_bounds__(64)
         int d = lane + 64 * r;
         acc[r] = d < dim ? row[d] : 0.0f;
     }
-    for (; j < n_samples && keys_sorted[j] == k; j++) {
-        const int i = vals_sorted[j];
-        const float err = s_err[i];
-        const float *src = src_mat + (size_t)other[i] * dim;
+    constexpr int U = NR <= 2 ? 8 : NR <= 4 ? 4 : 1;
+    for (;;) {
+        // this lane's sample of the next 64
+        const int jj = j + lane;
+        const bool mine = jj < n_samples && keys_sorted[jj] == k;
+        int src_row = 0;
+        float err = 0.0f;
+        if (mine) {
+            const int i = vals_sorted[jj];
+            err = s_err[i];
+            src_row = other[i];
+        }
+        const int cnt = __popcll(__ballot(mine)); // samples of row k are contiguous: lanes 0..cnt-1
+        int t = 0;
+        for (; t + U <= cnt; t += U) { // full groups: U source rows in flight, no branches
+            float v[U][NR], e[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const float *src = src_mat + (size_t)__shfl(src_row, t + u) * dim;
+                e[u] = __shfl(err, t + u);
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    int d = lane + 64 * r;
+                    v[u][r] = d < dim ? src[d] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int r = 0; r < NR; r++)
+                    acc[r] = fmaf(e[u], v[u][r], acc[r]);
+        }
+        for (; t < cnt; t++) {
+            const float *src = src_mat + (size_t)__shfl(src_row, t) * dim;
+            const float e1 = __shfl(err, t);
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                int d = lane + 64 * r;
+                if (d < dim)
+                    acc[r] = fmaf(e1, src[d], acc[r]);
+            }
+        }
+        if (cnt < 64)
+            break;
+        j += 64;
+    }
+    float *out = dst_out + (size_t)k * dim;
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        int d = lane + 64 * r;
+        if (d < dim)
+            out[d] = acc[r];
+    }
+}
+
+// centre row: staged = row + Σ neu1e of the walk positions centred on it, in (walk, position) order
+template <int NR>
+__global__ void __launch_bounds__(64)
+    k_n2v_apply_centers(const int *keys_sorted, const int *vals_sorted, const int *seg_start, int n_pos, const float *p_neu,
+                        const float *dst_old, float *dst_out, int dim) {
+    const int k = blockIdx.x;
+    int j = seg_start[k];
+    if (j < 0)
+        return;
+    const int lane = threadIdx.x;
+    float acc[NR];
+    const float *row = dst_old + (size_t)k * dim;
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        int d = lane + 64 * r;
+        acc[r] = d < dim ? row[d] : 0.0f;
+    }
+    for (; j < n_pos && keys_sorted[j] == k; j++) {
+        const float *src = p_neu + (size_t)vals_sorted[j] * dim;
 #pragma unroll
         for (int r = 0; r < NR; r++) {
             int d = lane + 64 * r;
             if (d < dim)
-                acc[r] = fmaf(err, src[d], acc[r]);
+                acc[r] = __fadd_rn(acc[r], src[d]);
         }
     }
     float *out = dst_out + (size_t)k * dim;
@@ -279,14 +415,15 @@ struct mn_n2v_session {
     int device = 0;
     N2vArgs a;
     int B = 0, cap = 0, max_deg = 0, bits = 1;
-    size_t ns_max = 0, tmp_bytes = 0;
+    size_t ns_max = 0, np_max = 0, tmp_bytes = 0;
     // graph + model
     int *off = nullptr, *adj = nullptr, *neg = nullptr;
     float *syn0 = nullptr, *syn1 = nullptr, *sig = nullptr, *staged = nullptr;
     // batch scratch
     int *s_center = nullptr, *s_target = nullptr, *keys = nullptr, *vals = nullptr, *keys_s = nullptr, *vals_s = nullptr,
         *keys_c = nullptr, *seg = nullptr, *seg_c = nullptr, *nseg = nullptr, *nseg_c = nullptr;
-    float *s_err = nullptr;
+    float *s_err = nullptr, *p_neu = nullptr;
+    int *p_center = nullptr;
     double *cum = nullptr;
     void *tmp = nullptr;
     unsigned long long *pairs = nullptr;
@@ -295,14 +432,15 @@ struct mn_n2v_session {
         (void)hipFree(off); (void)hipFree(adj); (void)hipFree(neg); (void)hipFree(syn0); (void)hipFree(syn1); (void)hipFree(sig);
         (void)hipFree(staged); (void)hipFree(s_center); (void)hipFree(s_target); (void)hipFree(keys); (void)hipFree(vals);
         (void)hipFree(keys_s); (void)hipFree(vals_s); (void)hipFree(keys_c); (void)hipFree(seg); (void)hipFree(seg_c);
-        (void)hipFree(nseg); (void)hipFree(nseg_c); (void)hipFree(s_err); (void)hipFree(cum); (void)hipFree(tmp); (void)hipFree(pairs);
+        (void)hipFree(nseg); (void)hipFree(nseg_c); (void)hipFree(s_err); (void)hipFree(p_neu); (void)hipFree(p_center); (void)hipFree(cum); (void)hipFree(tmp); (void)hipFree(pairs);
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
     }
 };
 
 template <int NR>
-static int n2v_samples_t(mn_n2v_session *S, int epoch, int w, int lo, int hi, int *d_center, int *d_target, float *d_err) {
+static int n2v_samples_t(mn_n2v_session *S, int epoch, int w, int lo, int hi, int *d_center, int *d_target, float *d_err,
+                         int *d_pcenter, float *d_pneu) {
     N2vBatchArgs b;
     memset(&b, 0, sizeof(b));
     b.a = S->a;
@@ -311,6 +449,8 @@ static int n2v_samples_t(mn_n2v_session *S, int epoch, int w, int lo, int hi, in
     b.s_center = d_center;
     b.s_target = d_target;
     b.s_err = d_err;
+    b.p_center = d_pcenter;
+    b.p_neu = d_pneu;
     b.cum_scratch = S->cum;
     b.max_deg = S->max_deg;
     b.pairs_out = S->pairs;
@@ -325,28 +465,30 @@ static int n2v_samples_t(mn_n2v_session *S, int epoch, int w, int lo, int hi, in
 }
 
 template <int NR>
-static int n2v_apply_t(mn_n2v_session *S, const int *d_center, const int *d_target, const float *d_err, int64_t ns64) {
+static int n2v_apply_t(mn_n2v_session *S, const int *d_center, const int *d_target, const float *d_err, int64_t ns64,
+                       const int *d_pcenter, const float *d_pneu, int64_t np64) {
     const N2vArgs &a = S->a;
     const int N = a.n, dim = a.dim;
-    if (ns64 <= 0)
+    if (ns64 <= 0 || np64 <= 0)
         return 0;
-    if ((size_t)ns64 > S->ns_max) {
-        nset_err("mn_n2v_apply: %lld samples exceed the session capacity %zu", (long long)ns64, S->ns_max);
+    if ((size_t)ns64 > S->ns_max || (size_t)np64 > S->np_max) {
+        nset_err("mn_n2v_apply: %lld samples / %lld positions exceed the session capacity %zu / %zu", (long long)ns64,
+                 (long long)np64, S->ns_max, S->np_max);
         return -1;
     }
-    const int ns = (int)ns64;
-    const unsigned g256 = (unsigned)((ns + 255) / 256);
-    // centres: syn0[c] += Σ err · syn1neg_old[t]  → staged
-    hipLaunchKernelGGL(k_n2v_keys, dim3(g256), dim3(256), 0, nullptr, d_center, ns, N, S->keys, S->vals);
-    if (rocprim::radix_sort_pairs(S->tmp, S->tmp_bytes, S->keys, S->keys_c, S->vals, S->vals_s, (size_t)ns, 0, S->bits, nullptr) !=
+    const int ns = (int)ns64, np = (int)np64;
+    const unsigned g256 = (unsigned)((ns + 255) / 256), p256 = (unsigned)((np + 255) / 256);
+    // centres: syn0[c] + Σ neu1e(position)  → staged (targets below still read the old centres)
+    hipLaunchKernelGGL(k_n2v_keys, dim3(p256), dim3(256), 0, nullptr, d_pcenter, np, N, S->keys, S->vals);
+    if (rocprim::radix_sort_pairs(S->tmp, S->tmp_bytes, S->keys, S->keys_c, S->vals, S->vals_s, (size_t)np, 0, S->bits, nullptr) !=
         hipSuccess) {
         nset_err("rocprim::radix_sort_pairs failed");
         return -1;
     }
     NCHK(hipMemsetAsync(S->seg_c, 0xFF, (size_t)N * sizeof(int), nullptr));
-    hipLaunchKernelGGL(k_n2v_segments, dim3(g256), dim3(256), 0, nullptr, S->keys_c, ns, N, S->seg_c);
-    hipLaunchKernelGGL((k_n2v_apply<NR>), dim3(N), dim3(64), 0, nullptr, S->keys_c, S->vals_s, S->seg_c, ns, d_target, d_err,
-                       a.syn0, a.syn1neg, S->staged, dim);
+    hipLaunchKernelGGL(k_n2v_segments, dim3(p256), dim3(256), 0, nullptr, S->keys_c, np, N, S->seg_c);
+    hipLaunchKernelGGL((k_n2v_apply_centers<NR>), dim3(N), dim3(64), 0, nullptr, S->keys_c, S->vals_s, S->seg_c, np, d_pneu, a.syn0,
+                       S->staged, dim);
     // targets: syn1neg[t] += Σ err · syn0_old[c]  (syn0 is still the old one) → in place
     hipLaunchKernelGGL(k_n2v_keys, dim3(g256), dim3(256), 0, nullptr, d_target, ns, N, S->keys, S->vals);
     if (rocprim::radix_sort_pairs(S->tmp, S->tmp_bytes, S->keys, S->keys_s, S->vals, S->vals_s, (size_t)ns, 0, S->bits, nullptr) !=
@@ -373,9 +515,10 @@ static int n2v_apply_t(mn_n2v_session *S, const int *d_center, const int *d_targ
         return fn<16>(__VA_ARGS__);                                   \
     } while (0)
 
-static int n2v_samples(mn_n2v_session *S, int epoch, int w, int lo, int hi, int *c, int *t, float *e) {
-    N2V_DISPATCH(n2v_samples_t, S, epoch, w, lo, hi, c, t, e);
+static int n2v_samples(mn_n2v_session *S, int epoch, int w, int lo, int hi, int *c, int *t, float *e, int *pc, float *pn) {
+    N2V_DISPATCH(n2v_samples_t, S, epoch, w, lo, hi, c, t, e, pc, pn);
 }
-static int n2v_apply(mn_n2v_session *S, const int *c, const int *t, const float *e, int64_t ns) {
-    N2V_DISPATCH(n2v_apply_t, S, c, t, e, ns);
+static int n2v_apply(mn_n2v_session *S, const int *c, const int *t, const float *e, int64_t ns, const int *pc, const float *pn,
+                     int64_t np) {
+    N2V_DISPATCH(n2v_apply_t, S, c, t, e, ns, pc, pn, np);
 }

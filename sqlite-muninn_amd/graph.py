@@ -37,8 +37,10 @@ GRAPH_SYMBOLS = [
     ("mn_n2v_begin", C.c_void_p, [C.c_int, _i32p, _i32p, C.POINTER(N2vParams), C.c_int]),
     ("mn_n2v_batch_walks", C.c_int, [C.c_void_p]),
     ("mn_n2v_sample_slots", C.c_int, [C.c_void_p]),
-    ("mn_n2v_samples", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    ("mn_n2v_apply", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    ("mn_n2v_position_slots", C.c_int, [C.c_void_p]),
+    ("mn_n2v_samples", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p]),
+    ("mn_n2v_apply", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64]),
     ("mn_n2v_sync", C.c_int, [C.c_void_p]),
     ("mn_n2v_finish", C.c_int, [C.c_void_p, np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS"), C.POINTER(N2vStats)]),
     ("mn_n2v_end", None, [C.c_void_p]),
@@ -116,3 +118,44 @@ def node2vec_train(off, adj, dim, p=1.0, q=1.0, num_walks=10, walk_length=80, wi
         m = L.mn_node2vec_last_error()
         raise MuninnHipError(m.decode() if m else "mn_node2vec_train failed")
     return out[:n], {"pairs": st.pairs, "device_ms": st.device_ms}
+
+
+# ───────────── host-side CSR builders (the device input formats; node ids are already indices) ─────────────
+
+def csr_pair_from_edges(n, src, dst, weights=None):
+    """GraphData.out / GraphData.in as CSR (src/graph_csr.c:20-70 over src/graph_load.c:218-246): out[src] lists dst
+    and in[dst] lists src, each in edge order.  → (off_out, tgt_out, w_out, off_in, tgt_in, w_in); weights None ⇒ None."""
+    src = np.asarray(src, np.int64)
+    dst = np.asarray(dst, np.int64)
+    w = None if weights is None else np.asarray(weights, np.float64)
+
+    def one(keys, vals):
+        o = np.argsort(keys, kind="stable")
+        off = np.zeros(n + 1, np.int64)
+        np.add.at(off, keys + 1, 1)
+        return np.cumsum(off).astype(np.int32), vals[o].astype(np.int32), None if w is None else w[o].copy()
+
+    return one(src, dst) + one(dst, src)
+
+
+def graph_from_edges(n, src, dst, weights=None, device=0):
+    """Graph (Leiden input) from an edge list with integer node indices."""
+    return Graph(n, *csr_pair_from_edges(n, src, dst, weights), device=device)
+
+
+def n2v_csr_from_edges(n, src, dst):
+    """node2vec.c's own adjacency (src/node2vec.c:96-134): undirected, duplicate edges dropped, every list in
+    insertion order (edge i adds src→dst, then dst→src).  → (off int32[n+1], adj int32[E])."""
+    src = np.asarray(src, np.int64)
+    dst = np.asarray(dst, np.int64)
+    a = np.empty(2 * len(src), np.int64)
+    b = np.empty(2 * len(src), np.int64)
+    a[0::2], a[1::2] = src, dst
+    b[0::2], b[1::2] = dst, src
+    _, first = np.unique(a * n + b, return_index=True)
+    first.sort()
+    a, b = a[first], b[first]
+    o = np.argsort(a, kind="stable")
+    off = np.zeros(n + 1, np.int64)
+    np.add.at(off, a + 1, 1)
+    return np.cumsum(off).astype(np.int32), b[o].astype(np.int32)

@@ -59,7 +59,7 @@ def node2vec_train_distributed(off, adj, dim, p=1.0, q=1.0, num_walks=10, walk_l
                                learning_rate=0.025, epochs=1, batch_walks=0, device=0, group=None):
     """Data-parallel Node2Vec (config 4): every rank holds a replica of syn0/syn1neg; the walks of each batch are
     split over the ranks (contiguous slices, rank order = walk order); each rank computes the (centre, target, err)
-    samples of its slice on its GPU, the samples are all-gathered (RCCL over xGMI with backend "nccl"; staged through
+    samples and the per-position neu1e vectors of its slice on its GPU, both are all-gathered (RCCL over xGMI with backend "nccl"; staged through
     the host with "gloo") and every rank applies the whole batch.  Because the gathered sample order equals the
     single-GPU order, the embeddings are bit-identical to mn_node2vec_train(..., MN_N2V_BATCHED) on one GPU.
     Returns (embeddings [n][dim] float32, stats)."""
@@ -80,13 +80,15 @@ def node2vec_train_distributed(off, adj, dim, p=1.0, q=1.0, num_walks=10, walk_l
     if not S:
         raise MuninnHipError((L.mn_node2vec_last_error() or b"").decode())
     try:
-        B, cap = L.mn_n2v_batch_walks(S), L.mn_n2v_sample_slots(S)
+        B, cap, pcap = L.mn_n2v_batch_walks(S), L.mn_n2v_sample_slots(S), L.mn_n2v_position_slots(S)
         dev = torch.device("cuda", device)
         host_staged = dist.get_backend(group) == "gloo"
         per_max = (B + world - 1) // world
         lc = torch.empty(per_max * cap, dtype=torch.int32, device=dev)
         lt = torch.empty(per_max * cap, dtype=torch.int32, device=dev)
         le = torch.empty(per_max * cap, dtype=torch.float32, device=dev)
+        lpc = torch.empty(per_max * pcap, dtype=torch.int32, device=dev)
+        lpn = torch.empty(per_max * pcap * dim, dtype=torch.float32, device=dev)
 
         def gather(x, cnt):
             if host_staged:
@@ -108,13 +110,17 @@ def node2vec_train_distributed(off, adj, dim, p=1.0, q=1.0, num_walks=10, walk_l
                     lc[:per * cap].fill_(-1)
                     lt[:per * cap].fill_(-1)
                     le[:per * cap].zero_()
+                    lpc[:per * pcap].fill_(-1)
                     torch.cuda.synchronize(dev)
-                    if hi > lo and L.mn_n2v_samples(S, epoch, w, lo, hi, lc.data_ptr(), lt.data_ptr(), le.data_ptr()) != 0:
+                    if hi > lo and L.mn_n2v_samples(S, epoch, w, lo, hi, lc.data_ptr(), lt.data_ptr(), le.data_ptr(),
+                                                    lpc.data_ptr(), lpn.data_ptr()) != 0:
                         raise MuninnHipError((L.mn_node2vec_last_error() or b"").decode())
                     L.mn_n2v_sync(S)
                     gc, gt, ge = gather(lc, per * cap), gather(lt, per * cap), gather(le, per * cap)
+                    gpc, gpn = gather(lpc, per * pcap), gather(lpn, per * pcap * dim)
                     torch.cuda.synchronize(dev)
-                    if L.mn_n2v_apply(S, gc.data_ptr(), gt.data_ptr(), ge.data_ptr(), world * per * cap) != 0:
+                    if L.mn_n2v_apply(S, gc.data_ptr(), gt.data_ptr(), ge.data_ptr(), world * per * cap,
+                                      gpc.data_ptr(), gpn.data_ptr(), world * per * pcap) != 0:
                         raise MuninnHipError((L.mn_node2vec_last_error() or b"").decode())
                     L.mn_n2v_sync(S)
         out = np.zeros((n, dim), np.float32)

@@ -46,3 +46,26 @@ def test_no_cpu_fallback_in_product_sources():
 def test_gfx950_code_object_present(mn):
     blob = open(mn.build(), "rb").read()
     assert b"gfx950" in blob
+
+
+def test_host_csr_builders_match_oracle_graph_builders(mn):
+    import numpy as np
+
+    """graph.py's numpy CSR builders (device input formats, §8 a22) against the oracle's restatements of
+    graph_data_load / node2vec.c's graph build, which tests/test_leiden.py and test_node2vec.py pin to the reference."""
+    from oracle import orc_graph as og
+
+    rng = np.random.default_rng(8)
+    n = 300
+    chain = np.arange(n - 1)
+    s = np.concatenate([chain, rng.integers(0, n, 2000)])  # the chain makes first-seen order == index order
+    d = np.concatenate([chain + 1, rng.integers(0, n, 2000)])  # duplicates and self loops included
+    w = rng.random(len(s))
+    off, adj = mn.graph.n2v_csr_from_edges(n, s, d)
+    g = og.N2vGraph(s, d)
+    assert g.n == n and np.array_equal(off, g.off) and np.array_equal(adj, g.adj)
+    got = mn.graph.csr_pair_from_edges(n, s, d, w)
+    c = og.Csr(s, d, w, "both")
+    for a, b in zip(got, (c.off_out, c.tgt_out, c.w_out, c.off_in, c.tgt_in, c.w_in)):
+        assert np.array_equal(a, b)
+    assert mn.graph.csr_pair_from_edges(n, s, d)[2] is None
