@@ -25,6 +25,7 @@
 struct N2vBatchArgs {
     N2vArgs a;
     int epoch, w, b0, b1;
+    int split; // wavefronts per walk
     double total_words;
     int cap; // sample slots per walk
     int *s_center, *s_target;
@@ -133,7 +134,7 @@ DEVI int gen_walk(const N2vArgs &a, int n, unsigned &rng, int *walk, double *cum
 // overwritten by the next sample or by the walk's -1 tail fill.
 template <int NR, int PF, bool FULL>
 DEVI void n2v_score_chunk(const N2vArgs &a, const N2vBatchArgs &b, unsigned &rng, int s0, int nd, int center, int context,
-                          const float (&vc)[NR], float (&neu)[NR], float lr, size_t base, int &ns, int lane) {
+                          const float (&vc)[NR], float (&neu)[NR], float lr, size_t base, int &ns, int lane, const float *sig) {
     const int dim = a.dim;
     int tg[PF];
     bool ok[PF];
@@ -173,7 +174,7 @@ DEVI void n2v_score_chunk(const N2vArgs &a, const N2vBatchArgs &b, unsigned &rng
             for (int m = 32; m >= 1; m >>= 1)
                 acc = __fadd_rn(acc, __shfl_xor(acc, m));
             const float label = (i == 0 && s0 == 0) ? 1.0f : 0.0f;
-            const float err = __fmul_rn(__fsub_rn(label, fast_sigmoid(a.sig_table, acc)), lr);
+            const float err = __fmul_rn(__fsub_rn(label, fast_sigmoid(sig, acc)), lr);
             if (lane == 0) {
                 b.s_center[base + ns] = center;
                 b.s_target[base + ns] = tg[i];
@@ -191,11 +192,18 @@ __global__ void __launch_bounds__(64) k_n2v_walk_grad(N2vBatchArgs b) {
     extern __shared__ __align__(16) unsigned char smem[];
     const N2vArgs &a = b.a;
     const int lane = threadIdx.x;
-    const int n = b.b0 + blockIdx.x;
+    // `split` wavefronts share one walk: each regenerates it (cheap) and owns a contiguous range of positions, with
+    // its own fixed range of sample slots, so the (walk, position, pair, sample) order of the output is unchanged
+    const int wi = blockIdx.x / b.split, part = blockIdx.x % b.split;
+    const int n = b.b0 + wi;
     if (n >= b.b1)
         return;
-    double *cum_l = reinterpret_cast<double *>(smem);
-    int *walk = reinterpret_cast<int *>(cum_l + N2VB_LDS_DEG);
+    const bool uniform = a.p == 1.0 && a.q == 1.0;
+    double *cum_l = reinterpret_cast<double *>(smem); // only the biased walk needs it
+    int *walk = reinterpret_cast<int *>(smem + (uniform ? 0 : N2VB_LDS_DEG * sizeof(double)));
+    float *sig_l = reinterpret_cast<float *>(walk + ((a.walk_length + 3) & ~3));
+    for (int i = lane; i <= N2V_SIG_SIZE; i += 64)
+        sig_l[i] = a.sig_table[i];
     double *cum_g = b.cum_scratch ? b.cum_scratch + (size_t)blockIdx.x * b.max_deg : nullptr;
     unsigned rng = n2v_walk_seed(b.epoch, b.w, n);
     const double wc = ((double)(b.epoch * a.num_walks + b.w) * a.n + n) * a.walk_length;
@@ -206,18 +214,36 @@ __global__ void __launch_bounds__(64) k_n2v_walk_grad(N2vBatchArgs b) {
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
     const int dim = a.dim;
-    const size_t base = (size_t)blockIdx.x * b.cap;
-    const size_t pbase = (size_t)blockIdx.x * a.walk_length;
+    const size_t base = (size_t)wi * b.cap;
+    const size_t pbase = (size_t)wi * a.walk_length;
+    const int p0 = (int)((long long)part * a.walk_length / b.split);
+    const int p1 = (int)((long long)(part + 1) * a.walk_length / b.split);
+    const int pe = p1 < wlen ? p1 : wlen; // positions [p0, pe) are this wavefront's
+    // pairs of the positions before p0 / before pe: every pair owns (1+neg) sample slots and consumes neg draws
+    int pairs_p0 = 0, pairs_pe = 0;
+    for (int pos = 0; pos < pe; pos++) {
+        int cs = pos - a.window, ce = pos + a.window;
+        if (cs < 0)
+            cs = 0;
+        if (ce >= wlen)
+            ce = wlen - 1;
+        if (pos < p0)
+            pairs_p0 += ce - cs;
+        pairs_pe += ce - cs;
+    }
+    for (int i = 0; i < pairs_p0 * a.neg; i++)
+        xs32(rng);
+    const int slot_end = part == b.split - 1 ? b.cap : pairs_pe * (1 + a.neg);
 #ifdef MN_N2V_PF // timing experiments only
     constexpr int PF = MN_N2V_PF;
 #else
-    // target rows in flight per wavefront.  Measured on MI355X (1M nodes, dim 128, device time of one pass):
-    // PF 1: 1.72 s, 2: 1.52 s, 3: 1.51 s, 4: 1.62 s, 6: 2.24 s
-    constexpr int PF = NR <= 4 ? 3 : 2;
+    // target rows in flight per wavefront.  Measured on MI355X (1M nodes, 20M edges, dim 128, neg 5: device time of one
+    // pass of 1M walks, everything else equal): PF 2: 1.37 s, 3: 1.34 s, 6: 1.28 s (one branch-free chunk per pair)
+    constexpr int PF = NR <= 4 ? 6 : 2;
 #endif
-    int ns = 0;
+    int ns = pairs_p0 * (1 + a.neg);
     unsigned long long pairs = 0;
-    for (int pos = 0; pos < wlen; pos++) {
+    for (int pos = p0; pos < pe; pos++) {
         const int center = walk[pos];
         int cs = pos - a.window, ce = pos + a.window;
         if (cs < 0)
@@ -240,9 +266,9 @@ __global__ void __launch_bounds__(64) k_n2v_walk_grad(N2vBatchArgs b) {
             for (int s0 = 0; s0 <= a.neg; s0 += PF) {
                 const int nd = a.neg + 1 - s0 < PF ? a.neg + 1 - s0 : PF;
                 if (nd == PF)
-                    n2v_score_chunk<NR, PF, true>(a, b, rng, s0, nd, center, context, vc, neu, lr, base, ns, lane);
+                    n2v_score_chunk<NR, PF, true>(a, b, rng, s0, nd, center, context, vc, neu, lr, base, ns, lane, sig_l);
                 else
-                    n2v_score_chunk<NR, PF, false>(a, b, rng, s0, nd, center, context, vc, neu, lr, base, ns, lane);
+                    n2v_score_chunk<NR, PF, false>(a, b, rng, s0, nd, center, context, vc, neu, lr, base, ns, lane, sig_l);
             }
         }
         if (lane == 0)
@@ -257,11 +283,11 @@ __global__ void __launch_bounds__(64) k_n2v_walk_grad(N2vBatchArgs b) {
         }
 #endif
     }
-    for (int i = ns + lane; i < b.cap; i += 64) {
+    for (int i = ns + lane; i < slot_end; i += 64) {
         b.s_center[base + i] = -1;
         b.s_target[base + i] = -1;
     }
-    for (int i = wlen + lane; i < a.walk_length; i += 64)
+    for (int i = (p0 > wlen ? p0 : wlen) + lane; i < p1; i += 64)
         b.p_center[pbase + i] = -1;
     if (lane == 0)
         atomicAdd(b.pairs_out, pairs);
@@ -458,8 +484,17 @@ static int n2v_samples_t(mn_n2v_session *S, int epoch, int w, int lo, int hi, in
     b.w = w;
     b.b0 = lo;
     b.b1 = hi;
-    const size_t lds = N2VB_LDS_DEG * sizeof(double) + (size_t)S->a.walk_length * sizeof(int) + 64;
-    hipLaunchKernelGGL((k_n2v_walk_grad<NR>), dim3(hi - lo), dim3(64), lds, nullptr, b);
+    const bool uniform = S->a.p == 1.0 && S->a.q == 1.0;
+    // enough wavefronts for several full rounds of the chip (8192 resident); the biased walk is too dear to repeat
+    int split = uniform ? (32768 + (hi - lo) - 1) / (hi - lo) : 1;
+    split = std::max(1, std::min(split, std::min(8, S->a.walk_length)));
+#ifdef MN_N2V_NO_SPLIT // timing experiments only
+    split = 1;
+#endif
+    b.split = split;
+    const size_t lds = (uniform ? 0 : N2VB_LDS_DEG * sizeof(double)) + (size_t)((S->a.walk_length + 3) & ~3) * sizeof(int) +
+                       (N2V_SIG_SIZE + 1) * sizeof(float) + 64;
+    hipLaunchKernelGGL((k_n2v_walk_grad<NR>), dim3((unsigned)(hi - lo) * split), dim3(64), lds, nullptr, b);
     NCHK(hipGetLastError());
     return 0;
 }
