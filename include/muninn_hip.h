@@ -174,8 +174,8 @@ typedef struct {
     double device_ms;
 } mn_leiden_stats;
 /* run_leiden (src/graph_community.c:336-429).  use_both = (direction == "both").  community_out[n_nodes] is
- * renumbered 0..K-1 in first-seen order; *modularity_out = Q.  batch: nodes per parallel round (BATCHED; <=1 → N/(2·avg degree)
- * clamped to [256, 65536]).
+ * renumbered 0..K-1 in first-seen order; *modularity_out = Q.  batch: nodes per parallel round (BATCHED; <=1 → N/16
+ * clamped to [256, 32768]).
  * Returns 0 / -1. */
 int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int mode, int batch, int *community_out,
                     double *modularity_out);

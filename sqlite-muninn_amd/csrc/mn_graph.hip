@@ -602,10 +602,10 @@ extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int
     if (N == 0)
         return 0;
     if (mode == MN_LEIDEN_BATCHED && batch <= 1) {
-        // few in-batch neighbours per node keeps the rounds close to the sequential sweep: ~N / (2·avg degree)
-        long long avg = N ? (g->e_out + (use_both ? g->e_in : 0)) / N : 1;
-        long long bsz = N / std::max<long long>(8, 2 * avg);
-        batch = (int)std::min<long long>(65536, std::max<long long>(256, bsz));
+        // A round costs about the same wall time up to a few full waves of the chip (8192 resident wavefronts), and
+        // larger rounds need more sweeps.  Measured on the cfg5 graph (N = 500k, <k> = 37): round size 6 250 → 205 ms,
+        // 12 500 → 124 ms, 25 000 → 107 ms, 50 000 → 121 ms, 100 000 → 170 ms, modularity 0.668–0.674 throughout.
+        batch = (int)std::min<long long>(32768, std::max<long long>(256, N / 16));
     }
     hipStream_t st = g->stream;
     DevGraph dg = {N, g->off_out, g->tgt_out, g->w_out, g->off_in, g->tgt_in, g->w_in};

@@ -333,8 +333,7 @@ def test_graph_leiden_sql_fast_mode_matches_oracle_schedule(conn, gpu, monkeypat
     monkeypatch.setenv("MUNINN_GRAPH_MODE", "fast")
     rows = conn.execute("SELECT node, community_id, modularity FROM graph_leiden WHERE edge_table='gf' AND src_col='src' AND dst_col='dst'").fetchall()
     csr = og.Csr(s, d, None, "both")
-    avg = (len(csr.tgt_out) + len(csr.tgt_in)) // csr.n
-    batch = min(65536, max(256, csr.n // max(8, 2 * avg)))
+    batch = min(32768, max(256, csr.n // 16))  # the device's default round size
     oc, oq, _ = og.leiden(csr, res, batch)
     assert np.array_equal(np.array([r[1] for r in rows], np.int32), oc)
     assert rows[0][2] == oq
