@@ -161,6 +161,21 @@ typedef struct mn_graph mn_graph; /* device-resident adjacency: GraphData.out / 
 /* Per-node edge order must be the adjacency-list order (edge-table row order).  weights NULL = 1.0. */
 mn_graph *mn_graph_create(int n_nodes, const int *off_out, const int *tgt_out, const double *w_out, const int *off_in,
                           const int *tgt_in, const double *w_in, int device);
+/* The same graph from the reference's stored form: the rows of graph_adjacency's shadow tables
+ * "{t}_csr_fwd" / "{t}_csr_rev" (src/graph_adjacency.c:182-197), one mn_csr_block per row in block_id order.  A block
+ * holds offsets int32[nodes_in_block + 1] rebased to 0, targets int32[edges] as GLOBAL node indices, weights f64[edges]
+ * or nothing (src/graph_csr.c:335-400).  Blocks are uploaded to their place in the device arrays directly — the
+ * reference's deserialize → merge → GraphData adjacency-list round trip (src/graph_adjacency.c:1458-1530) has no
+ * counterpart.  A single monolithic row (block_size 0) is one block. */
+typedef struct {
+    const void *offsets;
+    int offsets_bytes;
+    const void *targets;
+    int targets_bytes;
+    const void *weights; /* NULL / 0 bytes when unweighted */
+    int weights_bytes;
+} mn_csr_block;
+mn_graph *mn_graph_create_blocked(int n_nodes, const mn_csr_block *fwd, int n_fwd, const mn_csr_block *rev, int n_rev, int device);
 void mn_graph_destroy(mn_graph *g);
 const char *mn_graph_last_error(void);
 

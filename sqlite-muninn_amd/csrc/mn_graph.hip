@@ -437,6 +437,116 @@ extern "C" mn_graph *mn_graph_create(int n_nodes, const int *off_out, const int 
     return g;
 }
 
+// One direction of a blocked CSR (the rows of "{t}_csr_fwd" / "{t}_csr_rev") straight into device buffers: per
+// block, node count = offsets_bytes/4 - 1 and edge count = targets_bytes/4 (csr_deserialize, src/graph_csr.c:122-163);
+// offsets are rebased by the running edge count, targets are already global (csr_merge_blocks, :402-477).
+static int upload_blocks(const mn_csr_block *blk, int nb, int n_nodes, std::vector<int> &off, int **d_tgt, double **d_w,
+                         long long *n_edges, bool *weighted) {
+    off.assign((size_t)n_nodes + 1, 0);
+    long long edges = 0;
+    for (int b = 0; b < nb; b++) {
+        if (!blk[b].offsets || blk[b].offsets_bytes < 4 || blk[b].targets_bytes < 0 || blk[b].targets_bytes % 4) {
+            gset_err("mn_graph_create_blocked: block %d is malformed", b);
+            return -1;
+        }
+        edges += blk[b].targets_bytes / 4;
+    }
+    if (edges > 0x7fffffffLL) {
+        gset_err("mn_graph_create_blocked: %lld edges exceed int32 offsets", edges);
+        return -1;
+    }
+    *weighted = nb > 0 && blk[0].weights != nullptr && blk[0].weights_bytes > 0; // has_weights of the first block (:415)
+    *d_tgt = nullptr;
+    *d_w = nullptr;
+    GCHK(hipMalloc(d_tgt, (size_t)std::max<long long>(1, edges) * sizeof(int)));
+    if (*weighted)
+        GCHK(hipMalloc(d_w, (size_t)std::max<long long>(1, edges) * sizeof(double)));
+    long long eoff = 0;
+    int noff = 0;
+    for (int b = 0; b < nb; b++) {
+        const int bn = blk[b].offsets_bytes / 4 - 1, be = blk[b].targets_bytes / 4;
+        const int *bo = static_cast<const int *>(blk[b].offsets);
+        for (int i = 0; i < bn && noff + i < n_nodes; i++) {
+            if (bo[i] < 0 || bo[i] > be) {
+                gset_err("mn_graph_create_blocked: block %d offsets out of range", b);
+                return -1;
+            }
+            off[(size_t)noff + i] = (int)(bo[i] + eoff);
+        }
+        if (be > 0 && blk[b].targets)
+            GCHK(hipMemcpy(*d_tgt + eoff, blk[b].targets, (size_t)be * sizeof(int), hipMemcpyHostToDevice));
+        if (*weighted && be > 0) {
+            if (!blk[b].weights || blk[b].weights_bytes != be * 8) {
+                gset_err("mn_graph_create_blocked: block %d weights do not match its targets", b);
+                return -1;
+            }
+            GCHK(hipMemcpy(*d_w + eoff, blk[b].weights, (size_t)be * sizeof(double), hipMemcpyHostToDevice));
+        }
+        eoff += be;
+        noff += bn;
+    }
+    for (int i = std::min(noff, n_nodes); i <= n_nodes; i++) // sentinel, and nodes the blocks did not cover (:470-475)
+        off[(size_t)i] = (int)eoff;
+    *n_edges = eoff;
+    return 0;
+}
+
+extern "C" mn_graph *mn_graph_create_blocked(int n_nodes, const mn_csr_block *fwd, int n_fwd, const mn_csr_block *rev, int n_rev,
+                                             int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        gset_err("mn_graph_create_blocked: HIP device %d not available (no CPU fallback)", device);
+        return nullptr;
+    }
+    if (n_nodes < 0 || n_fwd < 0 || n_rev < 0 || (n_fwd && !fwd) || (n_rev && !rev)) {
+        gset_err("mn_graph_create_blocked: bad arguments");
+        return nullptr;
+    }
+    mn_graph *g = new mn_graph();
+    g->device = device;
+    g->n = n_nodes;
+    std::vector<int> oo, oi;
+    bool wo = false, wi = false;
+    bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreate(&g->ev0) == hipSuccess && hipEventCreate(&g->ev1) == hipSuccess;
+    ok = ok && upload_blocks(fwd, n_fwd, n_nodes, oo, &g->tgt_out, &g->w_out, &g->e_out, &wo) == 0 &&
+         upload_blocks(rev, n_rev, n_nodes, oi, &g->tgt_in, &g->w_in, &g->e_in, &wi) == 0;
+    if (ok) {
+        // out-of-range targets would fault in the kernels: the rows come from a file, so look before launching
+        std::vector<int> chk;
+        for (int dir = 0; dir < 2 && ok; dir++) {
+            const long long ne = dir ? g->e_in : g->e_out;
+            chk.resize((size_t)ne);
+            if (ne)
+                ok = hipMemcpy(chk.data(), dir ? g->tgt_in : g->tgt_out, (size_t)ne * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+            for (long long e = 0; e < ne && ok; e++)
+                if (chk[(size_t)e] < 0 || chk[(size_t)e] >= n_nodes) {
+                    gset_err("mn_graph_create_blocked: target %d out of range", chk[(size_t)e]);
+                    ok = false;
+                }
+        }
+    }
+    if (ok) {
+        g->weighted = wo || wi;
+        for (int v = 0; v < n_nodes; v++) {
+            int dO = oo[v + 1] - oo[v], dI = oi[v + 1] - oi[v];
+            if (dO < 0 || dI < 0) {
+                gset_err("mn_graph_create_blocked: offsets are not monotone at node %d", v);
+                ok = false;
+                break;
+            }
+            if (dO > g->max_deg_out) g->max_deg_out = dO;
+            if (dO + dI > g->max_deg_both) g->max_deg_both = dO + dI;
+        }
+    }
+    ok = ok && up(&g->off_out, oo.data(), (size_t)n_nodes + 1) == 0 && up(&g->off_in, oi.data(), (size_t)n_nodes + 1) == 0;
+    if (!ok) {
+        mn_graph_destroy(g);
+        return nullptr;
+    }
+    return g;
+}
+
 extern "C" void mn_graph_destroy(mn_graph *g) {
     if (!g)
         return;

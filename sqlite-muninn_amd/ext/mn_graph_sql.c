@@ -382,6 +382,145 @@ static const char *safe_text(sqlite3_value *v) {
     return v && sqlite3_value_type(v) != SQLITE_NULL ? (const char *)sqlite3_value_text(v) : 0;
 }
 
+/* ── a graph_adjacency table as edge_table (src/graph_community.c:577-581) ──
+ * The reference recognises one by the 'edge_table' key in "{t}_config" (is_graph_adjacency,
+ * src/graph_adjacency.c:1414-1424).  If its delta log is empty the stored CSR is current and is used as is
+ * (:1571-1572): node ids from "{t}_nodes" in idx order and the "{t}_csr_fwd" / "{t}_csr_rev" block rows go
+ * straight to the device (mn_graph_create_blocked); otherwise the original edge table named in the config is
+ * read with direction 'both' (:1536-1569).  Only shadow tables are read, so the graph_adjacency module itself
+ * does not have to be registered. */
+static char *adj_cfg(sqlite3 *db, const char *t, const char *key) {
+    char *sql = sqlite3_mprintf("SELECT value FROM \"%w_config\" WHERE key=%Q", t, key);
+    sqlite3_stmt *st = 0;
+    char *out = 0;
+    if (sqlite3_prepare_v2(db, sql, -1, &st, 0) == SQLITE_OK && sqlite3_step(st) == SQLITE_ROW && sqlite3_column_text(st, 0))
+        out = sqlite3_mprintf("%s", (const char *)sqlite3_column_text(st, 0));
+    sqlite3_finalize(st);
+    sqlite3_free(sql);
+    return out;
+}
+
+static long long adj_delta_count(sqlite3 *db, const char *t) {
+    char *sql = sqlite3_mprintf("SELECT COUNT(*) FROM \"%w_delta\"", t);
+    sqlite3_stmt *st = 0;
+    long long n = 0;
+    if (sqlite3_prepare_v2(db, sql, -1, &st, 0) == SQLITE_OK && sqlite3_step(st) == SQLITE_ROW)
+        n = sqlite3_column_int64(st, 0);
+    sqlite3_finalize(st);
+    sqlite3_free(sql);
+    return n;
+}
+
+/* all rows of one CSR shadow table, block_id order; blobs are copied because they must outlive the statement */
+static int adj_read_blocks(sqlite3 *db, const char *t, const char *suffix, mn_csr_block **out, int *n_out) {
+    char *sql = sqlite3_mprintf("SELECT offsets, targets, weights FROM \"%w%s\" ORDER BY block_id", t, suffix);
+    sqlite3_stmt *st = 0;
+    int rc = sqlite3_prepare_v2(db, sql, -1, &st, 0);
+    sqlite3_free(sql);
+    *out = 0;
+    *n_out = 0;
+    if (rc != SQLITE_OK)
+        return rc;
+    int cap = 0;
+    while (sqlite3_step(st) == SQLITE_ROW) {
+        if (*n_out == cap) {
+            cap = cap ? cap * 2 : 16;
+            *out = (mn_csr_block *)realloc(*out, (size_t)cap * sizeof(mn_csr_block));
+        }
+        mn_csr_block *b = &(*out)[(*n_out)++];
+        memset(b, 0, sizeof(*b));
+        for (int col = 0; col < 3; col++) {
+            int bytes = sqlite3_column_bytes(st, col);
+            const void *src = sqlite3_column_blob(st, col);
+            void *copy = 0;
+            if (src && bytes > 0) {
+                copy = malloc((size_t)bytes);
+                memcpy(copy, src, (size_t)bytes);
+            } else {
+                bytes = 0;
+            }
+            if (col == 0) { b->offsets = copy; b->offsets_bytes = bytes; }
+            else if (col == 1) { b->targets = copy; b->targets_bytes = bytes; }
+            else { b->weights = copy; b->weights_bytes = bytes; }
+        }
+    }
+    sqlite3_finalize(st);
+    return SQLITE_OK;
+}
+
+static void adj_free_blocks(mn_csr_block *b, int n) {
+    for (int i = 0; i < n; i++) {
+        free((void *)b[i].offsets);
+        free((void *)b[i].targets);
+        free((void *)b[i].weights);
+    }
+    free(b);
+}
+
+/* the stored CSR of a fresh graph_adjacency table → device graph + node ids; *ids_out owns malloc'd strings */
+static mn_graph *adj_load_fresh(sqlite3 *db, const char *t, char ***ids_out, int *n_out, char **err) {
+    char *sql = sqlite3_mprintf("SELECT id FROM \"%w_nodes\" ORDER BY idx", t);
+    sqlite3_stmt *st = 0;
+    int rc = sqlite3_prepare_v2(db, sql, -1, &st, 0);
+    sqlite3_free(sql);
+    if (rc != SQLITE_OK) {
+        *err = sqlite3_mprintf("failed to load nodes");
+        return 0;
+    }
+    char **ids = 0;
+    int n = 0, cap = 0;
+    while (sqlite3_step(st) == SQLITE_ROW) {
+        const char *id = (const char *)sqlite3_column_text(st, 0);
+        if (!id)
+            continue;
+        if (n == cap) {
+            cap = cap ? cap * 2 : 256;
+            ids = (char **)realloc(ids, (size_t)cap * sizeof(char *));
+        }
+        size_t len = strlen(id) + 1;
+        ids[n] = (char *)malloc(len);
+        memcpy(ids[n++], id, len);
+    }
+    sqlite3_finalize(st);
+    *ids_out = ids;
+    *n_out = n;
+    if (n == 0)
+        return 0; /* empty graph: no error */
+    mn_csr_block *fwd = 0, *rev = 0;
+    int nf = 0, nr = 0;
+    mn_graph *g = 0;
+    if (adj_read_blocks(db, t, "_csr_fwd", &fwd, &nf) != SQLITE_OK)
+        *err = sqlite3_mprintf("failed to load forward CSR");
+    else if (adj_read_blocks(db, t, "_csr_rev", &rev, &nr) != SQLITE_OK)
+        *err = sqlite3_mprintf("failed to load reverse CSR");
+    else if (!(g = mn_graph_create_blocked(n, fwd, nf, rev, nr, 0)))
+        *err = sqlite3_mprintf("graph_leiden: %s", mn_graph_last_error());
+    adj_free_blocks(fwd, nf);
+    adj_free_blocks(rev, nr);
+    return g;
+}
+
+/* run_leiden on a device graph and hand the result to the cursor (takes ownership of ids) */
+static int lei_run(LeiCursor *c, LeiVtab *vt, mn_graph *g, int n, char **ids, const char *direction, double resolution) {
+    c->community = (int *)malloc((size_t)n * sizeof(int));
+    int rc = mn_graph_leiden(g, resolution, !strcmp(direction, "both"),
+                             graph_mode_fast(n, 2000) ? MN_LEIDEN_BATCHED : MN_LEIDEN_SEQUENTIAL, 0, c->community, &c->Q);
+    mn_graph_destroy(g);
+    if (rc != 0) {
+        vt->base.zErrMsg = sqlite3_mprintf("graph_leiden: %s", mn_graph_last_error());
+        for (int i = 0; i < n; i++)
+            free(ids[i]);
+        free(ids);
+        free(c->community);
+        c->community = 0;
+        return SQLITE_ERROR;
+    }
+    c->node = ids;
+    c->n = n;
+    c->eof = 0;
+    return SQLITE_OK;
+}
+
 /* src/graph_community.c:516-610 + graph_data_load (src/graph_load.c:144-250) */
 static int lei_filter(sqlite3_vtab_cursor *cur, int idxNum, const char *idxStr, int argc, sqlite3_value **argv) {
     (void)idxStr;
@@ -426,6 +565,42 @@ static int lei_filter(sqlite3_vtab_cursor *cur, int idxNum, const char *idxStr, 
         vt->base.zErrMsg = sqlite3_mprintf("invalid timestamp column identifier");
         return SQLITE_ERROR;
     }
+    const char *load_dir = direction;
+    char *a_table = adj_cfg(vt->db, edge_table, "edge_table"), *a_src = 0, *a_dst = 0, *a_w = 0;
+    if (a_table) { /* edge_table names a graph_adjacency table */
+        if (adj_delta_count(vt->db, edge_table) == 0) {
+            sqlite3_free(a_table);
+            char **ids = 0, *err = 0;
+            int n = 0;
+            mn_graph *g = adj_load_fresh(vt->db, edge_table, &ids, &n, &err);
+            if (!g) {
+                for (int i = 0; i < n; i++)
+                    free(ids[i]);
+                free(ids);
+                if (err) {
+                    vt->base.zErrMsg = err;
+                    return SQLITE_ERROR;
+                }
+                return SQLITE_OK; /* empty graph */
+            }
+            return lei_run(c, vt, g, n, ids, direction, resolution);
+        }
+        /* stale: the original edge table, both directions, no time window (src/graph_adjacency.c:1536-1569) */
+        a_src = adj_cfg(vt->db, edge_table, "src_col");
+        a_dst = adj_cfg(vt->db, edge_table, "dst_col");
+        a_w = adj_cfg(vt->db, edge_table, "weight_col");
+        if (!a_src || !a_dst) {
+            vt->base.zErrMsg = sqlite3_mprintf("graph_adjacency '%s': missing config", edge_table);
+            sqlite3_free(a_table); sqlite3_free(a_src); sqlite3_free(a_dst); sqlite3_free(a_w);
+            return SQLITE_ERROR;
+        }
+        edge_table = a_table;
+        src_col = a_src;
+        dst_col = a_dst;
+        weight_col = a_w;
+        ts_col = 0;
+        load_dir = "both";
+    }
     char *sql;
     if (weight_col && ts_col)
         sql = sqlite3_mprintf("SELECT \"%w\", \"%w\", \"%w\" FROM \"%w\" WHERE (\"%w\" >= ?1 OR ?1 IS NULL) AND (\"%w\" <= ?2 OR ?2 IS NULL)",
@@ -440,6 +615,8 @@ static int lei_filter(sqlite3_vtab_cursor *cur, int idxNum, const char *idxStr, 
     sqlite3_stmt *st = 0;
     int rc = sqlite3_prepare_v2(vt->db, sql, -1, &st, 0);
     sqlite3_free(sql);
+    const int with_w = weight_col != 0;
+    sqlite3_free(a_table); sqlite3_free(a_src); sqlite3_free(a_dst); sqlite3_free(a_w); /* names are in the statement now */
     if (rc != SQLITE_OK) {
         vt->base.zErrMsg = sqlite3_mprintf("failed to prepare: %s", sqlite3_errmsg(vt->db));
         return SQLITE_ERROR;
@@ -449,9 +626,8 @@ static int lei_filter(sqlite3_vtab_cursor *cur, int idxNum, const char *idxStr, 
         if (t1) sqlite3_bind_value(st, 2, t1); else sqlite3_bind_null(st, 2);
     }
     int add_fwd = 1, add_rev = 1;
-    if (!strcmp(direction, "forward")) add_rev = 0;
-    else if (!strcmp(direction, "reverse")) add_fwd = 0;
-    const int with_w = weight_col != 0;
+    if (!strcmp(load_dir, "forward")) add_rev = 0;
+    else if (!strcmp(load_dir, "reverse")) add_fwd = 0;
     NodeMap nm;
     nm_init(&nm);
     EList *outl = 0, *inl = 0;
@@ -498,22 +674,8 @@ static int lei_filter(sqlite3_vtab_cursor *cur, int idxNum, const char *idxStr, 
         nm_free(&nm);
         return SQLITE_ERROR;
     }
-    c->community = (int *)malloc((size_t)n * sizeof(int));
-    rc = mn_graph_leiden(g, resolution, !strcmp(direction, "both"),
-                         graph_mode_fast(n, 2000) ? MN_LEIDEN_BATCHED : MN_LEIDEN_SEQUENTIAL, 0, c->community, &c->Q);
-    mn_graph_destroy(g);
-    if (rc != 0) {
-        vt->base.zErrMsg = sqlite3_mprintf("graph_leiden: %s", mn_graph_last_error());
-        nm_free(&nm);
-        free(c->community);
-        c->community = 0;
-        return SQLITE_ERROR;
-    }
-    c->node = nm.ids; /* ownership moves to the cursor */
-    c->n = n;
     free(nm.slots);
-    c->eof = 0;
-    return SQLITE_OK;
+    return lei_run(c, vt, g, n, nm.ids, direction, resolution); /* ownership of the ids moves to the cursor */
 }
 
 static int lei_next(sqlite3_vtab_cursor *cur) {

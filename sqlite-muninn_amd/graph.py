@@ -45,6 +45,7 @@ GRAPH_SYMBOLS = [
     ("mn_n2v_finish", C.c_int, [C.c_void_p, np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS"), C.POINTER(N2vStats)]),
     ("mn_n2v_end", None, [C.c_void_p]),
     ("mn_graph_create", C.c_void_p, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    ("mn_graph_create_blocked", C.c_void_p, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]),
     ("mn_graph_destroy", None, [C.c_void_p]),
     ("mn_graph_last_error", C.c_char_p, []),
     ("mn_graph_leiden", C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, _i32p, C.POINTER(C.c_double)]),
@@ -68,6 +69,11 @@ def _gerr():
     return m.decode() if m else ""
 
 
+class CsrBlock(C.Structure):
+    _fields_ = [("offsets", C.c_void_p), ("offsets_bytes", C.c_int), ("targets", C.c_void_p), ("targets_bytes", C.c_int),
+                ("weights", C.c_void_p), ("weights_bytes", C.c_int)]
+
+
 class Graph:
     """Device copy of GraphData.out / GraphData.in as CSR.  off/tgt int32, weights float64 or None."""
 
@@ -83,6 +89,32 @@ class Graph:
                                         device)
         if not self.h:
             raise MuninnHipError("mn_graph_create failed: " + _gerr())
+
+    @classmethod
+    def from_blocks(cls, n, fwd, rev, device=0):
+        """fwd / rev: lists of (offsets bytes, targets bytes, weights bytes | None) — the rows of the reference's
+        "{t}_csr_fwd" / "{t}_csr_rev" shadow tables in block_id order (mn_graph_create_blocked)."""
+        self = cls.__new__(cls)
+        self.L = _glib()
+        self.n = int(n)
+
+        def pack(rows):
+            arr = (CsrBlock * max(1, len(rows)))()
+            keep = []
+            for i, (o, t, w) in enumerate(rows):
+                bufs = [C.create_string_buffer(bytes(x), len(x)) if x else None for x in (o, t, w)]
+                keep.append(bufs)
+                arr[i] = CsrBlock(C.cast(bufs[0], C.c_void_p) if bufs[0] else None, len(o) if o else 0,
+                                  C.cast(bufs[1], C.c_void_p) if bufs[1] else None, len(t) if t else 0,
+                                  C.cast(bufs[2], C.c_void_p) if bufs[2] else None, len(w) if w else 0)
+            return arr, keep
+
+        fa, k1 = pack(fwd)
+        ra, k2 = pack(rev)
+        self.h = self.L.mn_graph_create_blocked(self.n, C.byref(fa), len(fwd), C.byref(ra), len(rev), device)
+        if not self.h:
+            raise MuninnHipError("mn_graph_create_blocked failed: " + _gerr())
+        return self
 
     def close(self):
         if getattr(self, "h", None):

@@ -426,3 +426,53 @@ def test_fast_mode_bulk_load_and_reopen(ext_built, gpu, tmp_path, monkeypatch):
     recall2 = np.mean([len(truth[i] & {r[0] for r in again[i]}) / 10 for i in range(len(Q))])
     assert abs(recall2 - recall) < 0.03
     c.close()
+
+
+# ───────────────────────── graph_adjacency's stored CSR as input ─────────────────────────
+
+def _gunzip_golden(name, tmp_path):
+    import gzip
+    import shutil
+
+    dst = str(tmp_path / name)
+    with gzip.open(os.path.join(ROOT, "tests", "golden", name + ".gz"), "rb") as fi, open(dst, "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    return dst
+
+
+@gpu_mark
+@pytest.mark.parametrize("state", ["fresh", "stale"])
+def test_graph_leiden_on_a_graph_adjacency_table_matches_reference(ext_built, gpu, tmp_path, monkeypatch, state):
+    """tests/golden/adjacency_{fresh,stale}.db were written by the REFERENCE's graph_adjacency vtab (two CSR blocks;
+    the stale one has 40 rows in its delta log).  graph_leiden pointed at that table must answer what the reference
+    answers: from the stored CSR blocks when fresh (uploaded as stored, mn_graph_create_blocked), from the original
+    edge table when stale (src/graph_adjacency.c:1532-1573).  oracle/gen_golden.py:adjacency_kats."""
+    monkeypatch.setenv("MUNINN_GRAPH_MODE", "exact")
+    z = np.load(os.path.join(ROOT, "tests", "golden", "adjacency.npz"))
+    c = sqlite3.connect(_gunzip_golden(f"adjacency_{state}.db", tmp_path))
+    c.enable_load_extension(True)
+    c.load_extension(ext_built)
+    rows = c.execute("SELECT node, community_id, modularity FROM graph_leiden WHERE edge_table='g' AND src_col='src' AND dst_col='dst'").fetchall()
+    assert [r[0] for r in rows] == z[f"{state}_nodes"].tolist()
+    assert np.array_equal(np.array([r[1] for r in rows], np.int32), z[f"{state}_comm"])
+    assert np.float64(rows[0][2]).view(np.int64) == z[f"{state}_q"][0]
+    c.close()
+
+
+@gpu_mark
+def test_graph_from_stored_blocks_equals_graph_from_edges(gpu, tmp_path):
+    """The C-ABI entry itself: blocks read from the reference-written file → same partition as the golden."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "adjacency.npz"))
+    c = sqlite3.connect(_gunzip_golden("adjacency_fresh.db", tmp_path))
+    n = c.execute("SELECT COUNT(*) FROM g_nodes").fetchone()[0]
+    fwd = c.execute("SELECT offsets, targets, weights FROM g_csr_fwd ORDER BY block_id").fetchall()
+    rev = c.execute("SELECT offsets, targets, weights FROM g_csr_rev ORDER BY block_id").fetchall()
+    c.close()
+    assert len(fwd) == int(z["n_blocks"][0]) >= 2
+    g = gpu.Graph.from_blocks(n, fwd, rev)
+    comm, q, _ = g.leiden(1.0, "both", gpu.LEIDEN_SEQUENTIAL)
+    g.close()
+    assert np.array_equal(comm, z["fresh_comm"]) and np.float64(q).view(np.int64) == z["fresh_q"][0]
+    with pytest.raises(Exception, match="out of range|malformed"):
+        bad = [(fwd[0][0], np.full(len(fwd[0][1]) // 4, n + 5, np.int32).tobytes(), fwd[0][2])] + list(fwd[1:])
+        gpu.Graph.from_blocks(n, bad, rev)
