@@ -127,7 +127,20 @@ struct WaveCtx {
     float qnorm;
     int *scratch;    // LDS, 64 ints
     unsigned long long n_dist, n_exp;
+    // speculative exact build (mn_spec.hip): every link row this search reads is logged, so that the commit
+    // step can tell whether an earlier insert of the same window rewrote one of them.  Level-0 rows are logged
+    // as the node's slot, upper rows as -(pool row) - 2.
+    int *rlog = nullptr;
+    int rcap = 0, nr = 0;
 };
+
+DEVI void log_row_read(const MnDevIndex &ix, WaveCtx &w, int node, int level, int lane) {
+    if (!w.rlog)
+        return;
+    if (lane == 0 && w.nr < w.rcap)
+        w.rlog[w.nr] = level == 0 ? node : -(ix.up_off[node] + level - 1) - 2;
+    w.nr++;
+}
 
 DEVI const int *link_row(const MnDevIndex &ix, int node, int level, int &W) {
     if (level == 0) {
@@ -156,6 +169,7 @@ DEVI int greedy_layer(const MnDevIndex &ix, WaveCtx &w, int entry, int level, in
             int W;
             const int *row = link_row(ix, cur, level, W);
             w.n_exp++;
+            log_row_read(ix, w, cur, level, lane);
             int nb = (lane < W) ? ld_link<COH>(row + lane) : -1;
             bool valid = lane >= i0 && nb >= 0 && !ix.deleted[nb >= 0 ? nb : 0];
             unsigned long long m = __ballot(valid);
@@ -228,6 +242,7 @@ DEVI void beam_layer(const MnDevIndex &ix, WaveCtx &w, WHeap &cand, WHeap &res, 
         int W;
         const int *row = link_row(ix, node, level, W);
         w.n_exp++;
+        log_row_read(ix, w, node, level, lane);
         int nb = (lane < W) ? ld_link<COH>(row + lane) : -1;
         bool todo = false;
         if (nb >= 0) { // :403-409 — mark visited first, then drop deleted

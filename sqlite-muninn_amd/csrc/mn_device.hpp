@@ -61,6 +61,10 @@ struct MnSearchArgs {
     int res_gcap;
     unsigned long long *counters; // [0] n_dist [1] n_expanded [2] overflowed queries
     int use_tile;                 // SSE order: stage candidate rows through the LDS tile (coalesced loads)
+    // build, speculative exact mode: per query the link rows its search read (mn_beam.hpp log_row_read)
+    int *readlog; // [nq][readcap] or null
+    int readcap;
+    int *nread;   // [nq] rows read (may exceed readcap)
 };
 
 // LDS budget per wavefront (items are 8 B: f32 distance bits, int32 slot)
@@ -104,6 +108,11 @@ void mn_launch_link(const MnDevIndex &ix, const MnLinkArgs &a, int max_tuples, h
 void mn_launch_insert_seq(const MnDevIndex &ix, const int *d_slots, int n, int ef, int *d_state, unsigned *bitmap0,
                           long long bm0_words, unsigned *bitmap_up, long long bmu_words, uint2 *cand_ovf, int cand_gcap,
                           uint2 *res_ovf, int res_gcap, unsigned long long *counters, hipStream_t st);
+
+// speculative exact inserts (mn_spec.hip): commit a window of searched inserts in order, stop at the first stale one
+void mn_launch_spec_commit(const MnDevIndex &ix, const int *d_slots, int W, int nlev, const int *sel, const int *nsel,
+                           const int *readlog, int readcap, const int *nread, int *stamp0, int *stampU, int epoch, int *d_ncommit,
+                           hipStream_t st);
 
 // rows[r] = (slot, level): writes the row's neighbour slots and dist(slot, neighbour) (mn_kernels.hip)
 void mn_launch_edge_rows(const MnDevIndex &ix, const int *d_row_slot, const int *d_row_level, int n_rows, int *d_out_nbr,

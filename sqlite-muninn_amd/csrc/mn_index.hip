@@ -106,6 +106,10 @@ struct mn_index {
     DevBuf<int> ws_state;
     DevBuf<int> er_slot, er_level, er_nbr;
     DevBuf<float> er_dist;
+    // speculative exact build: read logs of a window's searches, per-row rewrite epochs
+    DevBuf<int> ws_readlog, ws_nread, ws_ncommit, d_stamp0, d_stampU;
+    int spec_epoch = 0;
+    long long last_spec_searched = 0; // searches the last speculative build ran (≥ nodes inserted)
     mn_launch_stats last = {0, 0, 0, 0};
 };
 
@@ -440,6 +444,7 @@ extern "C" void mn_hnsw_destroy(mn_index *x) {
     x->lk_count.release(); x->lk_fill.release(); x->lk_binoff.release(); x->lk_touched.release(); x->lk_bins.release();
     x->lk_newrows.release(); x->ws_counters.release(); x->ws_state.release();
     x->er_slot.release(); x->er_level.release(); x->er_nbr.release(); x->er_dist.release();
+    x->ws_readlog.release(); x->ws_nread.release(); x->ws_ncommit.release(); x->d_stamp0.release(); x->d_stampU.release();
     if (x->ev0) (void)hipEventDestroy(x->ev0);
     if (x->ev1) (void)hipEventDestroy(x->ev1);
     if (x->stream) (void)hipStreamDestroy(x->stream);
@@ -609,14 +614,12 @@ extern "C" int mn_hnsw_search(mn_index *x, const float *query, int k, int ef, mn
 // ───────────────────────── insert ─────────────────────────
 
 // searched + linked against the graph frozen at call start; slots[] are already appended & uploaded
-static int run_batch(mn_index *x, const std::vector<int> &slots) {
+// search half of a group of inserts against the graph as it stands (k_beam<BUILD>): per node and layer the first
+// min(found, M_max) results → ws_sel / ws_nsel.  log_cap > 0 also records the link rows every search read.
+static int build_search(mn_index *x, const int *slots, int nq, MnSearchArgs &a, int log_cap) {
     hipStream_t st = x->stream;
-    const int nq = (int)slots.size();
-    if (nq == 0)
-        return 0;
     const int fz_max = x->max_level;
     const int nlev = fz_max + 1;
-    MnSearchArgs a;
     memset(&a, 0, sizeof(a));
     if (prepare_search_ws(x, nq, x->efc, a))
         return -1;
@@ -637,7 +640,7 @@ static int run_batch(mn_index *x, const std::vector<int> &slots) {
     if (x->ws_upidx.reserve((size_t)nq, false, st)) return -1;
     if (x->ws_sel.reserve((size_t)nq * nlev * x->M_max0, false, st)) return -1;
     if (x->ws_nsel.reserve((size_t)nq * nlev, false, st)) return -1;
-    HIPCHK(hipMemcpyAsync(x->ws_qslots.p, slots.data(), (size_t)nq * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(x->ws_qslots.p, slots, (size_t)nq * sizeof(int), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(x->ws_upidx.p, upidx.data(), (size_t)nq * sizeof(int), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(x->ws_nsel.p, 0, (size_t)nq * nlev * sizeof(int), st));
     a.query_slots = x->ws_qslots.p;
@@ -649,10 +652,30 @@ static int run_batch(mn_index *x, const std::vector<int> &slots) {
     a.sel = x->ws_sel.p;
     a.nsel = x->ws_nsel.p;
     a.nlev = nlev;
+    if (log_cap > 0) {
+        if (x->ws_readlog.reserve((size_t)nq * log_cap, false, st)) return -1;
+        if (x->ws_nread.reserve((size_t)nq, false, st)) return -1;
+        a.readlog = x->ws_readlog.p;
+        a.readcap = log_cap;
+        a.nread = x->ws_nread.p;
+    }
     MnDevIndex v = dev_view(x);
     HIPCHK(hipEventRecord(x->ev0, st));
     mn_launch_search(v, a, true, st);
     HIPCHK(hipEventRecord(x->ev1, st));
+    return 0;
+}
+
+static int run_batch(mn_index *x, const std::vector<int> &slots) {
+    hipStream_t st = x->stream;
+    const int nq = (int)slots.size();
+    if (nq == 0)
+        return 0;
+    const int nlev = x->max_level + 1;
+    MnSearchArgs a;
+    if (build_search(x, slots.data(), nq, a, 0))
+        return -1;
+    MnDevIndex v = dev_view(x);
     // link, layer by layer
     const int max_tuples = nq * x->M_max0;
     if (x->lk_target.reserve((size_t)max_tuples, false, st)) return -1;
@@ -745,6 +768,84 @@ static int run_sequential(mn_index *x, const std::vector<int> &slots) {
     return 0;
 }
 
+// The same inserts, same order, same graph as run_sequential — by speculation (mn_spec.hip): windows of consecutive
+// inserts are searched at once, then committed in order up to the first one whose search read a row that an earlier
+// insert of the window rewrote; the next window starts there.
+static int run_speculative(mn_index *x, const std::vector<int> &slots) {
+    hipStream_t st = x->stream;
+    const int n = (int)slots.size();
+    const int LOG_CAP = 2048;
+    if (x->d_stamp0.reserve((size_t)x->d_ids.cap, true, st, 0)) return -1;
+    if (x->d_stampU.reserve((size_t)std::max(1, x->n_pool_rows) + 1, true, st, 0)) return -1;
+    if (x->ws_ncommit.reserve(1, false, st)) return -1;
+    int window = 16, poor = 0;
+    long long searched = 0, rounds = 0, plain = 0;
+    for (int pos = 0; pos < n;) {
+        if (poor >= 8) {
+            // a small index: nearly every search crosses the previous insert's rows, so windows commit one insert at a
+            // time.  Run a stretch with the single-wavefront kernel, then try again (the index has grown meanwhile).
+            const int m = std::min(512, n - pos);
+            if (run_sequential(x, std::vector<int>(slots.begin() + pos, slots.begin() + pos + m)))
+                return -1;
+            pos += m;
+            plain += m;
+            poor = 4;
+            continue;
+        }
+        int W = std::min(window, n - pos);
+        // a node that raises the top layer becomes the entry point of everything after it (:660-663): it closes its window
+        for (int k = 0; k < W; k++)
+            if (x->levels[slots[pos + k]] > x->max_level) {
+                W = k + 1;
+                break;
+            }
+        MnSearchArgs a;
+        if (build_search(x, slots.data() + pos, W, a, LOG_CAP))
+            return -1;
+        if (++x->spec_epoch == 0x7fffffff) { // epochs are compared for equality only: restart them before they wrap
+            HIPCHK(hipMemsetAsync(x->d_stamp0.p, 0, x->d_stamp0.cap * sizeof(int), st));
+            HIPCHK(hipMemsetAsync(x->d_stampU.p, 0, x->d_stampU.cap * sizeof(int), st));
+            x->spec_epoch = 1;
+        }
+        MnDevIndex v = dev_view(x);
+        mn_launch_spec_commit(v, x->ws_qslots.p, W, a.nlev, x->ws_sel.p, x->ws_nsel.p, x->ws_readlog.p, LOG_CAP, x->ws_nread.p,
+                              x->d_stamp0.p, x->d_stampU.p, x->spec_epoch, x->ws_ncommit.p, st);
+        HIPCHK(hipGetLastError());
+        int done = 0;
+        HIPCHK(hipMemcpyAsync(&done, x->ws_ncommit.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        if (fetch_counters(x)) // synchronises
+            return -1;
+        if (x->last.last_n_overflow) {
+            set_err("mn_hnsw_insert: heap workspace exceeded");
+            return -1;
+        }
+        if (done < 1 || done > W) {
+            set_err("mn_hnsw_insert: speculative commit returned %d of %d", done, W);
+            return -1;
+        }
+        for (int k = 0; k < done; k++) { // entry point / top layer in insertion order (:660-663)
+            int lv = x->levels[slots[pos + k]];
+            if (lv > x->max_level) {
+                x->entry_id = x->ids[slots[pos + k]];
+                x->max_level = lv;
+            }
+        }
+        searched += W;
+        rounds++;
+        pos += done;
+        poor = done <= 1 && W > 1 ? poor + 1 : 0;
+        // A window's searches run side by side and a search is one latency-bound wavefront, so a wider window costs
+        // bandwidth, not time; searches beyond the committed prefix are simply repeated.  Keep it a few times the prefix.
+        window = done == W ? std::min(64, window * 2) : std::max(16, std::min(64, 3 * done));
+    }
+    x->host_links_valid = false;
+    x->last_spec_searched = searched;
+    if (getenv("MN_SPEC_TRACE"))
+        fprintf(stderr, "[mn_spec] %d inserts: %lld rounds (%.1f committed per round), %lld searches, %lld by k_insert_seq\n", n,
+                rounds, rounds ? (double)(n - plain) / rounds : 0.0, searched, plain);
+    return 0;
+}
+
 static int insert_impl(mn_index *x, const int64_t *ids, const float *vectors, int64_t n, int mode) {
     if (use_device(x))
         return -1;
@@ -788,8 +889,14 @@ static int insert_impl(mn_index *x, const int64_t *ids, const float *vectors, in
         pos = 1;
     }
     std::vector<int> rest(slots.begin() + pos, slots.end());
-    if (mode == MN_BUILD_SEQUENTIAL)
+    if (mode == MN_BUILD_SEQUENTIAL) {
+        // same result either way; speculation pays once several inserts are queued (MN_SPECULATE=0 turns it off)
+        const char *sp = getenv("MN_SPECULATE");
+        const bool spec_on = !(sp && atoi(sp) == 0);
+        if (spec_on && rest.size() >= 4)
+            return run_speculative(x, rest);
         return run_sequential(x, rest);
+    }
     return run_batch(x, rest);
 }
 

@@ -179,6 +179,10 @@ __global__ void __launch_bounds__(64) k_beam(MnDevIndex ix, MnSearchArgs a) {
     w.qnorm = 0.0f;
     if (ix.metric == 1)
         w.qnorm = BUILD ? ix.norms[qslot] : lds_self_norm<ORDER>(q, ix.dim, ix.ld, lane);
+    if (BUILD && a.readlog) {
+        w.rlog = a.readlog + (size_t)qi * a.readcap;
+        w.rcap = a.readcap;
+    }
 
     WHeap cand, res;
     cand.l = cand_l;
@@ -248,6 +252,8 @@ __global__ void __launch_bounds__(64) k_beam(MnDevIndex ix, MnSearchArgs a) {
         }
     }
     if (lane == 0) {
+        if (BUILD && a.readlog)
+            a.nread[qi] = w.nr; // > readcap: the log is incomplete and the commit step must not trust it
         atomicAdd(&a.counters[0], w.n_dist);
         atomicAdd(&a.counters[1], w.n_exp);
         if (cand.ovf || res.ovf)

@@ -35,9 +35,11 @@ template <bool COH> DEVI int prune_mutual(const MnDevIndex &ix, const int *list,
 // list[0..nc) → list[0..keep) = the kept neighbours in the reference's order. tq = the row owner's vector
 // (LDS), tnorm its cached |t|². nd/mn: LDS scratch of ≥ 128 entries each. COH: read neighbour rows with
 // agent-scope loads (the sequential kernel edits them in the same launch).
-template <int ORDER, int NCH, bool COH>
-DEVI void prune_row(const MnDevIndex &ix, const float *tq, float tnorm, int *list, float *nd, int *mn, int nc, int keep,
-                    int level, int lane) {
+// TIES = false: a distance tie (where the outcome depends on neighbours' rows) is not resolved; the list is left
+// untouched and 1 is returned, so that the caller can redo the step where those rows are stable.  Returns 0 otherwise.
+template <int ORDER, int NCH, bool COH, bool TIES = true>
+DEVI int prune_row(const MnDevIndex &ix, const float *tq, float tnorm, int *list, float *nd, int *mn, int nc, int keep,
+                   int level, int lane) {
     const bool has0 = lane < nc, has1 = lane + 64 < nc;
     const int s0 = has0 ? list[lane] : 0;
     const int s1 = has1 ? list[lane + 64] : 0;
@@ -75,8 +77,10 @@ DEVI void prune_row(const MnDevIndex &ix, const float *tq, float tnorm, int *lis
         if (has1 && r1 < keep)
             list[r1] = s1;
         __builtin_amdgcn_wave_barrier();
-        return;
+        return 0;
     }
+    if (!TIES)
+        return 1;
     // tie path: mutual-neighbour counts (:613-616), then the reference's selection sort verbatim (:620-639)
     for (int j = 0; j < nc; j++) {
         const int nn = list[j];
@@ -105,4 +109,5 @@ DEVI void prune_row(const MnDevIndex &ix, const float *tq, float tnorm, int *lis
         }
     }
     __builtin_amdgcn_wave_barrier();
+    return 0;
 }

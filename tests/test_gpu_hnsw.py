@@ -335,6 +335,26 @@ def test_reference_binary_searches_device_built_graph(gpu, orc):
     g.close()
 
 
+def test_speculative_exact_inserts_equal_the_single_wavefront_kernel(gpu, monkeypatch):
+    """mn_spec.hip: windows of inserts searched at once and committed in order up to the first stale one must leave
+    the graph k_insert_seq leaves (which the golden tests pin to the reference) — on an index large enough for windows
+    to commit several inserts, with duplicates so that the tie path of the parallel commit is exercised."""
+    n0, n1, dim, M, efc = 30000, 1500, 16, 8, 60
+    X = gauss(n0 + n1, dim, 71)
+    X[n0 + 100:n0 + 400] = X[np.random.default_rng(72).integers(0, n0, 300)]  # exact duplicates of indexed vectors
+    ids = np.arange(1, n0 + n1 + 1, dtype=np.int64)
+    graphs = []
+    for spec in ("0", "1"):
+        monkeypatch.setenv("MN_SPECULATE", spec)
+        g = gpu.HnswIndex(dim, "l2", M, efc)
+        assert g.build(ids[:n0], X[:n0], 16, 4096) == 0
+        assert g.insert_batch(ids[n0:], X[n0:], gpu.BUILD_SEQUENTIAL) == 0
+        graphs.append((g.export_links(0), g.export_links(1), g.entry_point, g.max_level))
+        g.close()
+    assert np.array_equal(graphs[0][0], graphs[1][0]) and np.array_equal(graphs[0][1], graphs[1][1])
+    assert graphs[0][2:] == graphs[1][2:]
+
+
 def test_m33_is_refused(gpu):
     with pytest.raises(Exception):
         gpu.HnswIndex(8, "l2", 33, 50)
