@@ -174,6 +174,7 @@ struct LeiArgs {
     double *dk;
     unsigned long long *Jq, *Lq; // fixed-point (2^20) tallies of the movers' degrees per community
     int apply_on_device;         // 0: weighted graph → the host applies winners in node order
+    int lds_cap;                 // k_leiden_eval: edges staged in LDS per node (multiple of 16, ≤ LEI_CAP)
 };
 
 #define LEI_FX 1048576.0
@@ -222,16 +223,19 @@ __global__ void __launch_bounds__(64) k_leiden_seq(LeiArgs a) {
     }
 }
 
+// LDS staging sized for the graph's largest node (a.lds_cap ≤ LEI_CAP edges, 13 B each) instead of LEI_CAP: with the
+// full 13 KB only 12 wavefronts fit a CU and the kernel, which is a chain of dependent gathers, starves.
 __global__ void __launch_bounds__(64) k_leiden_eval(LeiArgs a) {
-    __shared__ __align__(16) double lds_w[LEI_CAP];
-    __shared__ __align__(16) int lds_c[LEI_CAP];
-    __shared__ __align__(16) unsigned char lds_e[LEI_CAP];
+    extern __shared__ __align__(16) unsigned char lei_smem[];
+    double *lds_w = reinterpret_cast<double *>(lei_smem);
+    int *lds_c = reinterpret_cast<int *>(lds_w + a.lds_cap);
+    unsigned char *lds_e = reinterpret_cast<unsigned char *>(lds_c + a.lds_cap);
     const int v = a.b0 + blockIdx.x;
     if (v >= a.b1)
         return;
     double dk = 0.0;
     int best;
-    if (node_degree(a, v) <= LEI_CAP) {
+    if (node_degree(a, v) <= a.lds_cap) {
         best = best_move<false>(a.g, v, a.label, a.sum_tot, a.kdeg, a.m, a.resolution, a.use_both, a.elig_part, lds_c, lds_w,
                                 lds_e, threadIdx.x, &dk);
     } else {
@@ -639,7 +643,7 @@ static long long run_phase(mn_graph *g, LeiArgs a, int mode, int batch, int64_t 
             a.b1 = b + batch < g->n ? b + batch : g->n;
             const int nb = a.b1 - a.b0;
             GCHK(hipMemsetAsync(a.out + 1, 0, sizeof(int), st)); // safe winners of this round
-            hipLaunchKernelGGL(k_leiden_eval, dim3(nb), dim3(64), 0, st, a);
+            hipLaunchKernelGGL(k_leiden_eval, dim3(nb), dim3(64), (size_t)a.lds_cap * 13, st, a);
             hipLaunchKernelGGL(k_leiden_cmin, dim3((nb + 255) / 256), dim3(256), 0, st, a);
             hipLaunchKernelGGL(k_leiden_win, dim3((nb + 255) / 256), dim3(256), 0, st, a);
             ch_idx.clear();
@@ -788,6 +792,7 @@ extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int
     a.Jq = d.Jq;
     a.Lq = d.Lq;
     a.apply_on_device = g->weighted ? 0 : 1;
+    a.lds_cap = std::min(LEI_CAP, std::max(64, (max_deg + 15) & ~15));
     std::vector<double> r_sum_tot;
     HostState hs = {&community, &sum_tot, &k, d.sidx, d.sival, d.sdval};
 
