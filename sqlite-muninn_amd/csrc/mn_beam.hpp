@@ -121,6 +121,18 @@ DEVI uint2 heap_pop(WHeap &h, int lane) {
 
 // ───────────────────────── beam search ─────────────────────────
 
+// A query served by a workgroup of several wavefronts (k_beam_coop): wavefront 0 runs the search exactly as the
+// one-wavefront kernel does; whenever it needs the distances of a candidate list it posts the list here and every
+// wavefront of the group takes every nw-th candidate.  A row's distance is computed by one wavefront with the same
+// code either way, so the results are bit-identical; only the latency of the ≤ 64-row distance step shrinks.
+struct CoopCtx {
+    int *n;       // LDS [1]: candidates of the current request; < 0 = the search is over
+    int *list;    // LDS [64] candidate slots
+    float *dist;  // LDS [64] their distances
+    float *qnorm; // LDS [1]
+    int nw, wv;   // wavefronts in the group, this wavefront's index
+};
+
 struct WaveCtx {
     float *tile = nullptr; // LDS staging tile for the coalesced SSE-order loads (k_beam), or null
     const float *q;  // LDS query, zero padded to ld
@@ -132,6 +144,7 @@ struct WaveCtx {
     // as the node's slot, upper rows as -(pool row) - 2.
     int *rlog = nullptr;
     int rcap = 0, nr = 0;
+    CoopCtx *coop = nullptr;
 };
 
 DEVI void log_row_read(const MnDevIndex &ix, WaveCtx &w, int node, int level, int lane) {
@@ -140,6 +153,46 @@ DEVI void log_row_read(const MnDevIndex &ix, WaveCtx &w, int node, int level, in
     if (lane == 0 && w.nr < w.rcap)
         w.rlog[w.nr] = level == 0 ? node : -(ix.up_off[node] + level - 1) - 2;
     w.nr++;
+}
+
+// this wavefront's share of the posted candidate list: entries wv, wv+nw, wv+2nw, ...
+template <int ORDER, int NCH>
+DEVI void coop_share(const MnDevIndex &ix, const float *q, const CoopCtx &c, int n, int lane) {
+    const int cnt = n > c.wv ? (n - c.wv + c.nw - 1) / c.nw : 0;
+    if (cnt == 0)
+        return;
+    const int myslot = lane < cnt ? c.list[c.wv + lane * c.nw] : 0;
+    const float d = rows_distance<ORDER, NCH>(ix, q, *c.qnorm, myslot, cnt, lane);
+    if (lane < cnt)
+        c.dist[c.wv + lane * c.nw] = d;
+}
+
+// the helpers' whole life: wait for a request, do the share, repeat until the leader signals the end
+template <int ORDER, int NCH>
+DEVI void coop_helper(const MnDevIndex &ix, const float *q, const CoopCtx &c, int lane) {
+    for (;;) {
+        __syncthreads();
+        const int n = *c.n;
+        if (n < 0)
+            break;
+        coop_share<ORDER, NCH>(ix, q, c, n, lane);
+        __syncthreads();
+    }
+}
+
+template <int ORDER, int NCH>
+DEVI float ctx_distance(const MnDevIndex &ix, WaveCtx &w, int myslot, int n, int lane) {
+    if (!w.coop || n <= 2) // (helpers only reach a barrier when a request is posted)
+        return rows_distance<ORDER, NCH>(ix, w.q, w.qnorm, myslot, n, lane, w.tile);
+    const CoopCtx &c = *w.coop;
+    if (lane < n)
+        c.list[lane] = myslot;
+    if (lane == 0)
+        *c.n = n;
+    __syncthreads();
+    coop_share<ORDER, NCH>(ix, w.q, c, n, lane);
+    __syncthreads();
+    return lane < n ? c.dist[lane] : 0.0f;
 }
 
 DEVI const int *link_row(const MnDevIndex &ix, int node, int level, int &W) {
@@ -156,7 +209,7 @@ DEVI const int *link_row(const MnDevIndex &ix, int node, int level, int &W) {
 template <int ORDER, int NCH, bool COH = false>
 DEVI int greedy_layer(const MnDevIndex &ix, WaveCtx &w, int entry, int level, int lane) {
     int cur = entry;
-    float cur_d = rows_distance<ORDER, NCH>(ix, w.q, w.qnorm, cur, 1, lane, w.tile);
+    float cur_d = ctx_distance<ORDER, NCH>(ix, w, cur, 1, lane);
     cur_d = __shfl(cur_d, 0);
     w.n_dist += 1;
     int changed = 1;
@@ -182,7 +235,7 @@ DEVI int greedy_layer(const MnDevIndex &ix, WaveCtx &w, int entry, int level, in
                 w.scratch[rank] = nb;
             __builtin_amdgcn_wave_barrier();
             int myslot = lane < n ? w.scratch[lane] : 0;
-            float d = rows_distance<ORDER, NCH>(ix, w.q, w.qnorm, myslot, n, lane, w.tile);
+            float d = ctx_distance<ORDER, NCH>(ix, w, myslot, n, lane);
             w.n_dist += n;
             unsigned long long better = __ballot(lane < n && d < cur_d);
             if (!better)
@@ -212,7 +265,7 @@ DEVI void beam_layer(const MnDevIndex &ix, WaveCtx &w, WHeap &cand, WHeap &res, 
     cand.size = 0;
     res.size = 0;
     if (!ix.deleted[entry]) { // :360-366
-        float d = rows_distance<ORDER, NCH>(ix, w.q, w.qnorm, entry, 1, lane, w.tile);
+        float d = ctx_distance<ORDER, NCH>(ix, w, entry, 1, lane);
         d = __shfl(d, 0);
         w.n_dist += 1;
         heap_push(cand, entry, d, lane);
@@ -261,7 +314,7 @@ DEVI void beam_layer(const MnDevIndex &ix, WaveCtx &w, WHeap &cand, WHeap &res, 
                 w.scratch[rank] = nb;
             __builtin_amdgcn_wave_barrier();
             int myslot = lane < n ? w.scratch[lane] : 0;
-            float d = rows_distance<ORDER, NCH>(ix, w.q, w.qnorm, myslot, n, lane, w.tile);
+            float d = ctx_distance<ORDER, NCH>(ix, w, myslot, n, lane);
             w.n_dist += n;
             // :413-425, in list order.  Once the result set is full an element can only be accepted
             // if it beats the worst AT THAT MOMENT, which never exceeds the worst now: pre-filter.

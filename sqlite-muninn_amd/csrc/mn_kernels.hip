@@ -143,13 +143,10 @@ void mn_launch_dist_batch(int metric, int order, const float *d_query, const flo
 
 #include "mn_beam.hpp"
 
+// one query, one (leading) wavefront; `coop` = the group's shared area when helpers stand by (k_beam_coop)
 template <int ORDER, int NCH, bool BUILD>
-__global__ void __launch_bounds__(64) k_beam(MnDevIndex ix, MnSearchArgs a) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = threadIdx.x;
-    const long long qi = blockIdx.x;
-    if (qi >= a.nq)
-        return;
+DEVI void beam_query(const MnDevIndex &ix, const MnSearchArgs &a, const long long qi, const int lane, unsigned char *smem,
+                     CoopCtx *coop) {
     // LDS carve: cand heap | result heap | scratch | query
     uint2 *cand_l = reinterpret_cast<uint2 *>(smem);
     uint2 *res_l = cand_l + MN_CAND_LDS;
@@ -179,6 +176,11 @@ __global__ void __launch_bounds__(64) k_beam(MnDevIndex ix, MnSearchArgs a) {
     w.qnorm = 0.0f;
     if (ix.metric == 1)
         w.qnorm = BUILD ? ix.norms[qslot] : lds_self_norm<ORDER>(q, ix.dim, ix.ld, lane);
+    if (coop) {
+        w.coop = coop;
+        if (lane == 0)
+            *coop->qnorm = w.qnorm;
+    }
     if (BUILD && a.readlog) {
         w.rlog = a.readlog + (size_t)qi * a.readcap;
         w.rcap = a.readcap;
@@ -261,6 +263,40 @@ __global__ void __launch_bounds__(64) k_beam(MnDevIndex ix, MnSearchArgs a) {
     }
 }
 
+template <int ORDER, int NCH, bool BUILD>
+__global__ void __launch_bounds__(64) k_beam(MnDevIndex ix, MnSearchArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    if ((long long)blockIdx.x >= a.nq)
+        return;
+    beam_query<ORDER, NCH, BUILD>(ix, a, blockIdx.x, threadIdx.x, smem, nullptr);
+}
+
+// Few queries (a single xFilter, a window of speculative inserts): one WORKGROUP per query, see CoopCtx (mn_beam.hpp).
+#define MN_COOP_WAVES 8
+template <int ORDER, int NCH, bool BUILD>
+__global__ void __launch_bounds__(MN_COOP_WAVES * 64) k_beam_coop(MnDevIndex ix, MnSearchArgs a, size_t base_lds) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    if ((long long)blockIdx.x >= a.nq)
+        return;
+    const int lane = threadIdx.x & 63;
+    CoopCtx c;
+    c.n = reinterpret_cast<int *>(smem + base_lds);
+    c.qnorm = reinterpret_cast<float *>(c.n + 1);
+    c.list = c.n + 4;
+    c.dist = reinterpret_cast<float *>(c.list + 64);
+    c.nw = blockDim.x >> 6;
+    c.wv = threadIdx.x >> 6;
+    if (c.wv == 0) {
+        beam_query<ORDER, NCH, BUILD>(ix, a, blockIdx.x, lane, smem, &c);
+        if (lane == 0)
+            *c.n = -1;
+        __syncthreads(); // releases the helpers
+    } else {
+        const float *q = reinterpret_cast<const float *>(smem + (size_t)(MN_CAND_LDS + MN_RES_LDS) * sizeof(uint2) + 64 * sizeof(int));
+        coop_helper<ORDER, NCH>(ix, q, c, lane);
+    }
+}
+
 size_t mn_search_lds_bytes(int ld, bool tile) {
     size_t b = (size_t)(MN_CAND_LDS + MN_RES_LDS) * sizeof(uint2) + 64 * sizeof(int) + (size_t)ld * sizeof(float);
     if (tile)
@@ -275,6 +311,17 @@ template <int ORDER, int NCH>
 static void launch_beam(const MnDevIndex &ix, const MnSearchArgs &a, bool build, hipStream_t st) {
     dim3 grid((unsigned)a.nq), block(64);
     size_t lds = mn_search_lds_bytes(ix.ld, ORDER == MN_ORDER_SSE_V && a.use_tile);
+    const char *co = getenv("MN_COOP"); // MN_COOP=0: always one wavefront per query
+    if (a.nq <= 128 && !(co && atoi(co) == 0)) {
+        const size_t base = (lds + 15) & ~(size_t)15;
+        const size_t tot = base + (4 + 64 + 64) * sizeof(int);
+        dim3 cblock(MN_COOP_WAVES * 64);
+        if (build)
+            hipLaunchKernelGGL((k_beam_coop<ORDER, NCH, true>), grid, cblock, tot, st, ix, a, base);
+        else
+            hipLaunchKernelGGL((k_beam_coop<ORDER, NCH, false>), grid, cblock, tot, st, ix, a, base);
+        return;
+    }
     if (build)
         hipLaunchKernelGGL((k_beam<ORDER, NCH, true>), grid, block, lds, st, ix, a);
     else
