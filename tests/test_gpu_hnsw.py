@@ -355,6 +355,44 @@ def test_speculative_exact_inserts_equal_the_single_wavefront_kernel(gpu, monkey
     assert graphs[0][2:] == graphs[1][2:]
 
 
+def test_two_host_threads_two_indexes(gpu, orc):
+    """SURVEY §8b threading contract: one host thread per connection, several connections per process.  Each index has
+    its own HIP stream and the device is selected per call; two threads building and searching their own indexes at
+    the same time must get what they get alone (ctypes releases the GIL during the calls)."""
+    import threading
+
+    dim, n = 16, 2500
+    data = [(gauss(n, dim, 81 + t), gauss(40, dim, 91 + t)) for t in range(2)]
+    ids = np.arange(1, n + 1, dtype=np.int64)
+    want = []
+    for X, Q in data:
+        o = orc.Oracle(dim, "l2", 8, 60)
+        o.insert_many(ids, X)
+        want.append(o.search_many(Q, 5, 40))
+    got, errs = [None, None], []
+
+    def work(t):
+        try:
+            X, Q = data[t]
+            g = gpu.HnswIndex(dim, "l2", 8, 60)
+            for a in range(0, n, 500):  # exact inserts, several launches, interleaved with the other thread's
+                assert g.insert_batch(ids[a:a + 500], X[a:a + 500], gpu.BUILD_SEQUENTIAL) == 0
+                g.search_batch(Q, 5, 40)
+            got[t] = g.search_batch(Q, 5, 40)
+            g.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for t in range(2):
+        assert np.array_equal(got[t][0], want[t][0]) and same_bits(got[t][1], want[t][1])
+
+
 def test_m33_is_refused(gpu):
     with pytest.raises(Exception):
         gpu.HnswIndex(8, "l2", 33, 50)
