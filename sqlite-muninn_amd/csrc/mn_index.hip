@@ -887,6 +887,14 @@ static int insert_impl(mn_index *x, const int64_t *ids, const float *vectors, in
         x->entry_id = ids[0];
         x->max_level = x->levels[slots[0]];
         pos = 1;
+        // -1 is the reference's "no entry point" marker AND a legal rowid: after inserting rowid -1 into an empty index
+        // the reference still believes it is empty and the next insert becomes the entry point too, unlinked
+        // (one-at-a-time semantics only; found by scripts/fuzz_parity.py)
+        while (mode == MN_BUILD_SEQUENTIAL && x->entry_id == -1 && pos < (size_t)n) {
+            x->entry_id = ids[pos];
+            x->max_level = x->levels[slots[pos]];
+            pos++;
+        }
     }
     std::vector<int> rest(slots.begin() + pos, slots.end());
     if (mode == MN_BUILD_SEQUENTIAL) {
@@ -989,8 +997,10 @@ extern "C" int mn_hnsw_delete(mn_index *x, int64_t id) { // src/hnsw_algo.c:717-
         return -1;
     if (pull_links(x))
         return -1;
-    // dry run for overflow so a refused delete leaves the index untouched
-    std::vector<int> save0 = x->h_links0, saveu = x->h_links_up;
+    // a refused delete must leave the index untouched: journal every row before it is edited (only rows of the
+    // deleted node's neighbours are)
+    struct Saved { int *row; std::vector<int> old; };
+    std::vector<Saved> journal;
     x->deleted[s] = 1;
     x->node_count--;
     int min_conn = x->M / 2;
@@ -1000,6 +1010,12 @@ extern "C" int mn_hnsw_delete(mn_index *x, int64_t id) { // src/hnsw_algo.c:717-
         int *row = h_row(x, s, l, &W);
         int nc = h_row_count(row, W);
         std::vector<int> former(row, row + nc);
+        for (int i = 0; i < nc; i++)
+            if (l <= x->levels[former[i]]) {
+                int Wf;
+                int *fr = h_row(x, former[i], l, &Wf);
+                journal.push_back({fr, std::vector<int>(fr, fr + Wf)});
+            }
         for (int i = 0; i < nc; i++)
             if (!x->deleted[former[i]])
                 h_remove(x, former[i], l, s);
@@ -1033,8 +1049,8 @@ extern "C" int mn_hnsw_delete(mn_index *x, int64_t id) { // src/hnsw_algo.c:717-
         }
     }
     if (overflow) {
-        x->h_links0.swap(save0);
-        x->h_links_up.swap(saveu);
+        for (size_t i = journal.size(); i-- > 0;)
+            std::copy(journal[i].old.begin(), journal[i].old.end(), journal[i].row);
         x->deleted[s] = 0;
         x->node_count++;
         set_err("mn_hnsw_delete: reconnection would exceed the fixed neighbour-row width (unsupported)");

@@ -393,6 +393,25 @@ def test_two_host_threads_two_indexes(gpu, orc):
         assert np.array_equal(got[t][0], want[t][0]) and same_bits(got[t][1], want[t][1])
 
 
+def test_rowid_minus_one_is_also_the_empty_marker(gpu, orc):
+    """-1 is a legal rowid and the reference's "no entry point" value (src/hnsw_algo.c:194,:544): after rowid -1 goes
+    into an empty index the next insert is treated as the first one again.  Same here, in one call or several."""
+    X = gauss(6, 4, 95)
+    ids = np.array([-1, 14, 3, -7, 0, 9], np.int64)
+    o = orc.Oracle(4, "l2", 4, 20)
+    o.insert_many(ids, X)
+    for cuts in ([6], [1, 5], [2, 4]):
+        g = gpu.HnswIndex(4, "l2", 4, 20)
+        a = 0
+        for b in cuts + [6]:
+            if b > a:
+                assert g.insert_batch(ids[a:b], X[a:b], gpu.BUILD_SEQUENTIAL) == 0
+            a = b
+        assert g.graph(ids) == o.graph(ids), cuts
+        assert g.entry_point == o.entry_point and g.max_level == o.max_level
+        g.close()
+
+
 def test_m33_is_refused(gpu):
     with pytest.raises(Exception):
         gpu.HnswIndex(8, "l2", 33, 50)
