@@ -23,7 +23,7 @@ typedef long long sqlite3_int64;
 typedef unsigned long long sqlite3_uint64;
 
 typedef struct sqlite3_api_routines {
-    void *slot[272]; /* 2168 bytes in 3.50; only low slots are touched */
+    void *slot[272]; /* 2168 bytes in 3.50; slots above 162 are only touched after a version check */
 } sqlite3_api_routines;
 
 /* result codes / fundamental types / flags (sqlite.org/rescode.html, c3ref/c_blob.html) */
@@ -69,6 +69,8 @@ typedef void (*sqlite3_destructor_type)(void *);
 #define MN_SLOT_exec 55
 #define MN_SLOT_finalize 57
 #define MN_SLOT_free 58
+#define MN_SLOT_last_insert_rowid 65
+#define MN_SLOT_libversion_number 67
 #define MN_SLOT_malloc 68
 #define MN_SLOT_mprintf 69
 #define MN_SLOT_reset 77
@@ -92,6 +94,7 @@ typedef void (*sqlite3_destructor_type)(void *);
 #define MN_SLOT_create_module_v2 119
 #define MN_SLOT_context_db_handle 149
 #define MN_SLOT_create_function_v2 162
+#define MN_SLOT_set_last_insert_rowid 216 /* SQLite >= 3.18.0; guarded by libversion_number at the call site */
 
 extern const sqlite3_api_routines *mn_sqlite_api; /* set once by sqlite3_muninn_init */
 #define MN_API(slotno, fntype) ((fntype)(mn_sqlite_api->slot[slotno]))
@@ -169,6 +172,9 @@ struct sqlite3_index_info {
 };
 
 /* typed accessors, named as the C API names them */
+#define sqlite3_last_insert_rowid MN_API(MN_SLOT_last_insert_rowid, sqlite3_int64 (*)(sqlite3 *))
+#define sqlite3_set_last_insert_rowid MN_API(MN_SLOT_set_last_insert_rowid, void (*)(sqlite3 *, sqlite3_int64))
+#define sqlite3_libversion_number MN_API(MN_SLOT_libversion_number, int (*)(void))
 #define sqlite3_malloc MN_API(MN_SLOT_malloc, void *(*)(int))
 #define sqlite3_free MN_API(MN_SLOT_free, void (*)(void *))
 #define sqlite3_mprintf MN_API(MN_SLOT_mprintf, char *(*)(const char *, ...))

@@ -748,7 +748,19 @@ static int x_begin(sqlite3_vtab *vt) {
     (void)vt;
     return SQLITE_OK;
 }
-static int x_sync(sqlite3_vtab *vt) { return flush_pending((VtabHnsw *)vt); }
+static int x_sync(sqlite3_vtab *vt) {
+    VtabHnsw *v = (VtabHnsw *)vt;
+    if (v->n_pend == 0)
+        return SQLITE_OK;
+    /* the shadow-table statements below run after xUpdate has returned, so unlike the reference's (which run inside
+     * it) they would show through sqlite3_last_insert_rowid(): put the statement's own value back */
+    const int can_restore = sqlite3_libversion_number() >= 3018000;
+    const sqlite3_int64 last = sqlite3_last_insert_rowid(v->db);
+    int rc = flush_pending(v);
+    if (can_restore)
+        sqlite3_set_last_insert_rowid(v->db, last);
+    return rc;
+}
 static int x_commit(sqlite3_vtab *vt) {
     (void)vt;
     return SQLITE_OK;

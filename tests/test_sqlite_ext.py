@@ -476,3 +476,29 @@ def test_graph_from_stored_blocks_equals_graph_from_edges(gpu, tmp_path):
     with pytest.raises(Exception, match="out of range|malformed"):
         bad = [(fwd[0][0], np.full(len(fwd[0][1]) // 4, n + 5, np.int32).tobytes(), fwd[0][2])] + list(fwd[1:])
         gpu.Graph.from_blocks(n, bad, rev)
+
+
+@gpu_mark
+@pytest.mark.parametrize("mode", ["exact", "deferred"])
+@pytest.mark.parametrize("seed", range(12))
+def test_random_sql_sessions_match_reference_transcripts(ext_built, gpu, monkeypatch, seed, mode):
+    """tests/golden/vtab_fuzz.json.gz: transcripts of seeded random sessions (inserts with explicit / automatic /
+    duplicate / malformed rows, deletes, kNN and point queries, transactions) under the REFERENCE's extension — every
+    returned rowid, distance (f64 bits), error text, and the final shadow tables.  The same session here must produce
+    the same transcript line for line (oracle/gen_golden.py: vtab_fuzz_run)."""
+    import gzip
+    import json
+
+    from oracle.gen_golden import vtab_fuzz_run
+
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "vtab_fuzz.json.gz"), "rt") as f:
+        want = json.load(f)[str(seed)]
+    monkeypatch.setenv("MUNINN_HNSW_MODE", mode)
+    c = sqlite3.connect(":memory:")
+    c.enable_load_extension(True)
+    c.load_extension(ext_built)
+    got = vtab_fuzz_run(c, seed)
+    c.close()
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert a == b, f"line {i}: ours {a[:300]!r} reference {b[:300]!r}"
+    assert len(got) == len(want)
