@@ -502,3 +502,28 @@ def test_random_sql_sessions_match_reference_transcripts(ext_built, gpu, monkeyp
     for i, (a, b) in enumerate(zip(got, want)):
         assert a == b, f"line {i}: ours {a[:300]!r} reference {b[:300]!r}"
     assert len(got) == len(want)
+
+
+@gpu_mark
+@pytest.mark.parametrize("seed", range(8))
+def test_random_graph_sql_sessions_match_reference_transcripts(ext_built, gpu, monkeypatch, seed):
+    """tests/golden/graph_fuzz.json.gz: seeded sessions on the graph SQL surface under the REFERENCE's extension —
+    graph_leiden with random options on edge tables with text ids, NULLs, duplicates, weights and time windows;
+    node2vec_train with valid and invalid arguments into an hnsw_index table.  Same transcript here, line for line
+    (communities, modularity bits, embedding bytes, error texts).  oracle/gen_golden.py: graph_fuzz_run."""
+    import gzip
+    import json
+
+    from oracle.gen_golden import graph_fuzz_run
+
+    monkeypatch.setenv("MUNINN_GRAPH_MODE", "exact")
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "graph_fuzz.json.gz"), "rt") as f:
+        want = json.load(f)[str(seed)]
+    c = sqlite3.connect(":memory:")
+    c.enable_load_extension(True)
+    c.load_extension(ext_built)
+    got = graph_fuzz_run(c, seed)
+    c.close()
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert a == b, f"line {i}: ours {a[:400]!r} reference {b[:400]!r}"
+    assert len(got) == len(want)
