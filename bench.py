@@ -190,6 +190,13 @@ def main():
         raise SystemExit("build failed: " + pkg.hnsw._err())
     g.sync()
     build_s = time.perf_counter() - t0
+    build_s_max = build_s
+    if dist is not None:  # slowest rank's build: the N-GPU build rate is (vectors built by all ranks) / that
+        import torch
+
+        tb = torch.tensor([build_s], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+        build_s_max = float(tb.item())
 
     # ---- HBM-resident inputs / outputs ----
     dq = g.dev_malloc(Q.nbytes)
@@ -367,6 +374,9 @@ def main():
             "recall_queries": nrec,
             "n_dist_per_query": n_dist / NQ,
             "build_vectors_per_s": N / build_s,
+            # sharded index: every rank builds its own N-vector shard (config 3) → aggregate; replicas: the same graph is
+            # built once per GPU, which does not scale (a single sequential-semantics graph does not shard)
+            "build_vectors_per_s_all_gpus": (N * world if sharded else N) / build_s_max,
             "build_s": build_s,
             "build_mode": "batch-synchronous (batch <= max(1, n/16), cap 8192), one replica per GPU",
             "parity_vs_oracle": parity,
