@@ -185,8 +185,15 @@ def main():
     # ---- build on the device (reported, not the timed step) ----
     dev_ord = args.device if args.device >= 0 else local_rank
     g = pkg.HnswIndex(D, args.metric, M, EFC, order=order, device=dev_ord)
+    shared_build = world > 1 and not sharded
+    if dist is not None:
+        dist.barrier()
     t0 = time.perf_counter()
-    if g.build(ids, X, 16, 8192) != 0:
+    if shared_build:
+        # replicas of ONE graph: every batch's search half is split over the ranks, the selected lists are all-gathered
+        # (RCCL), every replica links the whole batch → the graph of a one-GPU build, on every GPU (parallel.py)
+        pkg.parallel.build_distributed(g, ids, X, 16, 8192)
+    elif g.build(ids, X, 16, 8192) != 0:
         raise SystemExit("build failed: " + pkg.hnsw._err())
     g.sync()
     build_s = time.perf_counter() - t0
@@ -376,9 +383,12 @@ def main():
             "build_vectors_per_s": N / build_s,
             # sharded index: every rank builds its own N-vector shard (config 3) → aggregate; replicas: the same graph is
             # built once per GPU, which does not scale (a single sequential-semantics graph does not shard)
-            "build_vectors_per_s_all_gpus": (N * world if sharded else N) / build_s_max,
+            "build_vectors_per_s_all_gpus": (N * world if sharded else N) / build_s_max,  # jointly built graph: N / time
             "build_s": build_s,
-            "build_mode": "batch-synchronous (batch <= max(1, n/16), cap 8192), one replica per GPU",
+            "build_mode": "batch-synchronous (batch <= max(1, n/16), cap 8192); " +
+                          ("one graph built jointly: search half of each batch split over the GPUs, selected lists all-gathered, "
+                           "every replica links (bit-identical to the 1-GPU build)" if shared_build else
+                           "one shard per GPU" if sharded else "single GPU"),
             "parity_vs_oracle": parity,
             "ef_sweep": sweep,
             "at_recall_target": at_target,

@@ -81,6 +81,21 @@ int mn_hnsw_insert_batch(mn_index *idx, const int64_t *ids, const float *vectors
 /* Bulk build helper: splits [n] into batches growing with the index (batch ≤ max(1, count/grow_div),
  * capped at max_batch) and calls the batched schedule on each.  grow_div ≤ 0 → 16, max_batch ≤ 0 → 8192. */
 int mn_hnsw_build(mn_index *idx, const int64_t *ids, const float *vectors, int64_t n, int grow_div, int max_batch);
+/* One MN_BUILD_BATCHED batch in three steps, so that several GPUs that each hold a replica of the index can share
+ * its search half (the dominant cost) and still all end up with the graph a single GPU builds:
+ *   stage  — add the batch's nodes (ids, levels from the index's own level stream, vectors) on this replica;
+ *            returns m = nodes waiting to be searched and linked (n, or n-1 when the first node of an empty index
+ *            just became the entry point), -1 on error;
+ *   search — search staged nodes [lo, hi) against the graph as it stands and write their selected-neighbour lists
+ *            into rows lo..hi of the caller's DEVICE arrays d_sel [m][nlev][row_width] / d_nsel [m][nlev]
+ *            (mn_hnsw_batch_dims gives nlev = top layer + 1 and row_width = 2M);
+ *   (the caller exchanges the rows between replicas — an all-gather — so that every replica holds all m)
+ *   link   — apply the whole batch's links from the full arrays and update entry point / top layer.
+ * Every replica must stage the same batches in the same order (the level stream is part of the index state). */
+int mn_hnsw_batch_stage(mn_index *idx, const int64_t *ids, const float *vectors, int64_t n);
+int mn_hnsw_batch_dims(mn_index *idx, int *nlev, int *row_width);
+int mn_hnsw_batch_search(mn_index *idx, int lo, int hi, int *d_sel, int *d_nsel);
+int mn_hnsw_batch_link(mn_index *idx, const int *d_sel, const int *d_nsel);
 
 /* hnsw_search (:670-704): ef = max(ef, k); results ascending by distance; returns count ≤ k */
 int mn_hnsw_search(mn_index *idx, const float *query, int k, int ef_search, mn_search_result *results);

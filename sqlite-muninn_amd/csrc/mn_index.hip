@@ -109,6 +109,8 @@ struct mn_index {
     // speculative exact build: read logs of a window's searches, per-row rewrite epochs
     DevBuf<int> ws_readlog, ws_nread, ws_ncommit, d_stamp0, d_stampU;
     int spec_epoch = 0;
+    std::vector<int> staged; // mn_hnsw_batch_stage: slots added but not yet searched / linked
+    DevBuf<int> d_staged;
     long long last_spec_searched = 0; // searches the last speculative build ran (≥ nodes inserted)
     mn_launch_stats last = {0, 0, 0, 0};
 };
@@ -444,6 +446,7 @@ extern "C" void mn_hnsw_destroy(mn_index *x) {
     x->lk_count.release(); x->lk_fill.release(); x->lk_binoff.release(); x->lk_touched.release(); x->lk_bins.release();
     x->lk_newrows.release(); x->ws_counters.release(); x->ws_state.release();
     x->er_slot.release(); x->er_level.release(); x->er_nbr.release(); x->er_dist.release();
+    x->d_staged.release();
     x->ws_readlog.release(); x->ws_nread.release(); x->ws_ncommit.release(); x->d_stamp0.release(); x->d_stampU.release();
     if (x->ev0) (void)hipEventDestroy(x->ev0);
     if (x->ev1) (void)hipEventDestroy(x->ev1);
@@ -666,17 +669,13 @@ static int build_search(mn_index *x, const int *slots, int nq, MnSearchArgs &a, 
     return 0;
 }
 
-static int run_batch(mn_index *x, const std::vector<int> &slots) {
+// link half of a group of inserts: nq batch nodes (device array of their slots) with their selected lists; then the
+// entry point / top layer update in batch order (src/hnsw_algo.c:660-663)
+static int link_batch(mn_index *x, const std::vector<int> &slots, const int *d_slots, int nlev, const int *d_sel,
+                      const int *d_nsel) {
     hipStream_t st = x->stream;
     const int nq = (int)slots.size();
-    if (nq == 0)
-        return 0;
-    const int nlev = x->max_level + 1;
-    MnSearchArgs a;
-    if (build_search(x, slots.data(), nq, a, 0))
-        return -1;
     MnDevIndex v = dev_view(x);
-    // link, layer by layer
     const int max_tuples = nq * x->M_max0;
     if (x->lk_target.reserve((size_t)max_tuples, false, st)) return -1;
     if (x->lk_src.reserve((size_t)max_tuples, false, st)) return -1;
@@ -691,9 +690,9 @@ static int run_batch(mn_index *x, const std::vector<int> &slots) {
     memset(&la, 0, sizeof(la));
     la.nq = nq;
     la.nlev = nlev;
-    la.query_slots = x->ws_qslots.p;
-    la.sel = x->ws_sel.p;
-    la.nsel = x->ws_nsel.p;
+    la.query_slots = d_slots;
+    la.sel = d_sel;
+    la.nsel = d_nsel;
     la.t_target = x->lk_target.p;
     la.t_src = x->lk_src.p;
     la.counters = x->lk_counters.p;
@@ -717,7 +716,6 @@ static int run_batch(mn_index *x, const std::vector<int> &slots) {
         return -1;
     }
     x->host_links_valid = false;
-    // entry point / max level in batch order (src/hnsw_algo.c:660-663)
     for (int j = 0; j < nq; j++) {
         int lv = x->levels[slots[j]];
         if (lv > x->max_level) {
@@ -728,7 +726,17 @@ static int run_batch(mn_index *x, const std::vector<int> &slots) {
     return 0;
 }
 
-// the reference's one-at-a-time semantics, all of `slots` in one (chunked) single-wavefront launch
+static int run_batch(mn_index *x, const std::vector<int> &slots) {
+    const int nq = (int)slots.size();
+    if (nq == 0)
+        return 0;
+    const int nlev = x->max_level + 1;
+    MnSearchArgs a;
+    if (build_search(x, slots.data(), nq, a, 0))
+        return -1;
+    return link_batch(x, slots, x->ws_qslots.p, nlev, x->ws_sel.p, x->ws_nsel.p);
+}
+
 static int run_sequential(mn_index *x, const std::vector<int> &slots) {
     hipStream_t st = x->stream;
     const int n = (int)slots.size();
@@ -846,6 +854,8 @@ static int run_speculative(mn_index *x, const std::vector<int> &slots) {
     return 0;
 }
 
+#define MN_BUILD_STAGE_ONLY 100 // internal: add the nodes, leave search + link to mn_hnsw_batch_search / _link
+
 static int insert_impl(mn_index *x, const int64_t *ids, const float *vectors, int64_t n, int mode) {
     if (use_device(x))
         return -1;
@@ -897,6 +907,10 @@ static int insert_impl(mn_index *x, const int64_t *ids, const float *vectors, in
         }
     }
     std::vector<int> rest(slots.begin() + pos, slots.end());
+    if (mode == MN_BUILD_STAGE_ONLY) { // mn_hnsw_batch_stage: the caller drives search and link itself
+        x->staged.swap(rest);
+        return 0;
+    }
     if (mode == MN_BUILD_SEQUENTIAL) {
         // same result either way; speculation pays once several inserts are queued (MN_SPECULATE=0 turns it off)
         const char *sp = getenv("MN_SPECULATE");
@@ -956,6 +970,70 @@ extern "C" int mn_hnsw_build(mn_index *x, const int64_t *ids, const float *vecto
         pos += b;
     }
     return 0;
+}
+
+// ── one batch of the batch-synchronous build in three steps, so that the search half can be split over several GPUs
+//    that each hold a replica of the index (sqlite-muninn_amd/parallel.py build_distributed) ──
+#define MN_STAGE_CHECK(x)                                                       \
+    if (use_device(x))                                                          \
+        return -1;
+
+extern "C" int mn_hnsw_batch_stage(mn_index *x, const int64_t *ids, const float *vectors, int64_t n) {
+    MN_STAGE_CHECK(x)
+    if (!x->staged.empty()) {
+        set_err("mn_hnsw_batch_stage: the previous batch was not linked");
+        return -1;
+    }
+    if (insert_impl(x, ids, vectors, n, MN_BUILD_STAGE_ONLY))
+        return -1;
+    const int m = (int)x->staged.size();
+    if (m) {
+        if (x->d_staged.reserve((size_t)m, false, x->stream)) return -1;
+        HIPCHK(hipMemcpy(x->d_staged.p, x->staged.data(), (size_t)m * sizeof(int), hipMemcpyHostToDevice));
+    }
+    return m;
+}
+
+extern "C" int mn_hnsw_batch_dims(mn_index *x, int *nlev, int *row_width) {
+    *nlev = x->max_level + 1;
+    *row_width = x->M_max0;
+    return 0;
+}
+
+extern "C" int mn_hnsw_batch_search(mn_index *x, int lo, int hi, int *d_sel, int *d_nsel) {
+    MN_STAGE_CHECK(x)
+    const int m = (int)x->staged.size();
+    if (lo < 0 || hi > m || lo > hi) {
+        set_err("mn_hnsw_batch_search: bad range [%d, %d) of %d staged nodes", lo, hi, m);
+        return -1;
+    }
+    if (hi == lo)
+        return 0;
+    const int nlev = x->max_level + 1;
+    MnSearchArgs a;
+    if (build_search(x, x->staged.data() + lo, hi - lo, a, 0))
+        return -1;
+    const size_t row = (size_t)nlev * x->M_max0;
+    HIPCHK(hipMemcpyAsync(d_sel + (size_t)lo * row, x->ws_sel.p, (size_t)(hi - lo) * row * sizeof(int), hipMemcpyDeviceToDevice,
+                          x->stream));
+    HIPCHK(hipMemcpyAsync(d_nsel + (size_t)lo * nlev, x->ws_nsel.p, (size_t)(hi - lo) * nlev * sizeof(int), hipMemcpyDeviceToDevice,
+                          x->stream));
+    if (fetch_counters(x)) // synchronises
+        return -1;
+    if (x->last.last_n_overflow) {
+        set_err("mn_hnsw_batch_search: %lld searches exceeded heap workspace", (long long)x->last.last_n_overflow);
+        return -1;
+    }
+    return 0;
+}
+
+extern "C" int mn_hnsw_batch_link(mn_index *x, const int *d_sel, const int *d_nsel) {
+    MN_STAGE_CHECK(x)
+    std::vector<int> slots;
+    slots.swap(x->staged);
+    if (slots.empty())
+        return 0;
+    return link_batch(x, slots, x->d_staged.p, x->max_level + 1, d_sel, d_nsel);
 }
 
 // ───────────────────────── delete (cold path, host-side list surgery on the mirror) ─────────────────────────

@@ -71,6 +71,10 @@ SYMBOLS = [
     ("mn_hnsw_export_nodes", C.c_int, [C.c_void_p, _i64p, _i32p, _i32p]),
     ("mn_hnsw_export_vectors", C.c_int, [C.c_void_p, _f32p]),
     ("mn_hnsw_export_links", C.c_int, [C.c_void_p, C.c_int, _i32p, C.POINTER(C.c_int)]),
+    ("mn_hnsw_batch_stage", C.c_int, [C.c_void_p, _i64p, _f32p, C.c_int64]),
+    ("mn_hnsw_batch_dims", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("mn_hnsw_batch_search", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    ("mn_hnsw_batch_link", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mn_hnsw_take_dirty", C.c_int64, [C.c_void_p, _i64p, C.c_int64]),
     ("mn_hnsw_edges_of", C.c_int64, [C.c_void_p, _i64p, C.c_int, _i64p, _i64p, _i32p, _f32p, C.c_int64]),
     ("mn_hnsw_last_launch", C.c_int, [C.c_void_p, C.POINTER(LaunchStats)]),
@@ -132,6 +136,7 @@ class HnswIndex:
         self.L = lib()
         self.dim = dim
         self.M = M
+        self.device = device
         self.h = self.L.mn_hnsw_create_on(dim, METRIC[metric] if isinstance(metric, str) else metric, M, ef_construction,
                                           device)
         if not self.h:

@@ -132,3 +132,61 @@ def node2vec_train_distributed(off, adj, dim, p=1.0, q=1.0, num_walks=10, walk_l
         return out, {"pairs": int(pairs.item()), "device_ms": st.device_ms, "batch_walks": B}
     finally:
         L.mn_n2v_end(S)
+
+
+def build_distributed(g, ids, vectors, grow_div=16, max_batch=8192, group=None, min_split=256):
+    """mn_hnsw_build on N GPUs that each hold a replica of ONE index: the batches are the same as on one GPU
+    (batch <= max(1, count/grow_div), capped at max_batch); inside a batch every rank searches a contiguous slice of the
+    batch's nodes against its replica (the replicas are identical, so the selected-neighbour lists are the ones a
+    single GPU computes), the lists are all-gathered (RCCL over xGMI under backend "nccl": m * nlev * 2M int32, a few
+    MB per batch) and every rank applies the whole batch's links.  All replicas end up with the graph of a one-GPU
+    mn_hnsw_build, bit for bit.  Batches below `min_split` nodes are searched whole by every rank (no exchange).
+    g: HnswIndex on this rank's device; ids / vectors: the SAME arrays on every rank."""
+    import ctypes as C
+
+    import numpy as np
+
+    from .hnsw import MuninnHipError, _err
+
+    L = g.L
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    ids = np.ascontiguousarray(ids, np.int64)
+    vectors = np.ascontiguousarray(vectors, np.float32)
+    n = len(ids)
+    dev = torch.device("cuda", g.device)
+    host_staged = dist.get_backend(group) == "gloo"
+    pos = 0
+    while pos < n:
+        b = max(1, g.node_count // grow_div)
+        b = min(b, max_batch, n - pos)
+        m = L.mn_hnsw_batch_stage(g.h, ids[pos:pos + b], vectors[pos:pos + b], b)
+        if m < 0:
+            raise MuninnHipError(_err())
+        pos += b
+        if m == 0:
+            continue
+        nlev, w0 = C.c_int(0), C.c_int(0)
+        L.mn_hnsw_batch_dims(g.h, C.byref(nlev), C.byref(w0))
+        nlev, w0 = nlev.value, w0.value
+        split = world > 1 and m >= min_split
+        per = (m + world - 1) // world if split else m
+        rows = per * world if split else m
+        sel = torch.full((rows, nlev, w0), -1, dtype=torch.int32, device=dev)
+        nsel = torch.zeros((rows, nlev), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize(dev)
+        lo, hi = (min(m, rank * per), min(m, rank * per + per)) if split else (0, m)
+        if L.mn_hnsw_batch_search(g.h, lo, hi, sel.data_ptr(), nsel.data_ptr()) != 0:
+            raise MuninnHipError(_err())
+        if split:
+            for t in (sel, nsel):
+                mine = t[rank * per:(rank + 1) * per]
+                if host_staged:
+                    out = torch.empty((world,) + tuple(mine.shape), dtype=t.dtype)
+                    dist.all_gather(list(out.unbind(0)), mine.cpu().contiguous(), group=group)
+                    t.copy_(out.reshape(t.shape).to(dev))
+                else:
+                    dist.all_gather_into_tensor(t, mine.clone(), group=group)
+            torch.cuda.synchronize(dev)
+        if L.mn_hnsw_batch_link(g.h, sel.data_ptr(), nsel.data_ptr()) != 0:
+            raise MuninnHipError(_err())
+    return 0

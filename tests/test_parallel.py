@@ -153,3 +153,49 @@ def test_node2vec_data_parallel_world2_bit_identical_to_one_gpu(gpu):
     for rank, emb, st in res:
         assert np.array_equal(emb.view(np.int32), single.view(np.int32)), rank
         assert st["pairs"] == st1["pairs"]
+
+
+def _build_worker(rank, world, port, q):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import muninn_amd
+
+    pkg = muninn_amd.pkg
+    X = np.random.default_rng(77).standard_normal((6000, 24)).astype(np.float32)
+    ids = np.arange(5, 6005, dtype=np.int64)
+    g = pkg.HnswIndex(24, "cosine", 8, 60)
+    pkg.parallel.build_distributed(g, ids, X, 16, 1024, min_split=64)
+    q.put((rank, g.export_links(0), g.export_links(1), g.entry_point, g.max_level))
+    g.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_build_shared_by_two_ranks_equals_one_gpu_build(gpu):
+    """parallel.build_distributed: two replicas (gloo exchange, both on the box's one GPU) split the search half of
+    every batch and all-gather the selected lists; each must end with exactly the graph mn_hnsw_build makes alone."""
+    X = np.random.default_rng(77).standard_normal((6000, 24)).astype(np.float32)
+    ids = np.arange(5, 6005, dtype=np.int64)
+    g = gpu.HnswIndex(24, "cosine", 8, 60)
+    assert g.build(ids, X, 16, 1024) == 0
+    want = (g.export_links(0), g.export_links(1), g.entry_point, g.max_level)
+    g.close()
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_build_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = _collect(procs, q, world, 300)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, l0, l1, ep, ml in res:
+        assert np.array_equal(l0, want[0]) and np.array_equal(l1, want[1]), rank
+        assert (ep, ml) == want[2:]
