@@ -185,7 +185,7 @@ def main():
     # ---- build on the device (reported, not the timed step) ----
     dev_ord = args.device if args.device >= 0 else local_rank
     g = pkg.HnswIndex(D, args.metric, M, EFC, order=order, device=dev_ord)
-    shared_build = world > 1 and not sharded
+    shared_build = world > 1 and not sharded and os.environ.get("MN_BENCH_SHARED_BUILD", "1") != "0"
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
