@@ -325,6 +325,42 @@ static int persist_marked(VtabHnsw *v, const sqlite3_int64 *new_ids, const float
         free(marked);
         return SQLITE_ERROR;
     }
+    /* persist_node upserts the node row of every neighbour as well (src/hnsw_vtab.c:243-256).  For a row that exists
+     * that changes nothing; it matters after a ROLLBACK, which takes shadow rows away while the index (the reference's
+     * in-memory one, ours in HBM) keeps the nodes: the next insert that links to such a node brings its row back. */
+    {
+        sqlite3_stmt *has = 0, *put = 0;
+        sql = sqlite3_mprintf("SELECT 1 FROM \"%w_nodes\" WHERE id = ?", v->name);
+        rc = sqlite3_prepare_v2(v->db, sql, -1, &has, 0);
+        sqlite3_free(sql);
+        if (rc == SQLITE_OK) {
+            sql = sqlite3_mprintf("INSERT OR REPLACE INTO \"%w_nodes\" (id, vector, level, deleted) VALUES (?, ?, ?, 0)", v->name);
+            rc = sqlite3_prepare_v2(v->db, sql, -1, &put, 0);
+            sqlite3_free(sql);
+        }
+        float *vb = rc == SQLITE_OK ? (float *)malloc((size_t)v->dim * sizeof(float)) : 0;
+        for (int64_t i = 0; i < nd && rc == SQLITE_OK && vb; i++) {
+            if (pset_has(v, marked[i]))
+                continue;
+            sqlite3_bind_int64(has, 1, marked[i]);
+            const int present = sqlite3_step(has) == SQLITE_ROW;
+            sqlite3_reset(has);
+            if (present || mn_hnsw_get_vector(v->index, marked[i], vb) != 0)
+                continue;
+            sqlite3_bind_int64(put, 1, marked[i]);
+            sqlite3_bind_blob(put, 2, vb, v->dim * (int)sizeof(float), SQLITE_STATIC);
+            sqlite3_bind_int(put, 3, mn_hnsw_node_level(v->index, marked[i]));
+            sqlite3_step(put);
+            sqlite3_reset(put);
+        }
+        free(vb);
+        sqlite3_finalize(has);
+        sqlite3_finalize(put);
+        if (rc != SQLITE_OK) {
+            free(marked);
+            return rc;
+        }
+    }
     /* old edges of the pre-existing marked nodes (new nodes have none yet) */
     sql = sqlite3_mprintf("DELETE FROM \"%w_edges\" WHERE source_id = ?", v->name);
     rc = sqlite3_prepare_v2(v->db, sql, -1, &st, 0);

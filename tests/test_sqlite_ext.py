@@ -479,11 +479,13 @@ def test_graph_from_stored_blocks_equals_graph_from_edges(gpu, tmp_path):
 
 
 @gpu_mark
-@pytest.mark.parametrize("mode", ["exact", "deferred"])
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed,mode", [(s, m) for s in range(12) for m in ("exact", "deferred")] +
+                         [(s, "exact") for s in range(100, 106)])  # 100+: sessions with ROLLBACKs
 def test_random_sql_sessions_match_reference_transcripts(ext_built, gpu, monkeypatch, seed, mode):
     """tests/golden/vtab_fuzz.json.gz: transcripts of seeded random sessions (inserts with explicit / automatic /
-    duplicate / malformed rows, deletes, kNN and point queries, transactions) under the REFERENCE's extension — every
+    duplicate / malformed rows, deletes, kNN and point queries, transactions — seeds 100+ also ROLLBACKs, after which the
+    reference's in-memory index still holds the rolled-back nodes and re-persists them when later inserts link to them;
+    the deferred mode drops queued rows on rollback instead, so those seeds run in exact mode only) under the REFERENCE's extension — every
     returned rowid, distance (f64 bits), error text, and the final shadow tables.  The same session here must produce
     the same transcript line for line (oracle/gen_golden.py: vtab_fuzz_run)."""
     import gzip
@@ -497,7 +499,7 @@ def test_random_sql_sessions_match_reference_transcripts(ext_built, gpu, monkeyp
     c = sqlite3.connect(":memory:")
     c.enable_load_extension(True)
     c.load_extension(ext_built)
-    got = vtab_fuzz_run(c, seed)
+    got = vtab_fuzz_run(c, seed, rollbacks=seed >= 100)
     c.close()
     for i, (a, b) in enumerate(zip(got, want)):
         assert a == b, f"line {i}: ours {a[:300]!r} reference {b[:300]!r}"
