@@ -13,11 +13,13 @@ t0 = time.time(); it = 0; bad = 0; refused = 0
 while time.time() - t0 < budget:
     it += 1
     dim = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 31, 32, 64, 100, 128, 257]))
-    M = int(rng.choice([2, 3, 4, 6, 8, 12, 16, 24, 32]))
+    M = int(rng.choice([2, 3, 4, 6, 8, 12, 16, 24, 32, 40, 48, 64]))
     efc = int(rng.choice([1, 5, 10, 40, 100, 200, 300]))
     metric = str(rng.choice(["l2", "cosine", "inner_product"]))
     wave = bool(rng.integers(0, 2))
     n = int(rng.choice([1, 2, 7, 60, 300, 1200, 2500]))
+    if M > 32:
+        n = min(n, 300)  # the CPU oracle's MN-RU prune is O(M^3) per full row
     kind = str(rng.choice(["gauss", "dups", "lattice", "zeros"]))
     if kind == "gauss":
         X = rng.standard_normal((n, dim)).astype(np.float32)

@@ -206,7 +206,9 @@ DEVI const int *link_row(const MnDevIndex &ix, int node, int level, int &W) {
 
 // src/hnsw_algo.c:257-282 incl. its quirk: after `current` is re-pointed the for-loop carries on at
 // index i+1 of the NEW node's list.
-template <int ORDER, int NCH, bool COH = false>
+// WIDE: rows may hold more than 64 links (M > 32) and are walked in 64-link chunks; with WIDE = false the chunk
+// logic folds away at compile time and the code is the single-pass one the throughput kernels were tuned with.
+template <int ORDER, int NCH, bool COH = false, bool WIDE = false>
 DEVI int greedy_layer(const MnDevIndex &ix, WaveCtx &w, int entry, int level, int lane) {
     int cur = entry;
     float cur_d = ctx_distance<ORDER, NCH>(ix, w, cur, 1, lane);
@@ -217,18 +219,29 @@ DEVI int greedy_layer(const MnDevIndex &ix, WaveCtx &w, int entry, int level, in
     while (changed && guard < (1 << 20)) {
         changed = 0;
         int i0 = 0;
+        bool fresh = true; // a row of more than 64 links (M > 32) is walked in 64-link chunks; count the node once
         for (;;) {
             guard++;
             int W;
             const int *row = link_row(ix, cur, level, W);
-            w.n_exp++;
-            log_row_read(ix, w, cur, level, lane);
-            int nb = (lane < W) ? ld_link<COH>(row + lane) : -1;
-            bool valid = lane >= i0 && nb >= 0 && !ix.deleted[nb >= 0 ? nb : 0];
+            const int c0 = WIDE ? (i0 & ~63) : 0;
+            if (fresh) {
+                w.n_exp++;
+                log_row_read(ix, w, cur, level, lane);
+            }
+            const int pos = c0 + lane;
+            int nb = (pos < W) ? ld_link<COH>(row + pos) : -1;
+            bool valid = pos >= i0 && nb >= 0 && !ix.deleted[nb >= 0 ? nb : 0];
             unsigned long long m = __ballot(valid);
             int n = __popcll(m);
-            if (n == 0)
+            if (n == 0) {
+                if (WIDE && c0 + 64 < W) { // nothing left in this chunk: on to the next one of the same list
+                    i0 = c0 + 64;
+                    fresh = false;
+                    continue;
+                }
                 break;
+            }
             int rank = __popcll(m & ((1ull << lane) - 1ull));
             __builtin_amdgcn_wave_barrier();
             if (valid)
@@ -238,13 +251,19 @@ DEVI int greedy_layer(const MnDevIndex &ix, WaveCtx &w, int entry, int level, in
             float d = ctx_distance<ORDER, NCH>(ix, w, myslot, n, lane);
             w.n_dist += n;
             unsigned long long better = __ballot(lane < n && d < cur_d);
-            if (!better)
+            if (!better) {
+                if (WIDE && c0 + 64 < W) {
+                    i0 = c0 + 64;
+                    fresh = false;
+                    continue;
+                }
                 break;
+            }
             int c = __ffsll((long long)better) - 1; // first compact index that improves
             cur_d = __shfl(d, c);
             cur = __shfl(myslot, c);
             // list position of compact index c = position of the (c+1)-th set bit of m
-            int pos_of_me = lane; // lanes with valid hold their own list position
+            int pos_of_me = pos; // lanes with valid hold their own list position
             __builtin_amdgcn_wave_barrier();
             if (valid)
                 w.scratch[rank] = pos_of_me;
@@ -253,13 +272,14 @@ DEVI int greedy_layer(const MnDevIndex &ix, WaveCtx &w, int entry, int level, in
             i0 = rfl(i0);
             cur = rfl(cur);
             changed = 1;
+            fresh = true;
         }
     }
     return cur;
 }
 
 // src/hnsw_algo.c:347-448.  Results are left in the result heap; the caller drains it.
-template <int ORDER, int NCH, bool COH = false>
+template <int ORDER, int NCH, bool COH = false, bool WIDE = false>
 DEVI void beam_layer(const MnDevIndex &ix, WaveCtx &w, WHeap &cand, WHeap &res, unsigned *bitmap, int entry, int level,
                      int ef, int lane) {
     cand.size = 0;
@@ -296,7 +316,11 @@ DEVI void beam_layer(const MnDevIndex &ix, WaveCtx &w, WHeap &cand, WHeap &res, 
         const int *row = link_row(ix, node, level, W);
         w.n_exp++;
         log_row_read(ix, w, node, level, lane);
-        int nb = (lane < W) ? ld_link<COH>(row + lane) : -1;
+        int improved = 0;
+        const int nchunk = WIDE ? (W + 63) >> 6 : 1; // one pass unless the row has more than 64 links: list order is kept
+        for (int ch = 0; ch < nchunk; ch++) {
+        const int c0 = WIDE ? ch << 6 : 0;
+        int nb = (c0 + lane < W) ? ld_link<COH>(row + c0 + lane) : -1;
         bool todo = false;
         if (nb >= 0) { // :403-409 — mark visited first, then drop deleted
             int vi = level == 0 ? nb : ix.up_off[nb];
@@ -306,7 +330,6 @@ DEVI void beam_layer(const MnDevIndex &ix, WaveCtx &w, WHeap &cand, WHeap &res, 
         }
         unsigned long long m = __ballot(todo);
         int n = __popcll(m);
-        int improved = 0;
         if (n > 0) {
             int rank = __popcll(m & ((1ull << lane) - 1ull));
             __builtin_amdgcn_wave_barrier();
@@ -347,6 +370,7 @@ DEVI void beam_layer(const MnDevIndex &ix, WaveCtx &w, WHeap &cand, WHeap &res, 
                 }
             }
         }
+        } // chunks of the row
         stale = improved ? 0 : stale + 1; // :428-432
     }
     if (guard >= (1 << 24))

@@ -83,18 +83,21 @@ __global__ void __launch_bounds__(64) k_link_reverse(MnDevIndex ix, MnLinkArgs a
     const int t = a.touched[blockIdx.x];
     const int W = a.level == 0 ? ix.W0 : ix.WU;
     const int M_max = a.M_max;
-    int *list = reinterpret_cast<int *>(smem);         // [128]
-    float *nd = reinterpret_cast<float *>(list + 128); // [128]
-    int *mn = reinterpret_cast<int *>(nd + 128);       // [128]
-    float *q = reinterpret_cast<float *>(mn + 128);    // [ld]
+    int *list = reinterpret_cast<int *>(smem);         // [192]  (a row of up to 128 links + the new one)
+    float *nd = reinterpret_cast<float *>(list + 192); // [192]
+    int *mn = reinterpret_cast<int *>(nd + 192);       // [192]
+    float *q = reinterpret_cast<float *>(mn + 192);    // [ld]
 
     const float *tv = ix.vectors + (size_t)t * ix.ld;
     for (int i = lane; i < ix.ld; i += 64)
         q[i] = tv[i];
     const int *row = row_ptr(ix, t, a.level);
-    int cur = lane < W ? row[lane] : -1;
-    int nc = __popcll(__ballot(cur >= 0));
-    list[lane] = cur;
+    int nc = 0;
+    for (int c0 = 0; c0 < W; c0 += 64) { // 64 links per pass
+        const int cur = c0 + lane < W ? row[c0 + lane] : -1;
+        nc += __popcll(__ballot(cur >= 0));
+        list[c0 + lane] = cur;
+    }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
     const float tnorm = ix.metric == 1 ? ix.norms[t] : 0.0f;
@@ -117,7 +120,9 @@ __global__ void __launch_bounds__(64) k_link_reverse(MnDevIndex ix, MnLinkArgs a
         last = best;
         const int s = a.query_slots[best];
         // node_add_neighbor (src/hnsw_algo.c:142-163): skip if already present
-        bool present = __ballot(lane < nc && list[lane] == s) != 0;
+        bool present = false;
+        for (int c0 = 0; c0 < nc; c0 += 64)
+            present |= __ballot(c0 + lane < nc && list[c0 + lane] == s) != 0;
         if (present)
             continue;
         __builtin_amdgcn_wave_barrier();
@@ -133,8 +138,8 @@ __global__ void __launch_bounds__(64) k_link_reverse(MnDevIndex ix, MnLinkArgs a
     }
     // stage the finished row
     int *out = a.newrows + (size_t)blockIdx.x * ix.W0;
-    if (lane < W)
-        out[lane] = lane < nc ? list[lane] : -1;
+    for (int i = lane; i < W; i += 64)
+        out[i] = i < nc ? list[i] : -1;
 }
 
 __global__ void k_link_commit(MnDevIndex ix, MnLinkArgs a) {
@@ -145,8 +150,8 @@ __global__ void k_link_commit(MnDevIndex ix, MnLinkArgs a) {
     const int W = a.level == 0 ? ix.W0 : ix.WU;
     int *row = row_ptr(ix, t, a.level);
     const int *src = a.newrows + (size_t)i * ix.W0;
-    if ((int)threadIdx.x < W)
-        row[threadIdx.x] = src[threadIdx.x];
+    for (int j = threadIdx.x; j < W; j += blockDim.x)
+        row[j] = src[j];
     if (threadIdx.x == 0)
         a.count[t] = 0;
 }
@@ -164,7 +169,7 @@ static int pick_nch_b(int ld) {
 
 template <int ORDER, int NCH>
 static void launch_reverse(const MnDevIndex &ix, const MnLinkArgs &a, int max_tuples, hipStream_t st) {
-    size_t lds = 128 * 3 * sizeof(int) + (size_t)ix.ld * sizeof(float);
+    size_t lds = 192 * 3 * sizeof(int) + (size_t)ix.ld * sizeof(float);
     hipLaunchKernelGGL((k_link_reverse<ORDER, NCH>), dim3(max_tuples), dim3(64), lds, st, ix, a);
 }
 

@@ -400,8 +400,8 @@ extern "C" mn_index *mn_hnsw_create_on(int dim, int metric, int M, int ef_constr
         set_err("mn_hnsw_create: bad parameters");
         return nullptr;
     }
-    if (2 * M > 64) {
-        set_err("mn_hnsw_create: M=%d not supported on device (a level-0 row of 2M links must fit one 64-lane wavefront)", M);
+    if (2 * M > 128) {
+        set_err("mn_hnsw_create: M=%d not supported on device (a level-0 row of 2M links is walked in at most two 64-link passes)", M);
         return nullptr;
     }
     int ndev = 0;
@@ -915,7 +915,7 @@ static int insert_impl(mn_index *x, const int64_t *ids, const float *vectors, in
         // same result either way; speculation pays once several inserts are queued (MN_SPECULATE=0 turns it off)
         const char *sp = getenv("MN_SPECULATE");
         const bool spec_on = !(sp && atoi(sp) == 0);
-        if (spec_on && rest.size() >= 4)
+        if (spec_on && rest.size() >= 4 && x->M_max0 <= 64) // (k_spec_commit stages ≤ 64 targets of ≤ 64 links)
             return run_speculative(x, rest);
         return run_sequential(x, rest);
     }
@@ -1182,7 +1182,7 @@ extern "C" int mn_hnsw_neighbors(mn_index *x, int64_t id, int level, int64_t *ou
     if (s < 0 || level > x->levels[s])
         return -1;
     int W = level == 0 ? x->M_max0 : x->M;
-    int tmp[64];
+    int tmp[128];
     const int *row;
     if (x->host_links_valid) {
         row = h_row(x, s, level, &W);

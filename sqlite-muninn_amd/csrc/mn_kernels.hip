@@ -144,7 +144,7 @@ void mn_launch_dist_batch(int metric, int order, const float *d_query, const flo
 #include "mn_beam.hpp"
 
 // one query, one (leading) wavefront; `coop` = the group's shared area when helpers stand by (k_beam_coop)
-template <int ORDER, int NCH, bool BUILD>
+template <int ORDER, int NCH, bool BUILD, bool WIDE>
 DEVI void beam_query(const MnDevIndex &ix, const MnSearchArgs &a, const long long qi, const int lane, unsigned char *smem,
                      CoopCtx *coop) {
     // LDS carve: cand heap | result heap | scratch | query
@@ -206,8 +206,8 @@ DEVI void beam_query(const MnDevIndex &ix, const MnSearchArgs &a, const long lon
     if (!BUILD) {
         // hnsw_search, src/hnsw_algo.c:676-703
         for (int l = a.max_level; l > 0; l--)
-            cur = greedy_layer<ORDER, NCH>(ix, w, cur, l, lane);
-        beam_layer<ORDER, NCH>(ix, w, cand, res, bm0, cur, 0, a.ef, lane);
+            cur = greedy_layer<ORDER, NCH, false, WIDE>(ix, w, cur, l, lane);
+        beam_layer<ORDER, NCH, false, WIDE>(ix, w, cand, res, bm0, cur, 0, a.ef, lane);
         int count = res.size;
         int outn = count < a.k ? count : a.k;
         for (int i = count - 1; i >= 0; i--) { // :436-441
@@ -228,13 +228,13 @@ DEVI void beam_query(const MnDevIndex &ix, const MnSearchArgs &a, const long lon
         // search half of hnsw_insert, src/hnsw_algo.c:550-579,:650-652, against the frozen graph
         const int level = ix.levels[qslot];
         for (int l = a.max_level; l > level; l--)
-            cur = greedy_layer<ORDER, NCH>(ix, w, cur, l, lane);
+            cur = greedy_layer<ORDER, NCH, false, WIDE>(ix, w, cur, l, lane);
         int start = level < a.max_level ? level : a.max_level;
         for (int l = start; l >= 0; l--) {
             unsigned *bm = bm0;
             if (l > 0)
                 bm = a.bitmap_up + ((size_t)a.up_bm_index[qi] * a.max_level + (l - 1)) * a.bmu_words;
-            beam_layer<ORDER, NCH>(ix, w, cand, res, bm, cur, l, a.ef, lane);
+            beam_layer<ORDER, NCH, false, WIDE>(ix, w, cand, res, bm, cur, l, a.ef, lane);
             const int M_max = (l == 0) ? ix.W0 : ix.WU;
             int count = res.size;
             int keep = count < M_max ? count : M_max;
@@ -263,17 +263,17 @@ DEVI void beam_query(const MnDevIndex &ix, const MnSearchArgs &a, const long lon
     }
 }
 
-template <int ORDER, int NCH, bool BUILD>
+template <int ORDER, int NCH, bool BUILD, bool WIDE = false>
 __global__ void __launch_bounds__(64) k_beam(MnDevIndex ix, MnSearchArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     if ((long long)blockIdx.x >= a.nq)
         return;
-    beam_query<ORDER, NCH, BUILD>(ix, a, blockIdx.x, threadIdx.x, smem, nullptr);
+    beam_query<ORDER, NCH, BUILD, WIDE>(ix, a, blockIdx.x, threadIdx.x, smem, nullptr);
 }
 
 // Few queries (a single xFilter, a window of speculative inserts): one WORKGROUP per query, see CoopCtx (mn_beam.hpp).
 #define MN_COOP_WAVES 8
-template <int ORDER, int NCH, bool BUILD>
+template <int ORDER, int NCH, bool BUILD, bool WIDE = false>
 __global__ void __launch_bounds__(MN_COOP_WAVES * 64) k_beam_coop(MnDevIndex ix, MnSearchArgs a, size_t base_lds) {
     extern __shared__ __align__(16) unsigned char smem[];
     if ((long long)blockIdx.x >= a.nq)
@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(MN_COOP_WAVES * 64) k_beam_coop(MnDevIndex ix,
     c.nw = blockDim.x >> 6;
     c.wv = threadIdx.x >> 6;
     if (c.wv == 0) {
-        beam_query<ORDER, NCH, BUILD>(ix, a, blockIdx.x, lane, smem, &c);
+        beam_query<ORDER, NCH, BUILD, WIDE>(ix, a, blockIdx.x, lane, smem, &c);
         if (lane == 0)
             *c.n = -1;
         __syncthreads(); // releases the helpers
@@ -311,18 +311,29 @@ template <int ORDER, int NCH>
 static void launch_beam(const MnDevIndex &ix, const MnSearchArgs &a, bool build, hipStream_t st) {
     dim3 grid((unsigned)a.nq), block(64);
     size_t lds = mn_search_lds_bytes(ix.ld, ORDER == MN_ORDER_SSE_V && a.use_tile);
+    const bool wide = ix.W0 > 64; // M > 32: rows walked in two 64-link passes
     const char *co = getenv("MN_COOP"); // MN_COOP=0: always one wavefront per query
     if (a.nq <= 128 && !(co && atoi(co) == 0)) {
         const size_t base = (lds + 15) & ~(size_t)15;
         const size_t tot = base + (4 + 64 + 64) * sizeof(int);
         dim3 cblock(MN_COOP_WAVES * 64);
-        if (build)
+        if (wide) {
+            if (build)
+                hipLaunchKernelGGL((k_beam_coop<ORDER, NCH, true, true>), grid, cblock, tot, st, ix, a, base);
+            else
+                hipLaunchKernelGGL((k_beam_coop<ORDER, NCH, false, true>), grid, cblock, tot, st, ix, a, base);
+        } else if (build)
             hipLaunchKernelGGL((k_beam_coop<ORDER, NCH, true>), grid, cblock, tot, st, ix, a, base);
         else
             hipLaunchKernelGGL((k_beam_coop<ORDER, NCH, false>), grid, cblock, tot, st, ix, a, base);
         return;
     }
-    if (build)
+    if (wide) {
+        if (build)
+            hipLaunchKernelGGL((k_beam<ORDER, NCH, true, true>), grid, block, lds, st, ix, a);
+        else
+            hipLaunchKernelGGL((k_beam<ORDER, NCH, false, true>), grid, block, lds, st, ix, a);
+    } else if (build)
         hipLaunchKernelGGL((k_beam<ORDER, NCH, true>), grid, block, lds, st, ix, a);
     else
         hipLaunchKernelGGL((k_beam<ORDER, NCH, false>), grid, block, lds, st, ix, a);
@@ -367,18 +378,21 @@ __global__ void __launch_bounds__(64)
     __builtin_amdgcn_wave_barrier();
     int W;
     const int *row = link_row(ix, s, level, W);
-    int nb = lane < W ? row[lane] : -1;
-    int n = __popcll(__ballot(nb >= 0));
-    float d = 0.0f;
-    if (n > 0) {
-        int myslot = lane < n ? nb : 0;
-        d = rows_distance<ORDER, NCH>(ix, q, ix.metric == 1 ? ix.norms[s] : 0.0f, myslot, n, lane);
-        if (lane < n && ix.deleted[myslot])
-            d = 0.0f;
-    }
-    if (lane < ix.W0) {
-        out_nbr[(size_t)r * ix.W0 + lane] = lane < W ? nb : -1;
-        out_dist[(size_t)r * ix.W0 + lane] = d;
+    for (int c0 = 0; c0 < ix.W0; c0 += 64) { // 64 links per pass (rows are packed: no gaps before the -1 padding)
+        const int p = c0 + lane;
+        const int nb = p < W ? row[p] : -1;
+        const int n = __popcll(__ballot(nb >= 0));
+        float d = 0.0f;
+        if (n > 0) {
+            const int myslot = lane < n ? nb : 0;
+            d = rows_distance<ORDER, NCH>(ix, q, ix.metric == 1 ? ix.norms[s] : 0.0f, myslot, n, lane);
+            if (lane < n && ix.deleted[myslot])
+                d = 0.0f;
+        }
+        if (p < ix.W0) {
+            out_nbr[(size_t)r * ix.W0 + p] = nb;
+            out_dist[(size_t)r * ix.W0 + p] = d;
+        }
     }
 }
 

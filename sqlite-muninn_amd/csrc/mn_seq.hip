@@ -32,18 +32,18 @@ DEVI int *seq_row(const MnDevIndex &ix, int node, int level) {
     return ix.links_up + ((size_t)ix.up_off[node] + (level - 1)) * ix.WU;
 }
 
-template <int ORDER, int NCH>
+template <int ORDER, int NCH, bool WIDE = false>
 __global__ void __launch_bounds__(64) k_insert_seq(MnDevIndex ix, MnSeqArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
     uint2 *cand_l = reinterpret_cast<uint2 *>(smem);
     uint2 *res_l = cand_l + MN_CAND_LDS;
     int *scratch = reinterpret_cast<int *>(res_l + MN_RES_LDS); // [64]
-    int *selbuf = scratch + 64;                                 // [64]
-    int *list = selbuf + 64;                                    // [128]
-    float *nd = reinterpret_cast<float *>(list + 128);          // [128]
-    int *mn = reinterpret_cast<int *>(nd + 128);                // [128]
-    float *q = reinterpret_cast<float *>(mn + 128);             // [ld]
+    int *selbuf = scratch + 64;                                 // [128]
+    int *list = selbuf + 128;                                   // [192]
+    float *nd = reinterpret_cast<float *>(list + 192);          // [192]
+    int *mn = reinterpret_cast<int *>(nd + 192);                // [192]
+    float *q = reinterpret_cast<float *>(mn + 192);             // [ld]
     float *tv = q + ix.ld;                                      // [ld]
 
     WaveCtx w;
@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(64) k_insert_seq(MnDevIndex ix, MnSeqArgs a) {
 
         int cur = entry;
         for (int l = maxl; l > level; l--) // :553-555
-            cur = greedy_layer<ORDER, NCH, true>(ix, w, cur, l, lane);
+            cur = greedy_layer<ORDER, NCH, true, WIDE>(ix, w, cur, l, lane);
 
         const int start = level < maxl ? level : maxl;
         for (int l = start; l >= 0; l--) { // :572-653
@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(64) k_insert_seq(MnDevIndex ix, MnSeqArgs a) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __builtin_amdgcn_s_waitcnt(0);
 
-            beam_layer<ORDER, NCH, true>(ix, w, cand, res, bm, cur, l, a.ef, lane);
+            beam_layer<ORDER, NCH, true, WIDE>(ix, w, cand, res, bm, cur, l, a.ef, lane);
             const int count = res.size;
             const int nsel = count < W ? count : W; // :511
             int first = cur;
@@ -115,9 +115,18 @@ __global__ void __launch_bounds__(64) k_insert_seq(MnDevIndex ix, MnSeqArgs a) {
                 if (ix.levels[t] < l)      // :590
                     continue;
                 int *trow = seq_row(ix, t, l);
-                int v = lane < W ? ld_link<true>(trow + lane) : -1;
-                const int cnt = __popcll(__ballot(v >= 0));
-                if (__ballot(v == s)) // already a neighbour (:147-150)
+                // the row, 64 links per pass (two passes when M > 32), staged in LDS in case it has to be pruned
+                int cnt = 0;
+                bool already = false;
+                __builtin_amdgcn_wave_barrier();
+                for (int c0 = 0; c0 < W; c0 += 64) {
+                    const int v = c0 + lane < W ? ld_link<true>(trow + c0 + lane) : -1;
+                    cnt += __popcll(__ballot(v >= 0));
+                    already |= __ballot(v == s) != 0;
+                    if (c0 + lane < W)
+                        list[c0 + lane] = v;
+                }
+                if (already) // already a neighbour (:147-150)
                     continue;
                 if (cnt < W) {
                     if (lane == 0)
@@ -126,9 +135,6 @@ __global__ void __launch_bounds__(64) k_insert_seq(MnDevIndex ix, MnSeqArgs a) {
                 }
                 // ── over-full: MN-RU prune of t's list (:601-646) ──
                 const int nc = W + 1;
-                __builtin_amdgcn_wave_barrier();
-                if (lane < W)
-                    list[lane] = v;
                 if (lane == 0)
                     list[W] = s;
                 const float *tsrc = ix.vectors + (size_t)t * ix.ld;
@@ -139,8 +145,8 @@ __global__ void __launch_bounds__(64) k_insert_seq(MnDevIndex ix, MnSeqArgs a) {
                 const float tnorm = ix.metric == 1 ? ix.norms[t] : 0.0f;
                 prune_row<ORDER, NCH, true>(ix, tv, tnorm, list, nd, mn, nc, W, l, lane);
                 w.n_dist += nc;
-                if (lane < W)
-                    st_link(trow + lane, list[lane]);
+                for (int i = lane; i < W; i += 64)
+                    st_link(trow + i, list[i]);
                 __builtin_amdgcn_wave_barrier();
             }
             if (count > 0) // :651-652
@@ -189,8 +195,14 @@ void mn_launch_insert_seq(const MnDevIndex &ix, const int *d_slots, int n, int e
     a.res_ovf = res_ovf;
     a.res_gcap = res_gcap;
     a.counters = counters;
-    size_t lds = (size_t)(MN_CAND_LDS + MN_RES_LDS) * sizeof(uint2) + (2 * 64 + 3 * 128) * sizeof(int) + 2 * (size_t)ix.ld * sizeof(float);
-#define MN_SQ(O, N) hipLaunchKernelGGL((k_insert_seq<O, N>), dim3(1), dim3(64), lds, st, ix, a)
+    size_t lds = (size_t)(MN_CAND_LDS + MN_RES_LDS) * sizeof(uint2) + (64 + 128 + 3 * 192) * sizeof(int) + 2 * (size_t)ix.ld * sizeof(float);
+#define MN_SQ(O, N)                                                                            \
+    do {                                                                                       \
+        if (ix.W0 > 64)                                                                        \
+            hipLaunchKernelGGL((k_insert_seq<O, N, true>), dim3(1), dim3(64), lds, st, ix, a); \
+        else                                                                                   \
+            hipLaunchKernelGGL((k_insert_seq<O, N>), dim3(1), dim3(64), lds, st, ix, a);       \
+    } while (0)
     if (ix.order == MN_ORDER_SSE_V) {
         MN_SQ(MN_ORDER_SSE_V, 0);
         return;

@@ -278,10 +278,12 @@ def test_sequential_insert_with_ties_matches_oracle(gpu, orc):
         g.close()
 
 
-@pytest.mark.parametrize("dups", [False, True])
-def test_m32_level0_rows_fill_the_wavefront(gpu, orc, dups):
-    """M=32: a level-0 row is 64 links = one wavefront, and the MN-RU prune sees 65 entries (two per lane)."""
-    dim, n, M, efc = 12, 1800, 32, 100
+@pytest.mark.parametrize("M,n,efc,dups", [(32, 1000, 100, False), (32, 1000, 100, True), (48, 260, 110, True),
+                                          (64, 200, 140, False)])  # (the CPU oracle's MN-RU is O(M^3) per prune)
+def test_wide_rows(gpu, orc, dups, M, n, efc):
+    """M=32: a level-0 row is 64 links = one wavefront and the MN-RU prune sees 65 entries.  M=48 / 64: rows of 96 / 128
+    links are walked in two 64-link passes everywhere (search, link, prune with up to 129 entries, persistence)."""
+    dim = 12
     X = gauss(n, dim, 51)
     if dups:
         X = X[np.random.default_rng(52).integers(0, 90, n)]
@@ -301,7 +303,7 @@ def test_m32_level0_rows_fill_the_wavefront(gpu, orc, dups):
         ob = orc.Oracle(dim, metric, M, efc)
         gb = gpu.HnswIndex(dim, metric, M, efc)
         pos = 0
-        for b in (1, 2, 7, 90, 400, 1300):
+        for b in (1, 2, 7, 40, n - 50):
             assert ob.insert_batch(ids[pos:pos + b], X[pos:pos + b]) == 0
             assert gb.insert_batch(ids[pos:pos + b], X[pos:pos + b], gpu.BUILD_BATCHED) == 0
             pos += b
@@ -412,9 +414,9 @@ def test_rowid_minus_one_is_also_the_empty_marker(gpu, orc):
         g.close()
 
 
-def test_m33_is_refused(gpu):
+def test_m65_is_refused(gpu):
     with pytest.raises(Exception):
-        gpu.HnswIndex(8, "l2", 33, 50)
+        gpu.HnswIndex(8, "l2", 65, 50)
 
 
 def test_baseline_full_size_1Mx768(gpu, orc):
