@@ -63,7 +63,9 @@ int mn_vec_parse_metric(const char *name, int *out_metric);
 int mn_vec_dist_batch(int metric, int order, const float *query, const float *rows, int64_t n, int dim, float *out);
 
 /* ---- hnsw_algo.c replacements (a5-a12) ---- */
-/* hnsw_create (src/hnsw_algo.c:181-208).  M_max0 = 2M, rng seed 42.  device = HIP ordinal. */
+/* hnsw_create (src/hnsw_algo.c:181-208).  M_max0 = 2M, rng seed 42.  device = HIP ordinal.
+ * 2 <= M <= 64 (neighbour rows are fixed-width: up to 128 links at layer 0, walked 64 at a time); NULL + mn_last_error()
+ * otherwise, or when no gfx950 device is available (there is no CPU fallback). */
 mn_index *mn_hnsw_create(int dim, int metric, int M, int ef_construction);
 mn_index *mn_hnsw_create_on(int dim, int metric, int M, int ef_construction, int device);
 /* hnsw_destroy (:210-220) */
