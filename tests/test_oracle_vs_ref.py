@@ -46,3 +46,29 @@ def test_pq_trace_live(ref):
     ids = np.arange(400, dtype=np.int64)
     a, b = ref.ref_pq_trace(ops, ids, d), ref.pq_trace(ops, ids, d)
     assert np.array_equal(a[0], b[0]) and same_bits(a[1], b[1])
+
+
+def test_committed_sql_transcripts_are_what_the_reference_extension_produces(ref):
+    """tests/golden/vtab_fuzz.json.gz and graph_fuzz.json.gz are replayed against OUR extension on the GPU box.  Here,
+    where the reference's own extension can be loaded (oracle/_ref/muninn.so), the same generator is run against it
+    again: the committed transcripts must be exactly what it produces (no hand editing, generator and fixtures in sync)."""
+    import gzip
+    import json
+    import os
+    import sqlite3
+
+    from oracle import gen_golden as gg
+
+    if not os.path.exists(ref.REF_EXT + ".so"):
+        pytest.skip("reference extension not built")
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for name, run, seeds in (("vtab_fuzz.json.gz", gg.vtab_fuzz_run, (0, 5, 11, 100, 105)), ("graph_fuzz.json.gz", gg.graph_fuzz_run, (0, 7))):
+        with gzip.open(os.path.join(G, name), "rt") as f:
+            want = json.load(f)
+        for seed in seeds:
+            c = sqlite3.connect(":memory:")
+            c.enable_load_extension(True)
+            c.load_extension(ref.REF_EXT)
+            got = run(c, seed, rollbacks=True) if (name.startswith("vtab") and seed >= 100) else run(c, seed)
+            c.close()
+            assert got == want[str(seed)], (name, seed)
