@@ -295,6 +295,10 @@ struct orc_index {
     unsigned *vstamp;
     int vstamp_cap;
     unsigned vepoch;
+    /* MN-RU: membership stamps of the list being pruned (same counts as the reference's scan, O(deg) per neighbour) */
+    unsigned *mstamp;
+    int mstamp_cap;
+    unsigned mepoch;
     orc_stats st;
 };
 
@@ -424,6 +428,7 @@ void orc_hnsw_destroy(orc_index *x) {
     free(x->deleted);
     free(x->ht);
     free(x->vstamp);
+    free(x->mstamp);
     free(x);
 }
 
@@ -715,6 +720,15 @@ static int mutual_count(const int *a, int na, const int *b, int nb) {
     return c;
 }
 
+/* The same number — |list ∩ b|, lists hold no duplicates — with the list's members stamped once per prune:
+ * O(|b|) instead of O(|list|·|b|).  ORC_FAITHFUL_MN=1 (environment) switches back to the scan above. */
+static int mutual_count_stamped(const orc_index *x, const int *b, int nb) {
+    int c = 0;
+    for (int j = 0; j < nb; j++)
+        c += x->mstamp[b[j]] == x->mepoch;
+    return c;
+}
+
 typedef struct {
     const int *v;
     int n;
@@ -744,6 +758,25 @@ static void prune_list(orc_index *x, int t, int level, int *list, int nc, int M_
     float tn = x->norms[t];
     memcpy(cp, list, (size_t)nc * sizeof(int));
     x->st.n_prune++;
+    static int faithful = -1;
+    if (faithful < 0) {
+        const char *e = getenv("ORC_FAITHFUL_MN");
+        faithful = e && atoi(e) != 0;
+    }
+    if (!faithful) {
+        if (x->mstamp_cap < x->n_slots) {
+            int nc2 = x->cap_slots > x->n_slots ? x->cap_slots : x->n_slots;
+            x->mstamp = (unsigned *)realloc(x->mstamp, (size_t)nc2 * sizeof(unsigned));
+            memset(x->mstamp + x->mstamp_cap, 0, (size_t)(nc2 - x->mstamp_cap) * sizeof(unsigned));
+            x->mstamp_cap = nc2;
+        }
+        if (++x->mepoch == 0) { /* wrapped: start over */
+            memset(x->mstamp, 0, (size_t)x->mstamp_cap * sizeof(unsigned));
+            x->mepoch = 1;
+        }
+        for (int j = 0; j < nc; j++)
+            x->mstamp[list[j]] = x->mepoch;
+    }
     for (int j = 0; j < nc; j++) {
         int nn = cp[j];
         if (x->deleted[nn]) { /* :610-612 */
@@ -752,7 +785,7 @@ static void prune_list(orc_index *x, int t, int level, int *list, int nc, int M_
         } else {
             nd[j] = node_dist(x, tv, tn, nn);
             nview b = view(vctx, nn, level);
-            mn[j] = b.valid ? mutual_count(list, nc, b.v, b.n) : 0;
+            mn[j] = !b.valid ? 0 : faithful ? mutual_count(list, nc, b.v, b.n) : mutual_count_stamped(x, b.v, b.n);
         }
     }
     for (int a = 0; a < M_max && a < nc; a++) { /* :620-639 */
