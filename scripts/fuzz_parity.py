@@ -19,7 +19,7 @@ while time.time() - t0 < budget:
     wave = bool(rng.integers(0, 2))
     n = int(rng.choice([1, 2, 7, 60, 300, 1200, 2500]))
     if M > 32:
-        n = min(n, 2 * M + 40)  # the CPU oracle's MN-RU prune is O(M^3) per full row: just enough nodes to fill rows
+        n = min(n, 2 * M + 40)  # exact inserts of wide rows are slow (single wavefront, up to 128 prunes each): just fill the rows
     kind = str(rng.choice(["gauss", "dups", "lattice", "zeros"]))
     if kind == "gauss":
         X = rng.standard_normal((n, dim)).astype(np.float32)

