@@ -28,6 +28,31 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_COPY_GBS = 6290.0  # same guide: what a float4 copy kernel reaches on this part (BASELINE.md §3 reports both)
+
+
+def spawn_ranks_if_needed(gpus: int, script: str, argv: list) -> None:
+    """`python bench.py --gpus N` (no torchrun on the command line) must still run N ranks: when N > 1 and this process
+    is not already a rank, start `python -m torch.distributed.run --nproc-per-node N <script> <argv>` as a CHILD and
+    exit with its code.  Called before torch / HIP are touched (a process that has initialised the GPU is never
+    re-executed); rank 0 of the children prints the one JSON line, which is relayed as is."""
+    in_rank = "WORLD_SIZE" in os.environ
+    if in_rank:
+        if int(os.environ["WORLD_SIZE"]) != gpus:
+            raise SystemExit(f"{os.path.basename(script)}: --gpus {gpus} disagrees with WORLD_SIZE={os.environ['WORLD_SIZE']}")
+        return
+    if gpus <= 1:
+        return
+    import socket
+    import subprocess
+
+    with socket.socket() as s:  # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 def gen_vectors(n, dim, seed, dataset, chunk=65536):
@@ -144,6 +169,7 @@ def main():
                     help="N>1: replica = same index on every GPU, queries sharded (no collective); sharded = config 3: "
                          "rowid mod N shards, same queries everywhere, RCCL all-gather + merge of per-shard top-k")
     args = ap.parse_args()
+    spawn_ranks_if_needed(args.gpus, os.path.abspath(__file__), sys.argv[1:])
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -153,6 +179,8 @@ def main():
         import torch
         import torch.distributed as dist
 
+        if args.device < 0 and args.backend == "gloo":  # rehearsal: more ranks than GPUs share the cards round-robin
+            args.device = local_rank % max(1, torch.cuda.device_count())
         dev_ord = args.device if args.device >= 0 else local_rank
         torch.cuda.set_device(dev_ord)
         if args.backend == "nccl":

@@ -34,8 +34,38 @@ def er_edges(n, m, seed=42):
     return s[keep], d[keep]
 
 
+def _dist_ctx(args):
+    """(rank, world, dist module or None, device ordinal) — ranks are started by torch.distributed.run (see bench.py)."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1:
+        return 0, 1, None, max(args.device, 0)
+    import torch
+    import torch.distributed as dist
+
+    dev = args.device if args.device >= 0 else (local % max(1, torch.cuda.device_count()) if args.backend == "gloo" else local)
+    torch.cuda.set_device(dev)
+    if not dist.is_initialized():
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo")
+    return rank, world, dist, dev
+
+
+def _max_over_ranks(dist, args, x):
+    if dist is None:
+        return x
+    import torch
+
+    t = torch.tensor([x], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def bench_node2vec(pkg, args):
     n, m, dim = args.n2v_nodes, args.n2v_edges, 128
+    rank, world, dist, dev = _dist_ctx(args)
     prm = dict(p=1.0, q=1.0, num_walks=10, walk_length=80, window=5, neg_samples=5, learning_rate=0.025, epochs=1)
     t0 = time.perf_counter()
     off, adj = pkg.graph.n2v_csr_from_edges(n, *er_edges(n, m))
@@ -56,16 +86,32 @@ def bench_node2vec(pkg, args):
               "embedding_bits_identical": bool(og_g.n == 3000 and np.array_equal(pe.view(np.int32), oe.view(np.int32))),
               "pairs_identical": bool(pst["pairs"] == opairs)}
 
+    def train():
+        if world > 1:  # config 4: walks of every batch split over the ranks, samples all-gathered (RCCL), replicas apply
+            return pkg.parallel.node2vec_train_distributed(off, adj, dim, device=dev, **prm)
+        return pkg.node2vec_train(off, adj, dim, mode=pkg.N2V_BATCHED, device=dev, **prm)
+
+    def barrier():
+        if dist is not None:
+            import torch
+
+            dist.barrier()
+            torch.cuda.synchronize()
+
     for _ in range(args.warmup):
-        pkg.node2vec_train(off, adj, dim, mode=pkg.N2V_BATCHED, **prm)
+        train()
     walls, devs, pairs = [], [], 0
     for _ in range(args.steps):
+        barrier()
         t0 = time.perf_counter()
-        emb, st = pkg.node2vec_train(off, adj, dim, mode=pkg.N2V_BATCHED, **prm)
-        walls.append(time.perf_counter() - t0)
-        devs.append(st["device_ms"])
+        emb, st = train()
+        barrier()
+        walls.append(_max_over_ranks(dist, args, time.perf_counter() - t0))
+        devs.append(_max_over_ranks(dist, args, st["device_ms"]))
         pairs = st["pairs"]
     wall, dev_ms = float(np.mean(walls)), float(np.mean(devs))
+    if rank != 0:
+        return None
     # SGNS reads+writes (1+neg) context rows and the centre row per pair: (2(1+neg)+2)·dim·4 B;
     # the walk adds deg(cur)·4 B per step
     steps_walk = n * prm["num_walks"] * (prm["walk_length"] - 1)
@@ -82,13 +128,16 @@ def bench_node2vec(pkg, args):
     cpu_s = time.perf_counter() - t0
     return {
         "metric": "Node2Vec (center, context) SGNS pairs/sec incl. walk generation, 1M-node / 20M-edge graph, dim 128",
-        "value": pairs / wall, "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": wall * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "value": pairs / wall, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"node2vec: ER G(n,m) seed 42, {n} nodes, {m} edge draws -> {len(adj)} directed adjacency "
                                f"entries; p=q=1, dim {dim}, window 5, neg 5, lr 0.025, 10 walks x 80, 1 epoch; "
                                f"batch-synchronous schedule (MN_N2V_BATCHED, default batch)",
-                   "nodes": n, "adjacency_entries": int(len(adj)), "pairs": int(pairs), "graph_build_s": gen_s},
+                   "nodes": n, "adjacency_entries": int(len(adj)), "pairs": int(pairs), "graph_build_s": gen_s,
+                   "parallelism": "single GPU" if world == 1 else
+                                  f"data-parallel over {world} ranks ({args.backend}): walk/error phase split, samples all-gathered in walk "
+                                  f"order, every replica applies the batch (embeddings bit-identical to 1 GPU)"},
         "parity_vs_oracle": parity,
         "embedding_norm_check": float(np.abs(np.linalg.norm(emb[:1000], axis=1) - 1.0).max()),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -103,9 +152,10 @@ def bench_node2vec(pkg, args):
 
 def bench_leiden(pkg, args):
     n = args.leiden_nodes
+    rank, world, dist, dev = _dist_ctx(args)  # run_leiden does not shard (1 GPU): N > 1 = N independent replicas
     t0 = time.perf_counter()
     s, d, truth = pkg.lfr.lfr_like(n, 40, min(200, n // 10), 0.3)
-    g = pkg.graph.graph_from_edges(n, s, d)
+    g = pkg.graph.graph_from_edges(n, s, d, device=dev)
     gen_s = time.perf_counter() - t0
     E = len(s)
     for _ in range(args.warmup):
@@ -114,9 +164,12 @@ def bench_leiden(pkg, args):
     for _ in range(args.steps):
         t0 = time.perf_counter()
         comm, q, st = g.leiden(1.0, "both", pkg.LEIDEN_BATCHED)
-        walls.append(time.perf_counter() - t0)
+        walls.append(_max_over_ranks(dist, args, time.perf_counter() - t0))
         devs.append(st["device_ms"])
     wall, dev_ms = float(np.mean(walls)), float(np.mean(devs))
+    if rank != 0:
+        g.close()
+        return None
     sweeps = st["move_sweeps"] + st["refine_sweeps"]
     # per sweep E_dir·(4+8+4) B (target, weight, community gather) + N·20 B; unweighted graphs carry no
     # weight array on the device, so 8 B of that is not read — kept in the figure as the survey defines it
@@ -149,7 +202,7 @@ def bench_leiden(pkg, args):
         return float(2 * mi / (ha + hb))
     out = {
         "metric": "Leiden (local moving + refinement, run_leiden) input edges/sec on a 10M-edge LFR-like graph",
-        "value": E / wall, "unit": "edges/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "value": E * world / wall, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": f"leiden: LFR-like n={n}, <k>=40, k_max 200, mu=0.3, seed 42 -> {E} edges, unweighted, "
@@ -180,17 +233,29 @@ def main():
     ap.add_argument("--n2v-edges", type=int, default=20_000_000)
     ap.add_argument("--n2v-cpu-nodes", type=int, default=3000)
     ap.add_argument("--leiden-nodes", type=int, default=500_000)
+    ap.add_argument("--gpus", type=int, default=1, help="N > 1: node2vec data-parallel over N ranks (config 4); leiden = N replicas")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--device", type=int, default=-1)
     args = ap.parse_args()
+    from bench import spawn_ranks_if_needed
+
+    spawn_ranks_if_needed(args.gpus, os.path.abspath(__file__), sys.argv[1:])
     import muninn_amd
 
     pkg = muninn_amd.pkg
     pkg.lib()  # fails loudly if libmuninn_hip.so is missing — there is no CPU fallback
     if pkg.device_count() < 1:
         raise SystemExit("bench_graph.py: no gfx950 device visible")
-    if args.workload in ("node2vec", "both"):
-        print(json.dumps(bench_node2vec(pkg, args)), flush=True)
-    if args.workload in ("leiden", "both"):
-        print(json.dumps(bench_leiden(pkg, args)), flush=True)
+    for name, fn in (("node2vec", bench_node2vec), ("leiden", bench_leiden)):
+        if args.workload in (name, "both"):
+            line = fn(pkg, args)
+            if line is not None:  # rank 0
+                print(json.dumps(line), flush=True)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MN_ABI_VERSION 1
+#define MN_ABI_VERSION 2
 
 /* src/vec_math.h:13 — values are persisted in "{table}_config" (src/hnsw_vtab.c:189) */
 typedef enum { MN_METRIC_L2 = 0, MN_METRIC_COSINE = 1, MN_METRIC_INNER_PRODUCT = 2 } mn_metric;
@@ -64,8 +64,9 @@ int mn_vec_dist_batch(int metric, int order, const float *query, const float *ro
 
 /* ---- hnsw_algo.c replacements (a5-a12) ---- */
 /* hnsw_create (src/hnsw_algo.c:181-208).  M_max0 = 2M, rng seed 42.  device = HIP ordinal.
- * 2 <= M <= 64 (neighbour rows are fixed-width: up to 128 links at layer 0, walked 64 at a time); NULL + mn_last_error()
- * otherwise, or when no gfx950 device is available (there is no CPU fallback). */
+ * 2 <= M <= 512 (the reference has no upper bound; here a list of 2M + 1 entries is pruned inside one workgroup's LDS;
+ * rows of more than 64 links are walked 64 at a time); NULL + mn_last_error() otherwise, or when no gfx950 device is
+ * available (there is no CPU fallback). */
 mn_index *mn_hnsw_create(int dim, int metric, int M, int ef_construction);
 mn_index *mn_hnsw_create_on(int dim, int metric, int M, int ef_construction, int device);
 /* hnsw_destroy (:210-220) */
@@ -75,7 +76,9 @@ void mn_hnsw_seed_rng(mn_index *idx, unsigned seed);
 /* distance summation order for this index; must be set before the first insert (default SSE) */
 int mn_hnsw_set_order(mn_index *idx, int order);
 
-/* hnsw_insert (:520-666): vector is copied.  0, or -1 on duplicate id / failure. */
+/* hnsw_insert (:520-666): vector is copied.  0, or -1 on duplicate id / failure — including the reference's "table full"
+ * failure (:61-74): its node table grows on the LIVE count while soft-deleted nodes keep their entries, so delete + insert
+ * churn can fill it; as there, the level draw is consumed and nothing else changes. */
 int mn_hnsw_insert(mn_index *idx, int64_t id, const float *vector);
 /* n inserts in one call.  mode MN_BUILD_SEQUENTIAL ≡ n × mn_hnsw_insert; MN_BUILD_BATCHED is the
  * batch-synchronous schedule.  vectors is host [n][dim].  Returns 0 / -1 (nothing inserted on -1). */
@@ -111,7 +114,11 @@ int mn_hnsw_search_batch_dev(mn_index *idx, const float *d_queries, int64_t nq, 
                              int64_t *d_out_ids, float *d_out_dists, int *d_out_counts);
 int mn_hnsw_sync(mn_index *idx);
 
-/* hnsw_delete (:717-805): soft delete + neighbour reconnection.  0 / -1. */
+/* hnsw_delete (:717-805): soft delete + neighbour reconnection.  0 / -1 (absent or already deleted).  Reconnection may
+ * leave a list longer than M_max — the reference's node_add_neighbor grows lists without bound (:142-163) — which the
+ * device rows follow (the table is re-strided when a list outgrows the row; the next insert that touches the list prunes it
+ * back to M_max exactly as the reference does, :601-646).  Only the few rows of the deleted node's neighbours move
+ * between host and device. */
 int mn_hnsw_delete(mn_index *idx, int64_t id);
 
 /* hnsw_get_vector / hnsw_get_node (:226-236): copies dim floats out (index lives in HBM).
@@ -127,7 +134,11 @@ int mn_hnsw_node_level(mn_index *idx, int64_t id);   /* -1 if absent */
 int mn_hnsw_node_deleted(mn_index *idx, int64_t id); /* -1 if absent */
 /* neighbour ids of `id` at `level` in list order; returns the count (may exceed cap), -1 if absent */
 int mn_hnsw_neighbors(mn_index *idx, int64_t id, int level, int64_t *out, int cap);
-/* load path of load_index_from_shadow (src/hnsw_vtab.c:286-341): nodes first, then edges, then entry */
+/* load path of load_index_from_shadow (src/hnsw_vtab.c:286-341): nodes first, then edges, then entry.
+ * Host-side staging only: vectors and rows reach the device in bulk at the next compute call.
+ * mn_hnsw_load_node: 0 = added; 1 = not added because the node table was full or the id is already present — the
+ * reference's loop ignores that failure and carries on without the node (:316), and so should the caller; -1 = error.
+ * mn_hnsw_load_neighbors: lists may be longer than M_max (a database whose deletes grew them); -1 only on a real error. */
 int mn_hnsw_load_node(mn_index *idx, int64_t id, const float *vector, int level, int deleted);
 int mn_hnsw_load_neighbors(mn_index *idx, int64_t id, int level, const int64_t *nbrs, int n);
 int mn_hnsw_set_entry(mn_index *idx, int64_t entry_point, int max_level);
@@ -138,7 +149,9 @@ int mn_hnsw_slot_count(mn_index *idx);
 int mn_hnsw_export_nodes(mn_index *idx, int64_t *ids, int *levels, int *deleted); /* each [slot_count] */
 int mn_hnsw_export_vectors(mn_index *idx, float *out);                             /* [slot_count][dim] */
 /* neighbour rows of every slot at `level` as slot indices, -1 padded: out is [slot_count][width];
- * rows of nodes whose level < `level` are all -1.  *width = 2M at level 0, M above. */
+ * rows of nodes whose level < `level` are all -1.  *width = mn_hnsw_row_width(idx, level): 2M at level 0, M above,
+ * more once a delete or a loaded database has grown a list past that. */
+int mn_hnsw_row_width(mn_index *idx, int level);
 int mn_hnsw_export_links(mn_index *idx, int level, int *out, int *width);
 
 /* The set of nodes the reference's xUpdate would have re-persisted (src/hnsw_vtab.c:755-768: the new

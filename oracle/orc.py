@@ -334,6 +334,13 @@ class Ref(_IndexBase):
     def delete(self, id):
         return self.R.hnsw_delete(self.h, int(id))
 
+    def add_neighbors(self, id, level, nbrs):
+        """node_add_neighbor(id, level, nbr) for every nbr, as the shadow-table loader does (src/hnsw_vtab.c:333-336)."""
+        nbrs = np.ascontiguousarray(nbrs, np.int64)
+        src = np.full(len(nbrs), int(id), np.int64)
+        lev = np.full(len(nbrs), int(level), np.int32)
+        return self.R.ref_load_edges(self.h, len(nbrs), src, nbrs, lev)
+
     @property
     def node_count(self):
         return self.R.ref_node_count(self.h)

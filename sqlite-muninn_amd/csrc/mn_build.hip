@@ -32,7 +32,7 @@ __global__ void k_link_forward(MnDevIndex ix, MnLinkArgs a, int max_tuples) {
         return;
     const int W = a.level == 0 ? ix.W0 : ix.WU;
     int n = a.nsel[(size_t)j * a.nlev + a.level];
-    const int *sel = a.sel + ((size_t)j * a.nlev + a.level) * ix.W0;
+    const int *sel = a.sel + ((size_t)j * a.nlev + a.level) * ix.M0;
     int *row = row_ptr(ix, s, a.level);
     for (int i = 0; i < W; i++)
         row[i] = i < n ? sel[i] : -1;
@@ -75,7 +75,7 @@ __global__ void k_link_scatter(MnLinkArgs a, int max_tuples) {
 }
 
 template <int ORDER, int NCH>
-__global__ void __launch_bounds__(64) k_link_reverse(MnDevIndex ix, MnLinkArgs a) {
+__global__ void __launch_bounds__(64) k_link_reverse(MnDevIndex ix, MnLinkArgs a, int LW) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
     if ((int)blockIdx.x >= a.counters[1])
@@ -83,10 +83,10 @@ __global__ void __launch_bounds__(64) k_link_reverse(MnDevIndex ix, MnLinkArgs a
     const int t = a.touched[blockIdx.x];
     const int W = a.level == 0 ? ix.W0 : ix.WU;
     const int M_max = a.M_max;
-    int *list = reinterpret_cast<int *>(smem);         // [192]  (a row of up to 128 links + the new one)
-    float *nd = reinterpret_cast<float *>(list + 192); // [192]
-    int *mn = reinterpret_cast<int *>(nd + 192);       // [192]
-    float *q = reinterpret_cast<float *>(mn + 192);    // [ld]
+    int *list = reinterpret_cast<int *>(smem);        // [LW]  (the row, up to its full capacity, + the new link)
+    float *nd = reinterpret_cast<float *>(list + LW); // [LW]
+    int *mn = reinterpret_cast<int *>(nd + LW);       // [LW]
+    float *q = reinterpret_cast<float *>(mn + LW);    // [ld]
 
     const float *tv = ix.vectors + (size_t)t * ix.ld;
     for (int i = lane; i < ix.ld; i += 64)
@@ -133,11 +133,11 @@ __global__ void __launch_bounds__(64) k_link_reverse(MnDevIndex ix, MnLinkArgs a
         if (nc <= M_max)
             continue;
         // ── prune to M_max (:601-646) ──
-        prune_row<ORDER, NCH, false>(ix, q, tnorm, list, nd, mn, nc, M_max, a.level, lane);
+        prune_any<ORDER, NCH, false>(ix, q, tnorm, list, nd, mn, nc, M_max, a.level, lane);
         nc = M_max;
     }
     // stage the finished row
-    int *out = a.newrows + (size_t)blockIdx.x * ix.W0;
+    int *out = a.newrows + (size_t)blockIdx.x * ix.WX;
     for (int i = lane; i < W; i += 64)
         out[i] = i < nc ? list[i] : -1;
 }
@@ -149,7 +149,7 @@ __global__ void k_link_commit(MnDevIndex ix, MnLinkArgs a) {
     int t = a.touched[i];
     const int W = a.level == 0 ? ix.W0 : ix.WU;
     int *row = row_ptr(ix, t, a.level);
-    const int *src = a.newrows + (size_t)i * ix.W0;
+    const int *src = a.newrows + (size_t)i * ix.WX;
     for (int j = threadIdx.x; j < W; j += blockDim.x)
         row[j] = src[j];
     if (threadIdx.x == 0)
@@ -169,8 +169,11 @@ static int pick_nch_b(int ld) {
 
 template <int ORDER, int NCH>
 static void launch_reverse(const MnDevIndex &ix, const MnLinkArgs &a, int max_tuples, hipStream_t st) {
-    size_t lds = 192 * 3 * sizeof(int) + (size_t)ix.ld * sizeof(float);
-    hipLaunchKernelGGL((k_link_reverse<ORDER, NCH>), dim3(max_tuples), dim3(64), lds, st, ix, a);
+    int LW = (ix.WX + 64 + 63) & ~63; // the row is staged 64 links at a time, then one more is appended
+    if (LW < 192)
+        LW = 192;
+    size_t lds = (size_t)LW * 3 * sizeof(int) + (size_t)ix.ld * sizeof(float);
+    hipLaunchKernelGGL((k_link_reverse<ORDER, NCH>), dim3(max_tuples), dim3(64), lds, st, ix, a, LW);
 }
 
 void mn_launch_link(const MnDevIndex &ix, const MnLinkArgs &a, int max_tuples, hipStream_t st) {

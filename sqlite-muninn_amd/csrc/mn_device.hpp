@@ -4,8 +4,11 @@
 // int32); int64 rowids only appear at the API boundary (ids[slot]).
 //   vectors  [cap][ld]   f32, ld = round_up(dim,4), pad = 0          (src/hnsw_algo.h:19 HnswNode.vector)
 //   norms    [cap]       f32 |v|² in the index's summation order (cosine only)
-//   links0   [cap][W0]   int32 neighbour slots at layer 0, list order preserved, -1 padded; W0 = 2M
-//   links_up [rows][WU]  int32, layers ≥ 1; node's layer l lives in row up_off[slot] + (l-1); WU = M
+//   links0   [cap][W0]   int32 neighbour slots at layer 0, list order preserved, -1 padded; W0 ≥ M0 = 2M
+//   links_up [rows][WU]  int32, layers ≥ 1; node's layer l lives in row up_off[slot] + (l-1); WU ≥ MU = M
+//   W0 / WU are row STRIDES; M0 / MU are the reference's M_max0 / M (src/hnsw_algo.c:188: the length a list is pruned
+//   back to).  They are equal until a delete's reconnection (:775-782) or a loaded database needs a longer list than
+//   M_max — the reference grows lists without bound there — at which point the host re-strides the table.
 //   up_off   [cap]       int32 first pool row of the node, -1 when level == 0
 //   levels   [cap] int8, deleted [cap] u8, ids [cap] int64, dirty [cap] u8 (nodes to re-persist)
 #pragma once
@@ -27,7 +30,9 @@ struct MnDevIndex {
     unsigned char *dirty; // [cap] set by the insert kernels on every node whose rows they (re)wrote: the persist set
     const long long *ids;
     int dim, ld, metric, order;
-    int W0, WU;
+    int W0, WU; // row strides (capacity of a list)
+    int M0, MU; // M_max at layer 0 / above: inserts select at most this many and prune over-full lists back to it
+    int WX;     // max(W0, WU): stride of per-row scratch that serves both kinds of row
     int n_slots;
     int n_pool_rows;
 };
@@ -46,7 +51,7 @@ struct MnSearchArgs {
     float *out_dists;   // [nq][k]
     int *out_counts;    // [nq]
     // build outputs: per (query, level) the first min(found, M_max) results
-    int *sel;          // [nq][nlev][W0]
+    int *sel;          // [nq][nlev][M0]
     int *nsel;         // [nq][nlev]
     int nlev;          // max_level + 1 at batch start
     const int *up_bm_index; // build: per query, index of its upper-layer bitmap block or -1
@@ -89,7 +94,7 @@ struct MnLinkArgs {
     int level, M_max;
     int nq, nlev;
     const int *query_slots; // [nq] slot of batch node j
-    const int *sel;         // [nq][nlev][W0]
+    const int *sel;         // [nq][nlev][M0]
     const int *nsel;        // [nq][nlev]
     // scratch (all device)
     int *t_target;  // [max_tuples]
@@ -100,11 +105,13 @@ struct MnLinkArgs {
     int *binoff;    // [n_slots]
     int *touched;   // [max_tuples]
     int *bins;      // [max_tuples]
-    int *newrows;   // [max_tuples][W0]
+    int *newrows;   // [max_tuples][WX]
 };
 void mn_launch_link(const MnDevIndex &ix, const MnLinkArgs &a, int max_tuples, hipStream_t st);
 
-// exact sequential inserts (mn_seq.hip)
+// exact sequential inserts (mn_seq.hip); LDS of the one workgroup (must stay within MN_LDS_LIMIT)
+#define MN_LDS_LIMIT (64 * 1024)
+size_t mn_insert_seq_lds_bytes(const MnDevIndex &ix);
 void mn_launch_insert_seq(const MnDevIndex &ix, const int *d_slots, int n, int ef, int *d_state, unsigned *bitmap0,
                           long long bm0_words, unsigned *bitmap_up, long long bmu_words, uint2 *cand_ovf, int cand_gcap,
                           uint2 *res_ovf, int res_gcap, unsigned long long *counters, hipStream_t st);

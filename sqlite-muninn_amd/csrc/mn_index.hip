@@ -12,7 +12,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
+
+#define MN_MAX_M 512        // longest supported M (lists of 2M + 1 entries are pruned in LDS)
+#define MN_MAX_ROW 2048     // longest neighbour list a row may grow to through deletes / loads (same LDS budget)
 
 static thread_local std::string g_err;
 
@@ -70,6 +74,7 @@ struct mn_index {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int dim = 0, ld = 0, metric = 0, order = MN_ORDER_SSE, M = 0, M_max0 = 0, efc = 0;
+    int W0 = 0, WU = 0; // row strides of links0 / links_up (>= M_max0 / M; grown when a list must exceed M_max)
     double level_mult = 0;
     int64_t entry_id = -1;
     int max_level = -1;
@@ -95,6 +100,11 @@ struct mn_index {
     std::vector<int> h_links0, h_links_up;
     bool host_links_valid = true;   // host mirror == device
     bool dev_links_stale = false;   // host mirror modified, device not yet updated
+    bool dev_links_all = false;     // ... and the whole table has to go (load, re-stride); otherwise only h_dirty_rows
+    std::vector<std::pair<int, int>> h_dirty_rows; // (slot, level) rows of the mirror edited since the last push
+    // nodes appended by mn_hnsw_load_node whose vectors wait on the host for one bulk upload
+    std::vector<float> load_vecs;
+    int load_first = -1;
     // workspaces
     DevBuf<unsigned> ws_bm0, ws_bmu;
     DevBuf<uint2> ws_cand, ws_res;
@@ -112,6 +122,7 @@ struct mn_index {
     std::vector<int> staged; // mn_hnsw_batch_stage: slots added but not yet searched / linked
     DevBuf<int> d_staged;
     long long last_spec_searched = 0; // searches the last speculative build ran (≥ nodes inserted)
+    bool broken = false; // an insert failed after its kernels had begun to rewrite link rows: nothing can be trusted
     mn_launch_stats last = {0, 0, 0, 0};
 };
 
@@ -182,7 +193,74 @@ static void ht_grow(mn_index *x) { // src/hnsw_algo.c:76-91: rehash in old-table
     x->ht_cap = nc;
 }
 
+// The reference grows its table on the LIVE count (src/hnsw_algo.c:527) while soft-deleted nodes keep their entries, so
+// delete + insert churn can fill it; ht_insert then fails ("table full", :61-74) and hnsw_insert returns -1.  Index of the
+// first of n inserts that would hit that, or -1.
+static int64_t first_table_full(const mn_index *x, int64_t n) {
+    long long cap = x->ht_cap, live = x->node_count, occ = x->n_slots;
+    for (int64_t i = 0; i < n; i++) {
+        if (live * 10 > cap * 7)
+            cap *= 2;
+        if (occ >= cap)
+            return i;
+        live++;
+        occ++;
+    }
+    return -1;
+}
+
+// what insert_impl needs to take back the nodes it appended when it fails before any link row was rewritten
+struct InsertUndo {
+    int first, node_count, max_level, n_pool_rows, old_cap = 0, grew_at = -1;
+    unsigned rng;
+    int64_t entry_id;
+    std::vector<int> old_ht; // the table as it stood just before the call's first growth
+};
+
+static void ht_erase_newest(std::vector<int> &t, int cap, const std::vector<int64_t> &ids, int slot) {
+    // entries are erased newest first, so each one is the last link of its probe chain: clearing it restores the table
+    int s = ht_hash(ids[slot], cap);
+    for (int i = 0; i < cap; i++) {
+        int p = (s + i) & (cap - 1);
+        if (t[p] == slot) {
+            t[p] = -1;
+            return;
+        }
+    }
+}
+
+static void undo_insert(mn_index *x, InsertUndo &u) {
+    int hi = x->n_slots;
+    if (u.grew_at >= 0) {
+        x->ht.swap(u.old_ht);
+        x->ht_cap = u.old_cap;
+        hi = u.grew_at;
+    }
+    for (int s = hi - 1; s >= u.first; s--)
+        ht_erase_newest(x->ht, x->ht_cap, x->ids, s);
+    x->ids.resize((size_t)u.first);
+    x->levels.resize((size_t)u.first);
+    x->deleted.resize((size_t)u.first);
+    x->up_off.resize((size_t)u.first);
+    x->n_slots = u.first;
+    x->n_pool_rows = u.n_pool_rows;
+    x->node_count = u.node_count;
+    x->rng_state = u.rng;
+    x->entry_id = u.entry_id;
+    x->max_level = u.max_level;
+    x->meta_uploaded = std::min(x->meta_uploaded, u.first);
+    x->staged.clear();
+    if (x->host_links_valid) {
+        x->h_links0.resize((size_t)x->n_slots * x->W0);
+        x->h_links_up.resize((size_t)x->n_pool_rows * x->WU);
+    }
+}
+
 static int use_device(mn_index *x) {
+    if (x->broken) {
+        set_err("index unusable: an earlier insert failed after it had begun to rewrite neighbour rows");
+        return -1;
+    }
     HIPCHK(hipSetDevice(x->device));
     return 0;
 }
@@ -202,8 +280,11 @@ static MnDevIndex dev_view(mn_index *x) {
     v.ld = x->ld;
     v.metric = x->metric;
     v.order = x->order;
-    v.W0 = x->M_max0;
-    v.WU = x->M;
+    v.W0 = x->W0;
+    v.WU = x->WU;
+    v.M0 = x->M_max0;
+    v.MU = x->M;
+    v.WX = std::max(x->W0, x->WU);
     v.n_slots = x->n_slots;
     v.n_pool_rows = x->n_pool_rows;
     return v;
@@ -233,11 +314,14 @@ static int host_add_node(mn_index *x, int64_t id, int level, int deleted) {
         return -1;
     }
     if (x->host_links_valid) {
-        x->h_links0.resize((size_t)x->n_slots * x->M_max0, -1);
-        x->h_links_up.resize((size_t)x->n_pool_rows * x->M, -1);
+        x->h_links0.resize((size_t)x->n_slots * x->W0, -1);
+        x->h_links_up.resize((size_t)x->n_pool_rows * x->WU, -1);
     }
     return s;
 }
+
+// upload n vectors (host [n][dim]) into slots [first, first+n), zero padded to ld, and their norms
+static int upload_vectors(mn_index *x, int first, const float *vecs, int n);
 
 // make device buffers large enough for the host tables and upload metadata of new slots
 static int sync_meta(mn_index *x) {
@@ -245,8 +329,8 @@ static int sync_meta(mn_index *x) {
     size_t ns = (size_t)x->n_slots;
     if (x->d_vectors.reserve(ns * x->ld, true, st)) return -1;
     if (x->d_norms.reserve(ns, true, st)) return -1;
-    if (x->d_links0.reserve(ns * x->M_max0, true, st, 0xFF)) return -1;
-    if (x->d_links_up.reserve((size_t)std::max(1, x->n_pool_rows) * x->M, true, st, 0xFF)) return -1;
+    if (x->d_links0.reserve(ns * x->W0, true, st, 0xFF)) return -1;
+    if (x->d_links_up.reserve((size_t)std::max(1, x->n_pool_rows) * x->WU, true, st, 0xFF)) return -1;
     if (x->d_up_off.reserve(ns, true, st)) return -1;
     if (x->d_levels.reserve(ns, true, st)) return -1;
     if (x->d_deleted.reserve(ns, true, st)) return -1;
@@ -261,10 +345,17 @@ static int sync_meta(mn_index *x) {
         HIPCHK(hipStreamSynchronize(st)); // host vectors may be reallocated by later appends
         x->meta_uploaded = x->n_slots;
     }
+    if (!x->load_vecs.empty()) { // vectors of loaded nodes (mn_hnsw_load_node): one upload for the lot
+        std::vector<float> v;
+        v.swap(x->load_vecs);
+        const int first = x->load_first;
+        x->load_first = -1;
+        if (upload_vectors(x, first, v.data(), (int)(v.size() / (size_t)x->dim)))
+            return -1;
+    }
     return 0;
 }
 
-// upload n vectors (host [n][dim]) into slots [first, first+n), zero padded to ld, and their norms
 static int upload_vectors(mn_index *x, int first, const float *vecs, int n) {
     hipStream_t st = x->stream;
     if (x->ld == x->dim) {
@@ -282,46 +373,84 @@ static int upload_vectors(mn_index *x, int first, const float *vecs, int n) {
     return 0;
 }
 
+static size_t d_row_off(const mn_index *x, int slot, int level) { // element offset of a row inside d_links0 / d_links_up
+    return level == 0 ? (size_t)slot * x->W0 : ((size_t)x->up_off[slot] + (level - 1)) * x->WU;
+}
+
 static int pull_links(mn_index *x) {
     if (x->host_links_valid)
         return 0;
-    x->h_links0.assign((size_t)x->n_slots * x->M_max0, -1);
-    x->h_links_up.assign((size_t)x->n_pool_rows * x->M, -1);
-    if (x->n_slots)
-        HIPCHK(hipMemcpyAsync(x->h_links0.data(), x->d_links0.p, x->h_links0.size() * sizeof(int), hipMemcpyDeviceToHost,
-                              x->stream));
-    if (x->n_pool_rows)
-        HIPCHK(hipMemcpyAsync(x->h_links_up.data(), x->d_links_up.p, x->h_links_up.size() * sizeof(int),
-                              hipMemcpyDeviceToHost, x->stream));
+    x->h_links0.assign((size_t)x->n_slots * x->W0, -1);
+    x->h_links_up.assign((size_t)x->n_pool_rows * x->WU, -1);
+    const size_t n0 = std::min(x->h_links0.size(), x->d_links0.cap), nu = std::min(x->h_links_up.size(), x->d_links_up.cap);
+    if (n0)
+        HIPCHK(hipMemcpyAsync(x->h_links0.data(), x->d_links0.p, n0 * sizeof(int), hipMemcpyDeviceToHost, x->stream));
+    if (nu)
+        HIPCHK(hipMemcpyAsync(x->h_links_up.data(), x->d_links_up.p, nu * sizeof(int), hipMemcpyDeviceToHost, x->stream));
     HIPCHK(hipStreamSynchronize(x->stream));
     x->host_links_valid = true;
     x->dev_links_stale = false;
+    x->dev_links_all = false;
+    x->h_dirty_rows.clear();
     return 0;
 }
+
+static int *h_row(mn_index *x, int slot, int level, int *W);
 
 static int push_links(mn_index *x) {
     if (!x->dev_links_stale)
         return 0;
     if (sync_meta(x))
         return -1;
-    if (x->n_slots)
-        HIPCHK(hipMemcpyAsync(x->d_links0.p, x->h_links0.data(), x->h_links0.size() * sizeof(int), hipMemcpyHostToDevice,
-                              x->stream));
-    if (x->n_pool_rows)
-        HIPCHK(hipMemcpyAsync(x->d_links_up.p, x->h_links_up.data(), x->h_links_up.size() * sizeof(int),
-                              hipMemcpyHostToDevice, x->stream));
+    if (x->dev_links_all) {
+        if (x->n_slots)
+            HIPCHK(hipMemcpyAsync(x->d_links0.p, x->h_links0.data(), x->h_links0.size() * sizeof(int), hipMemcpyHostToDevice,
+                                  x->stream));
+        if (x->n_pool_rows)
+            HIPCHK(hipMemcpyAsync(x->d_links_up.p, x->h_links_up.data(), x->h_links_up.size() * sizeof(int),
+                                  hipMemcpyHostToDevice, x->stream));
+    } else {
+        for (const auto &r : x->h_dirty_rows) { // a delete edits a few dozen rows: send those, not the table
+            int W;
+            const int *row = h_row(x, r.first, r.second, &W);
+            int *dst = (r.second == 0 ? x->d_links0.p : x->d_links_up.p) + d_row_off(x, r.first, r.second);
+            HIPCHK(hipMemcpyAsync(dst, row, (size_t)W * sizeof(int), hipMemcpyHostToDevice, x->stream));
+        }
+    }
     HIPCHK(hipStreamSynchronize(x->stream));
     x->dev_links_stale = false;
+    x->dev_links_all = false;
+    x->h_dirty_rows.clear();
     return 0;
 }
 
 static int *h_row(mn_index *x, int slot, int level, int *W) {
     if (level == 0) {
-        *W = x->M_max0;
-        return x->h_links0.data() + (size_t)slot * x->M_max0;
+        *W = x->W0;
+        return x->h_links0.data() + (size_t)slot * x->W0;
     }
-    *W = x->M;
-    return x->h_links_up.data() + ((size_t)x->up_off[slot] + (level - 1)) * x->M;
+    *W = x->WU;
+    return x->h_links_up.data() + ((size_t)x->up_off[slot] + (level - 1)) * x->WU;
+}
+
+// Give the rows of one kind (layer 0, or the layers above) a longer stride.  Needs the full mirror; the device copy is
+// dropped and rebuilt from it at the next push (fresh buffers, so that rows of future slots read as empty).
+static int restride(mn_index *x, bool layer0, int newW) {
+    if (pull_links(x))
+        return -1;
+    std::vector<int> &h = layer0 ? x->h_links0 : x->h_links_up;
+    const int oldW = layer0 ? x->W0 : x->WU;
+    const size_t rows = layer0 ? (size_t)x->n_slots : (size_t)x->n_pool_rows;
+    std::vector<int> nh(rows * (size_t)newW, -1);
+    for (size_t r = 0; r < rows; r++)
+        memcpy(nh.data() + r * newW, h.data() + r * oldW, (size_t)oldW * sizeof(int));
+    h.swap(nh);
+    (layer0 ? x->W0 : x->WU) = newW;
+    (void)hipStreamSynchronize(x->stream);
+    (layer0 ? x->d_links0 : x->d_links_up).release();
+    x->dev_links_stale = true;
+    x->dev_links_all = true;
+    return 0;
 }
 
 static int h_row_count(const int *row, int W) {
@@ -376,20 +505,17 @@ extern "C" int mn_vec_dist_batch(int metric, int order, const float *query, cons
     if (n <= 0)
         return 0;
     int ld = (dim + 3) & ~3;
-    float *dq = nullptr, *dr = nullptr, *dout = nullptr;
-    HIPCHK(hipMalloc(&dq, (size_t)dim * sizeof(float)));
-    HIPCHK(hipMalloc(&dr, (size_t)n * ld * sizeof(float)));
-    HIPCHK(hipMalloc(&dout, (size_t)n * sizeof(float)));
-    HIPCHK(hipMemcpy(dq, query, (size_t)dim * sizeof(float), hipMemcpyHostToDevice));
-    HIPCHK(hipMemset(dr, 0, (size_t)n * ld * sizeof(float)));
-    HIPCHK(hipMemcpy2D(dr, (size_t)ld * sizeof(float), rows, (size_t)dim * sizeof(float), (size_t)dim * sizeof(float),
+    DevBuf<float> dq, dr, dout; // released on every path
+    struct Rel { DevBuf<float> &a, &b, &c; ~Rel() { a.release(); b.release(); c.release(); } } rel{dq, dr, dout};
+    if (dq.reserve((size_t)dim, false, nullptr) || dr.reserve((size_t)n * ld, false, nullptr) || dout.reserve((size_t)n, false, nullptr))
+        return -1;
+    HIPCHK(hipMemcpy(dq.p, query, (size_t)dim * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(dr.p, 0, (size_t)n * ld * sizeof(float)));
+    HIPCHK(hipMemcpy2D(dr.p, (size_t)ld * sizeof(float), rows, (size_t)dim * sizeof(float), (size_t)dim * sizeof(float),
                        (size_t)n, hipMemcpyHostToDevice));
-    mn_launch_dist_batch(metric, order, dq, dr, n, dim, ld, dout, nullptr);
+    mn_launch_dist_batch(metric, order, dq.p, dr.p, n, dim, ld, dout.p, nullptr);
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(out, dout, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
-    (void)hipFree(dq);
-    (void)hipFree(dr);
-    (void)hipFree(dout);
+    HIPCHK(hipMemcpy(out, dout.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -400,8 +526,8 @@ extern "C" mn_index *mn_hnsw_create_on(int dim, int metric, int M, int ef_constr
         set_err("mn_hnsw_create: bad parameters");
         return nullptr;
     }
-    if (2 * M > 128) {
-        set_err("mn_hnsw_create: M=%d not supported on device (a level-0 row of 2M links is walked in at most two 64-link passes)", M);
+    if (M > MN_MAX_M) { // the reference has no upper bound; here a list (2M + 1 entries, three LDS arrays) must fit a workgroup's LDS
+        set_err("mn_hnsw_create: M=%d exceeds this build's limit of %d", M, MN_MAX_M);
         return nullptr;
     }
     int ndev = 0;
@@ -416,6 +542,8 @@ extern "C" mn_index *mn_hnsw_create_on(int dim, int metric, int M, int ef_constr
     x->metric = metric;
     x->M = M;
     x->M_max0 = 2 * M; // src/hnsw_algo.c:188
+    x->W0 = x->M_max0;
+    x->WU = M;
     x->efc = ef_construction;
     x->level_mult = 1.0 / log((double)M); // :192
     x->ht.assign(256, -1);                // :197
@@ -469,15 +597,24 @@ extern "C" int mn_hnsw_set_order(mn_index *x, int order) {
 
 // ───────────────────────── search ─────────────────────────
 
+// allocations of a search launch over nq queries (the only step of it that can fail for lack of memory)
+static int reserve_search_ws(mn_index *x, int64_t nq, int ef) {
+    hipStream_t st = x->stream;
+    const int64_t bm0_words = ((int64_t)x->n_slots + 31) / 32;
+    if (x->ws_bm0.reserve((size_t)nq * bm0_words, false, st)) return -1;
+    if (x->ws_cand.reserve((size_t)nq * (16 * ef + 1024), false, st)) return -1;
+    if (x->ws_res.reserve((size_t)nq * (ef > MN_RES_LDS ? ef : 8), false, st)) return -1;
+    if (x->ws_counters.reserve(4, false, st)) return -1;
+    return 0;
+}
+
 static int prepare_search_ws(mn_index *x, int64_t nq, int ef, MnSearchArgs &a, bool zero_counters = true) {
     hipStream_t st = x->stream;
     a.bm0_words = ((int64_t)x->n_slots + 31) / 32;
     a.cand_gcap = 16 * ef + 1024;
     a.res_gcap = ef > MN_RES_LDS ? ef : 8;
-    if (x->ws_bm0.reserve((size_t)nq * a.bm0_words, false, st)) return -1;
-    if (x->ws_cand.reserve((size_t)nq * a.cand_gcap, false, st)) return -1;
-    if (x->ws_res.reserve((size_t)nq * a.res_gcap, false, st)) return -1;
-    if (x->ws_counters.reserve(4, false, st)) return -1;
+    if (reserve_search_ws(x, nq, ef))
+        return -1;
     HIPCHK(hipMemsetAsync(x->ws_bm0.p, 0, (size_t)nq * a.bm0_words * sizeof(unsigned), st));
     if (zero_counters)
         HIPCHK(hipMemsetAsync(x->ws_counters.p, 0, 4 * sizeof(unsigned long long), st));
@@ -540,13 +677,18 @@ extern "C" int mn_hnsw_search_batch_dev(mn_index *x, const float *d_queries, int
     const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(nq, (int64_t)((8ull << 30) / per_q)));
     const int entry_slot = ht_find(x, x->entry_id);
     MnDevIndex v = dev_view(x);
+    // every allocation happens here, for the largest chunk: nothing between the two event records can fail half-way
+    if (reserve_search_ws(x, chunk, ef))
+        return -1;
     HIPCHK(hipEventRecord(x->ev0, st));
     for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
         const int64_t m = std::min<int64_t>(chunk, nq - q0);
         MnSearchArgs a;
         memset(&a, 0, sizeof(a));
-        if (prepare_search_ws(x, m, ef, a, q0 == 0))
+        if (prepare_search_ws(x, m, ef, a, q0 == 0)) { // (sized above: memsets only)
+            (void)hipEventRecord(x->ev1, st);
             return -1;
+        }
         a.queries = d_queries + (size_t)q0 * x->dim;
         a.nq = m;
         a.k = k;
@@ -685,7 +827,7 @@ static int link_batch(mn_index *x, const std::vector<int> &slots, const int *d_s
     if (x->lk_binoff.reserve((size_t)x->d_ids.cap, false, st)) return -1;
     if (x->lk_touched.reserve((size_t)max_tuples, false, st)) return -1;
     if (x->lk_bins.reserve((size_t)max_tuples, false, st)) return -1;
-    if (x->lk_newrows.reserve((size_t)max_tuples * x->M_max0, false, st)) return -1;
+    if (x->lk_newrows.reserve((size_t)max_tuples * std::max(x->W0, x->WU), false, st)) return -1;
     MnLinkArgs la;
     memset(&la, 0, sizeof(la));
     la.nq = nq;
@@ -709,12 +851,7 @@ static int link_batch(mn_index *x, const std::vector<int> &slots, const int *d_s
         mn_launch_link(v, la, mt, st);
     }
     HIPCHK(hipGetLastError());
-    if (fetch_counters(x))
-        return -1;
-    if (x->last.last_n_overflow) {
-        set_err("mn_hnsw_insert: %lld searches exceeded heap workspace", (long long)x->last.last_n_overflow);
-        return -1;
-    }
+    HIPCHK(hipStreamSynchronize(st)); // (the searches' heap workspace was checked before this step: run_batch / batch_search)
     x->host_links_valid = false;
     for (int j = 0; j < nq; j++) {
         int lv = x->levels[slots[j]];
@@ -726,14 +863,23 @@ static int link_batch(mn_index *x, const std::vector<int> &slots, const int *d_s
     return 0;
 }
 
-static int run_batch(mn_index *x, const std::vector<int> &slots) {
+static int run_batch(mn_index *x, const std::vector<int> &slots, bool *links_touched) {
     const int nq = (int)slots.size();
+    *links_touched = false;
     if (nq == 0)
         return 0;
     const int nlev = x->max_level + 1;
     MnSearchArgs a;
     if (build_search(x, slots.data(), nq, a, 0))
         return -1;
+    // the search half only reads the graph: a failure up to here leaves it untouched (the caller takes the nodes back)
+    if (fetch_counters(x)) // synchronises
+        return -1;
+    if (x->last.last_n_overflow) {
+        set_err("mn_hnsw_insert: %lld searches exceeded heap workspace", (long long)x->last.last_n_overflow);
+        return -1;
+    }
+    *links_touched = true;
     return link_batch(x, slots, x->ws_qslots.p, nlev, x->ws_sel.p, x->ws_nsel.p);
 }
 
@@ -742,6 +888,11 @@ static int run_sequential(mn_index *x, const std::vector<int> &slots) {
     const int n = (int)slots.size();
     if (n == 0)
         return 0;
+    if (mn_insert_seq_lds_bytes(dev_view(x)) > MN_LDS_LIMIT) {
+        set_err("mn_hnsw_insert: dimension %d with neighbour lists of up to %d entries does not fit the insert kernel's LDS", x->dim,
+                std::max(x->W0, x->WU));
+        return -1;
+    }
     MnSearchArgs a;
     memset(&a, 0, sizeof(a));
     if (prepare_search_ws(x, 1, x->efc, a))
@@ -876,21 +1027,50 @@ static int insert_impl(mn_index *x, const int64_t *ids, const float *vectors, in
                 return -1;
             }
     }
+    {
+        const int64_t f = first_table_full(x, n);
+        if (f >= 0) {
+            // the reference: random_level() is drawn, ht_insert fails, hnsw_insert returns -1 (src/hnsw_algo.c:532-540)
+            if (n == 1)
+                (void)random_level(x);
+            set_err("mn_hnsw_insert: node table full (%d entries incl. soft-deleted nodes; the table grows on the live count only)",
+                    x->ht_cap);
+            return -1;
+        }
+    }
     if (push_links(x))
         return -1;
     const int first = x->n_slots;
+    InsertUndo undo;
+    undo.first = first;
+    undo.node_count = x->node_count;
+    undo.max_level = x->max_level;
+    undo.n_pool_rows = x->n_pool_rows;
+    undo.rng = x->rng_state;
+    undo.entry_id = x->entry_id;
     std::vector<int> slots((size_t)n);
     for (int64_t i = 0; i < n; i++) {
-        if (x->node_count * 10 > x->ht_cap * 7) // :527
+        if (x->node_count * 10 > x->ht_cap * 7) { // :527
+            if (undo.grew_at < 0) {
+                undo.grew_at = x->n_slots;
+                undo.old_ht = x->ht;
+                undo.old_cap = x->ht_cap;
+            }
             ht_grow(x);
+        }
         int level = random_level(x); // :532
         slots[i] = host_add_node(x, ids[i], level, 0);
+        if (slots[i] < 0) { // (first_table_full rules this out)
+            undo_insert(x, undo);
+            set_err("mn_hnsw_insert: node table insert failed for id %lld", (long long)ids[i]);
+            return -1;
+        }
         x->node_count++;
     }
-    if (sync_meta(x))
+    if (sync_meta(x) || upload_vectors(x, first, vectors, (int)n)) {
+        undo_insert(x, undo);
         return -1;
-    if (upload_vectors(x, first, vectors, (int)n))
-        return -1;
+    }
     HIPCHK(hipMemsetAsync(x->d_dirty.p + first, 1, (size_t)n, x->stream)); // new nodes are always persisted
     size_t pos = 0;
     if (x->entry_id == -1) { // :544-548 first node just becomes the entry point
@@ -911,15 +1091,29 @@ static int insert_impl(mn_index *x, const int64_t *ids, const float *vectors, in
         x->staged.swap(rest);
         return 0;
     }
+    int rc;
+    bool links_touched = true; // the exact modes edit rows in place from the first insert on
     if (mode == MN_BUILD_SEQUENTIAL) {
         // same result either way; speculation pays once several inserts are queued (MN_SPECULATE=0 turns it off)
         const char *sp = getenv("MN_SPECULATE");
         const bool spec_on = !(sp && atoi(sp) == 0);
-        if (spec_on && rest.size() >= 4 && x->M_max0 <= 64) // (k_spec_commit stages ≤ 64 targets of ≤ 64 links)
-            return run_speculative(x, rest);
-        return run_sequential(x, rest);
+        // (k_spec_commit stages ≤ 64 targets of ≤ 64 links, on rows that never outgrew M_max)
+        if (spec_on && rest.size() >= 4 && x->W0 <= 64 && x->W0 == x->M_max0 && x->WU == x->M)
+            rc = run_speculative(x, rest);
+        else
+            rc = run_sequential(x, rest);
+    } else {
+        rc = run_batch(x, rest, &links_touched);
     }
-    return run_batch(x, rest);
+    if (rc != 0) {
+        // "nothing inserted on -1": take the nodes back while the graph is still as it was; past that point the rows of
+        // existing nodes may already name the new slots, and the index refuses further use instead of serving them
+        if (!links_touched)
+            undo_insert(x, undo);
+        else if (!rest.empty())
+            x->broken = true;
+    }
+    return rc;
 }
 
 // The persist set of src/hnsw_vtab.c:755-768, accumulated over any number of inserts: every new node and
@@ -1036,104 +1230,144 @@ extern "C" int mn_hnsw_batch_link(mn_index *x, const int *d_sel, const int *d_ns
     return link_batch(x, slots, x->d_staged.p, x->max_level + 1, d_sel, d_nsel);
 }
 
-// ───────────────────────── delete (cold path, host-side list surgery on the mirror) ─────────────────────────
+// ───────────────────────── delete (cold path, host-side list surgery) ─────────────────────────
+// hnsw_delete edits the lists of the deleted node's neighbours only (a few dozen rows).  Those rows are worked on as
+// plain growable lists — the reference's node_add_neighbor grows a list without bound (src/hnsw_algo.c:142-163) — read
+// from the host mirror when it is current and otherwise row by row from HBM, and written back the same way.  Only when
+// a list ends up longer than the row stride is the table re-strided (rare: reconnection under heavy deletion at tiny M).
 
-static int h_add(mn_index *x, int slot, int level, int nbr) { // node_add_neighbor, src/hnsw_algo.c:142-163
-    if (level > x->levels[slot])
-        return -1;
-    int W;
-    int *row = h_row(x, slot, level, &W);
-    int n = h_row_count(row, W);
-    for (int i = 0; i < n; i++)
-        if (row[i] == nbr)
-            return 0;
-    if (n >= W)
-        return -2; // the reference would grow the list; fixed-width device rows cannot
-    row[n] = nbr;
-    return 0;
-}
-
-static void h_remove(mn_index *x, int slot, int level, int nbr) { // :166-177 swap with last
-    if (level > x->levels[slot])
-        return;
-    int W;
-    int *row = h_row(x, slot, level, &W);
-    int n = h_row_count(row, W);
-    for (int i = 0; i < n; i++)
-        if (row[i] == nbr) {
-            row[i] = row[n - 1];
-            row[n - 1] = -1;
-            return;
+struct RowEdit {
+    mn_index *x;
+    std::unordered_map<unsigned long long, std::vector<int>> rows;
+    std::vector<unsigned long long> modified;
+    static unsigned long long key(int slot, int level) { return ((unsigned long long)level << 32) | (unsigned)slot; }
+    std::vector<int> *get(int slot, int level) {
+        const unsigned long long k = key(slot, level);
+        auto it = rows.find(k);
+        if (it != rows.end())
+            return &it->second;
+        const int W = level == 0 ? x->W0 : x->WU;
+        std::vector<int> buf((size_t)W, -1);
+        if (x->host_links_valid) {
+            int w2;
+            memcpy(buf.data(), h_row(x, slot, level, &w2), (size_t)W * sizeof(int));
+        } else {
+            const int *src = (level == 0 ? x->d_links0.p : x->d_links_up.p) + d_row_off(x, slot, level);
+            if (hipMemcpy(buf.data(), src, (size_t)W * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+                return nullptr;
         }
+        buf.resize((size_t)h_row_count(buf.data(), W));
+        return &(rows[k] = std::move(buf));
+    }
+    void touch(int slot, int level) { modified.push_back(key(slot, level)); }
+};
+
+static int grown_stride(int W, int need) { // a little headroom, so that a run of deletes does not re-stride every time
+    int nw = std::max(need, W + std::max(16, W / 2));
+    return (nw + 15) & ~15;
 }
 
 extern "C" int mn_hnsw_delete(mn_index *x, int64_t id) { // src/hnsw_algo.c:717-805
     if (use_device(x))
         return -1;
-    int s = ht_find(x, id);
+    const int s = ht_find(x, id);
     if (s < 0 || x->deleted[s])
         return -1;
-    if (pull_links(x))
+    if (push_links(x) || sync_meta(x)) // rows are read from whichever copy is current
         return -1;
-    // a refused delete must leave the index untouched: journal every row before it is edited (only rows of the
-    // deleted node's neighbours are)
-    struct Saved { int *row; std::vector<int> old; };
-    std::vector<Saved> journal;
-    x->deleted[s] = 1;
-    x->node_count--;
-    int min_conn = x->M / 2;
-    bool overflow = false;
-    for (int l = 0; l <= x->levels[s] && !overflow; l++) {
-        int W;
-        int *row = h_row(x, s, l, &W);
-        int nc = h_row_count(row, W);
-        std::vector<int> former(row, row + nc);
-        for (int i = 0; i < nc; i++)
-            if (l <= x->levels[former[i]]) {
-                int Wf;
-                int *fr = h_row(x, former[i], l, &Wf);
-                journal.push_back({fr, std::vector<int>(fr, fr + Wf)});
-            }
-        for (int i = 0; i < nc; i++)
-            if (!x->deleted[former[i]])
-                h_remove(x, former[i], l, s);
-        for (int i = 0; i < nc && !overflow; i++) {
-            int orphan = former[i];
-            if (x->deleted[orphan] || l > x->levels[orphan])
+    HIPCHK(hipStreamSynchronize(x->stream));
+    RowEdit ed{x, {}, {}};
+    const int min_conn = x->M / 2;
+    auto live_at = [&](int n, int l) { return !x->deleted[n] && l <= x->levels[n]; };
+    // (the reference flags the node deleted first, :722; nothing below looks at that flag for s itself)
+    for (int l = 0; l <= x->levels[s]; l++) {
+        std::vector<int> *own = ed.get(s, l);
+        if (!own) {
+            set_err("mn_hnsw_delete: cannot read neighbour rows");
+            return -1;
+        }
+        const std::vector<int> former(*own); // :731-738
+        const int nc = (int)former.size();
+        for (int i = 0; i < nc; i++) { // :741-746 node_remove_neighbor: swap with last (:166-177)
+            const int nb = former[i];
+            if (x->deleted[nb] || l > x->levels[nb])
                 continue;
-            int Wo;
-            int *orow = h_row(x, orphan, l, &Wo);
-            if (h_row_count(orow, Wo) >= min_conn)
+            std::vector<int> *r = ed.get(nb, l);
+            if (!r)
+                return -1;
+            for (size_t k = 0; k < r->size(); k++)
+                if ((*r)[k] == s) {
+                    (*r)[k] = r->back();
+                    r->pop_back();
+                    ed.touch(nb, l);
+                    break;
+                }
+        }
+        for (int i = 0; i < nc; i++) { // :750-785 reconnect neighbours left with fewer than M/2 links
+            const int orphan = former[i];
+            if (!live_at(orphan, l))
                 continue;
-            for (int j = 0; j < nc && h_row_count(orow, Wo) < min_conn; j++) {
+            std::vector<int> *orow = ed.get(orphan, l);
+            if (!orow)
+                return -1;
+            if ((int)orow->size() >= min_conn)
+                continue;
+            for (int j = 0; j < nc && (int)orow->size() < min_conn; j++) {
                 if (i == j)
                     continue;
-                int cand = former[j];
-                if (x->deleted[cand] || l > x->levels[cand])
+                const int cand = former[j];
+                if (!live_at(cand, l))
                     continue;
-                bool already = false;
-                for (int k = 0; k < h_row_count(orow, Wo); k++)
-                    if (orow[k] == cand) {
-                        already = true;
-                        break;
-                    }
-                if (!already) {
-                    if (h_add(x, orphan, l, cand) == -2 || h_add(x, cand, l, orphan) == -2) {
-                        overflow = true;
-                        break;
-                    }
+                if (std::find(orow->begin(), orow->end(), cand) != orow->end())
+                    continue;
+                orow->push_back(cand); // node_add_neighbor(orphan, l, cand): not present (checked above)
+                ed.touch(orphan, l);
+                std::vector<int> *crow = ed.get(cand, l);
+                if (!crow)
+                    return -1;
+                orow = ed.get(orphan, l); // (the map may have rehashed)
+                if (std::find(crow->begin(), crow->end(), orphan) == crow->end()) { // node_add_neighbor skips duplicates (:147-150)
+                    crow->push_back(orphan);
+                    ed.touch(cand, l);
                 }
             }
         }
     }
-    if (overflow) {
-        for (size_t i = journal.size(); i-- > 0;)
-            std::copy(journal[i].old.begin(), journal[i].old.end(), journal[i].row);
-        x->deleted[s] = 0;
-        x->node_count++;
-        set_err("mn_hnsw_delete: reconnection would exceed the fixed neighbour-row width (unsupported)");
+    // longest list per kind of row → does the table need a longer stride?
+    int need0 = 0, needU = 0;
+    for (unsigned long long k : ed.modified) {
+        const int len = (int)ed.rows[k].size();
+        ((k >> 32) == 0 ? need0 : needU) = std::max((k >> 32) == 0 ? need0 : needU, len);
+    }
+    if (std::max(need0, needU) > MN_MAX_ROW) {
+        set_err("mn_hnsw_delete: a neighbour list would grow to %d entries (limit %d)", std::max(need0, needU), MN_MAX_ROW);
         return -1;
     }
+    if (need0 > x->W0 && restride(x, true, grown_stride(x->W0, need0)))
+        return -1;
+    if (needU > x->WU && restride(x, false, grown_stride(x->WU, needU)))
+        return -1;
+    std::sort(ed.modified.begin(), ed.modified.end());
+    ed.modified.erase(std::unique(ed.modified.begin(), ed.modified.end()), ed.modified.end());
+    for (unsigned long long k : ed.modified) {
+        const int slot = (int)(k & 0xffffffffu), level = (int)(k >> 32);
+        const std::vector<int> &list = ed.rows[k];
+        const int W = level == 0 ? x->W0 : x->WU;
+        std::vector<int> padded((size_t)W, -1);
+        std::copy(list.begin(), list.end(), padded.begin());
+        if (x->host_links_valid) {
+            int w2;
+            memcpy(h_row(x, slot, level, &w2), padded.data(), (size_t)W * sizeof(int));
+            if (!x->dev_links_all)
+                x->h_dirty_rows.push_back({slot, level});
+            x->dev_links_stale = true;
+        } else {
+            int *dst = (level == 0 ? x->d_links0.p : x->d_links_up.p) + d_row_off(x, slot, level);
+            HIPCHK(hipMemcpy(dst, padded.data(), (size_t)W * sizeof(int), hipMemcpyHostToDevice));
+        }
+    }
+    x->deleted[s] = 1; // :722-723
+    x->node_count--;
     if (x->entry_id == id) { // :790-802 scan in hash-table order, strict >
         x->entry_id = -1;
         x->max_level = -1;
@@ -1145,7 +1379,6 @@ extern "C" int mn_hnsw_delete(mn_index *x, int64_t id) { // src/hnsw_algo.c:717-
             }
         }
     }
-    x->dev_links_stale = true;
     if (s < x->meta_uploaded)
         HIPCHK(hipMemcpy(x->d_deleted.p + s, &x->deleted[s], 1, hipMemcpyHostToDevice));
     return 0;
@@ -1158,6 +1391,8 @@ extern "C" int mn_hnsw_get_vector(mn_index *x, int64_t id, float *out) {
         return -1;
     int s = ht_find(x, id);
     if (s < 0 || x->deleted[s])
+        return -1;
+    if (!x->load_vecs.empty() && sync_meta(x))
         return -1;
     HIPCHK(hipMemcpy(out, x->d_vectors.p + (size_t)s * x->ld, (size_t)x->dim * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
@@ -1181,17 +1416,17 @@ extern "C" int mn_hnsw_neighbors(mn_index *x, int64_t id, int level, int64_t *ou
     int s = ht_find(x, id);
     if (s < 0 || level > x->levels[s])
         return -1;
-    int W = level == 0 ? x->M_max0 : x->M;
-    int tmp[128];
+    int W = level == 0 ? x->W0 : x->WU;
+    std::vector<int> tmp;
     const int *row;
     if (x->host_links_valid) {
         row = h_row(x, s, level, &W);
     } else { // one row straight from HBM: do not pull the whole graph for a point read
-        const int *src = level == 0 ? x->d_links0.p + (size_t)s * W
-                                    : x->d_links_up.p + ((size_t)x->up_off[s] + (level - 1)) * W;
+        tmp.resize((size_t)W);
         HIPCHK(hipStreamSynchronize(x->stream));
-        HIPCHK(hipMemcpy(tmp, src, (size_t)W * sizeof(int), hipMemcpyDeviceToHost));
-        row = tmp;
+        HIPCHK(hipMemcpy(tmp.data(), (level == 0 ? x->d_links0.p : x->d_links_up.p) + d_row_off(x, s, level),
+                         (size_t)W * sizeof(int), hipMemcpyDeviceToHost));
+        row = tmp.data();
     }
     int n = h_row_count(row, W);
     for (int i = 0; i < n && i < cap; i++)
@@ -1209,13 +1444,23 @@ extern "C" int mn_hnsw_load_node(mn_index *x, int64_t id, const float *vector, i
     if (x->node_count * 10 > x->ht_cap * 7) // src/hnsw_vtab.c:304-306
         ht_grow(x);
     int s = host_add_node(x, id, level, deleted);
-    if (s < 0)
-        return -1;
+    if (s < 0) {
+        // Table full (it grows on the LIVE count while soft-deleted rows keep their entries): the reference's load loop
+        // ignores ht_insert's failure and carries on without the node (src/hnsw_vtab.c:316); so does this one.
+        // A duplicate id takes the same path there.
+        return 1;
+    }
     if (!deleted)
         x->node_count++;
-    if (sync_meta(x))
-        return -1;
-    return upload_vectors(x, s, vector, 1);
+    // host only: the vector waits for one bulk upload (sync_meta) instead of a copy + two synchronisations per row
+    if (x->load_vecs.empty())
+        x->load_first = s;
+    x->load_vecs.insert(x->load_vecs.end(), vector, vector + x->dim);
+    x->dev_links_stale = true; // new (empty) rows of the mirror
+    x->dev_links_all = true;
+    if (x->load_vecs.size() * sizeof(float) >= (256u << 20))
+        return sync_meta(x);
+    return 0;
 }
 
 extern "C" int mn_hnsw_load_neighbors(mn_index *x, int64_t id, int level, const int64_t *nbrs, int n) {
@@ -1230,12 +1475,27 @@ extern "C" int mn_hnsw_load_neighbors(mn_index *x, int64_t id, int level, const 
         int t = ht_find(x, nbrs[i]);
         if (t < 0)
             continue;
-        if (h_add(x, s, level, t) == -2) {
-            set_err("mn_hnsw_load_neighbors: more than %d neighbours at level %d", level == 0 ? x->M_max0 : x->M, level);
-            return -1;
+        int W;
+        int *row = h_row(x, s, level, &W);
+        int cnt = h_row_count(row, W);
+        bool present = false; // node_add_neighbor (src/hnsw_algo.c:142-163): no duplicates, grows as needed
+        for (int k = 0; k < cnt; k++)
+            present |= row[k] == t;
+        if (present)
+            continue;
+        if (cnt >= W) { // a list longer than M_max (left by deletes in the database that is being loaded)
+            if (cnt + 1 > MN_MAX_ROW) {
+                set_err("mn_hnsw_load_neighbors: more than %d neighbours at level %d", MN_MAX_ROW, level);
+                return -1;
+            }
+            if (restride(x, level == 0, grown_stride(W, cnt + 1)))
+                return -1;
+            row = h_row(x, s, level, &W);
         }
+        row[cnt] = t;
     }
     x->dev_links_stale = true;
+    x->dev_links_all = true;
     return 0;
 }
 
@@ -1263,18 +1523,22 @@ extern "C" int mn_hnsw_export_vectors(mn_index *x, float *out) {
         return -1;
     if (x->n_slots == 0)
         return 0;
+    if (sync_meta(x))
+        return -1;
     HIPCHK(hipStreamSynchronize(x->stream));
     HIPCHK(hipMemcpy2D(out, (size_t)x->dim * sizeof(float), x->d_vectors.p, (size_t)x->ld * sizeof(float),
                        (size_t)x->dim * sizeof(float), (size_t)x->n_slots, hipMemcpyDeviceToHost));
     return 0;
 }
 
+extern "C" int mn_hnsw_row_width(mn_index *x, int level) { return level == 0 ? x->W0 : x->WU; }
+
 extern "C" int mn_hnsw_export_links(mn_index *x, int level, int *out, int *width) {
     if (use_device(x))
         return -1;
     if (pull_links(x))
         return -1;
-    const int W = level == 0 ? x->M_max0 : x->M;
+    const int W = level == 0 ? x->W0 : x->WU;
     *width = W;
     for (int s = 0; s < x->n_slots; s++) {
         int *dst = out + (size_t)s * W;
@@ -1312,7 +1576,7 @@ extern "C" int64_t mn_hnsw_edges_of(mn_index *x, const int64_t *ids, int n, int6
     if (R == 0)
         return 0;
     hipStream_t st = x->stream;
-    const int W0 = x->M_max0;
+    const int W0 = std::max(x->W0, x->WU); // rows of either kind are written with the common stride WX
     if (x->er_slot.reserve((size_t)R, false, st)) return -1;
     if (x->er_level.reserve((size_t)R, false, st)) return -1;
     if (x->er_nbr.reserve((size_t)R * W0, false, st)) return -1;

@@ -235,10 +235,10 @@ DEVI void beam_query(const MnDevIndex &ix, const MnSearchArgs &a, const long lon
             if (l > 0)
                 bm = a.bitmap_up + ((size_t)a.up_bm_index[qi] * a.max_level + (l - 1)) * a.bmu_words;
             beam_layer<ORDER, NCH, false, WIDE>(ix, w, cand, res, bm, cur, l, a.ef, lane);
-            const int M_max = (l == 0) ? ix.W0 : ix.WU;
+            const int M_max = (l == 0) ? ix.M0 : ix.MU;
             int count = res.size;
             int keep = count < M_max ? count : M_max;
-            int *sel = a.sel + ((size_t)qi * a.nlev + l) * ix.W0;
+            int *sel = a.sel + ((size_t)qi * a.nlev + l) * ix.M0;
             int first = cur;
             for (int i = count - 1; i >= 0; i--) {
                 uint2 it = heap_pop(res, lane);
@@ -311,7 +311,7 @@ template <int ORDER, int NCH>
 static void launch_beam(const MnDevIndex &ix, const MnSearchArgs &a, bool build, hipStream_t st) {
     dim3 grid((unsigned)a.nq), block(64);
     size_t lds = mn_search_lds_bytes(ix.ld, ORDER == MN_ORDER_SSE_V && a.use_tile);
-    const bool wide = ix.W0 > 64; // M > 32: rows walked in two 64-link passes
+    const bool wide = ix.WX > 64; // rows of more than 64 links (M > 32, or lists grown by deletes) are walked in 64-link passes
     const char *co = getenv("MN_COOP"); // MN_COOP=0: always one wavefront per query
     if (a.nq <= 128 && !(co && atoi(co) == 0)) {
         const size_t base = (lds + 15) & ~(size_t)15;
@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(64)
     __builtin_amdgcn_wave_barrier();
     int W;
     const int *row = link_row(ix, s, level, W);
-    for (int c0 = 0; c0 < ix.W0; c0 += 64) { // 64 links per pass (rows are packed: no gaps before the -1 padding)
+    for (int c0 = 0; c0 < ix.WX; c0 += 64) { // 64 links per pass (rows are packed: no gaps before the -1 padding)
         const int p = c0 + lane;
         const int nb = p < W ? row[p] : -1;
         const int n = __popcll(__ballot(nb >= 0));
@@ -389,9 +389,9 @@ __global__ void __launch_bounds__(64)
             if (lane < n && ix.deleted[myslot])
                 d = 0.0f;
         }
-        if (p < ix.W0) {
-            out_nbr[(size_t)r * ix.W0 + p] = nb;
-            out_dist[(size_t)r * ix.W0 + p] = d;
+        if (p < ix.WX) {
+            out_nbr[(size_t)r * ix.WX + p] = nb;
+            out_dist[(size_t)r * ix.WX + p] = d;
         }
     }
 }

@@ -1,6 +1,9 @@
 // MN-RU prune of one over-full neighbour row (src/hnsw_algo.c:601-646), shared by the exact sequential
 // insert (mn_seq.hip), its speculative variant (mn_spec.hip) and the batch link step (mn_build.hip).  One wavefront;
-// the row's nc = W+1 entries (W ≤ 128, so nc ≤ 129) sit in LDS, lane i owns entries i, i+64 and i+128.
+// the list's nc entries sit in LDS.  Up to 192 entries (any M ≤ 64 whose lists never outgrew M_max) lane i owns
+// entries i, i+64 and i+128 in registers (prune_row); longer lists — M > 64, or lists that a delete's reconnection or
+// a loaded database grew past M_max, which the reference allows without bound (:142-163,:775-782) — take the same
+// decisions from LDS alone (prune_row_long).  prune_any picks.
 #pragma once
 #include "mn_dist.hpp"
 
@@ -16,12 +19,25 @@ DEVI const int *prune_row_ptr(const MnDevIndex &ix, int node, int level) {
     return ix.links_up + ((size_t)ix.up_off[node] + (level - 1)) * ix.WU;
 }
 
-// MN(t, nn) = |list ∩ N(nn)| (src/hnsw_algo.c:460-475); list in LDS, nn's row (≤ 128 links: two per lane) from HBM
+// MN(t, nn) = |list ∩ N(nn)| (src/hnsw_algo.c:460-475); list in LDS, nn's row from HBM (two links per lane when it has
+// at most 128, otherwise 64 at a time: a row holds no duplicates, so an entry is found in at most one pass)
 template <bool COH> DEVI int prune_mutual(const MnDevIndex &ix, const int *list, int nc, int nn, int level, int lane) {
     if (ix.levels[nn] < level)
         return 0;
     const int W = level == 0 ? ix.W0 : ix.WU;
     const int *row = prune_row_ptr(ix, nn, level);
+    if (W > 128) {
+        int c = 0;
+        for (int c0 = 0; c0 < W; c0 += 64) {
+            const int mine = c0 + lane < W ? prune_ld<COH>(row + c0 + lane) : -1;
+            if (!__ballot(mine >= 0))
+                break; // rows are packed: nothing after the first empty pass
+            for (int i = 0; i < nc; i++)
+                if (__ballot(mine >= 0 && mine == list[i]))
+                    c++;
+        }
+        return c;
+    }
     const int mine0 = lane < W ? prune_ld<COH>(row + lane) : -1;
     const int mine1 = lane + 64 < W ? prune_ld<COH>(row + lane + 64) : -1;
     int c = 0;
@@ -32,6 +48,9 @@ template <bool COH> DEVI int prune_mutual(const MnDevIndex &ix, const int *list,
     }
     return c;
 }
+
+template <bool COH>
+DEVI void prune_ties(const MnDevIndex &ix, int *list, float *nd, int *mn, int nc, int keep, int level, int lane);
 
 // list[0..nc) → list[0..keep) = the kept neighbours in the reference's order. tq = the row owner's vector
 // (LDS), tnorm its cached |t|². nd/mn: LDS scratch of ≥ 192 entries each; lane i owns entries i, i+64, i+128
@@ -89,7 +108,13 @@ DEVI int prune_row(const MnDevIndex &ix, const float *tq, float tnorm, int *list
     }
     if (!TIES)
         return 1;
-    // tie path: mutual-neighbour counts (:613-616), then the reference's selection sort verbatim (:620-639)
+    prune_ties<COH>(ix, list, nd, mn, nc, keep, level, lane);
+    return 0;
+}
+
+// tie path: mutual-neighbour counts (:613-616), then the reference's selection sort verbatim (:620-639)
+template <bool COH>
+DEVI void prune_ties(const MnDevIndex &ix, int *list, float *nd, int *mn, int nc, int keep, int level, int lane) {
     for (int j = 0; j < nc; j++) {
         const int nn = list[j];
         const int c = ix.deleted[nn] ? -1 : prune_mutual<COH>(ix, list, nc, nn, level, lane);
@@ -117,5 +142,60 @@ DEVI int prune_row(const MnDevIndex &ix, const float *tq, float tnorm, int *list
         }
     }
     __builtin_amdgcn_wave_barrier();
+}
+
+// The same prune for a list of any length (nd / mn: LDS scratch of nc entries rounded up to 64).
+template <int ORDER, int NCH, bool COH, bool TIES = true>
+DEVI int prune_row_long(const MnDevIndex &ix, const float *tq, float tnorm, int *list, float *nd, int *mn, int nc, int keep,
+                        int level, int lane) {
+    for (int c0 = 0; c0 < nc; c0 += 64) { // :606-612 distances from the row's owner, 64 rows per pass
+        const int n = nc - c0 < 64 ? nc - c0 : 64;
+        const int sl = lane < n ? list[c0 + lane] : 0;
+        float d = rows_distance<ORDER, NCH>(ix, tq, tnorm, sl, n, lane);
+        if (lane < n && ix.deleted[sl])
+            d = 1e30f;
+        if (lane < n)
+            nd[c0 + lane] = d;
+    }
+    __builtin_amdgcn_wave_barrier();
+    bool clash = false; // all distinct and ordered → the selection sort is an ascending sort: rank and scatter
+    for (int c0 = 0; c0 < nc; c0 += 64) {
+        const int e = c0 + lane;
+        if (e < nc) {
+            const float de = nd[e];
+            int r = 0;
+            for (int x = 0; x < nc; x++) {
+                const float o = nd[x];
+                if (x != e && !(o < de) && !(de < o))
+                    clash = true;
+                r += o < de;
+            }
+            mn[e] = r;
+        }
+    }
+    if (!__ballot(clash)) {
+        __builtin_amdgcn_wave_barrier();
+        int *old = reinterpret_cast<int *>(nd); // the distances are no longer needed: keep the unsorted list there
+        for (int e = lane; e < nc; e += 64)
+            old[e] = list[e];
+        __builtin_amdgcn_wave_barrier();
+        for (int e = lane; e < nc; e += 64)
+            if (mn[e] < keep)
+                list[mn[e]] = old[e];
+        __builtin_amdgcn_wave_barrier();
+        return 0;
+    }
+    if (!TIES)
+        return 1;
+    __builtin_amdgcn_wave_barrier();
+    prune_ties<COH>(ix, list, nd, mn, nc, keep, level, lane);
     return 0;
+}
+
+template <int ORDER, int NCH, bool COH, bool TIES = true>
+DEVI int prune_any(const MnDevIndex &ix, const float *tq, float tnorm, int *list, float *nd, int *mn, int nc, int keep,
+                   int level, int lane) {
+    if (nc <= 192) // uniform
+        return prune_row<ORDER, NCH, COH, TIES>(ix, tq, tnorm, list, nd, mn, nc, keep, level, lane);
+    return prune_row_long<ORDER, NCH, COH, TIES>(ix, tq, tnorm, list, nd, mn, nc, keep, level, lane);
 }

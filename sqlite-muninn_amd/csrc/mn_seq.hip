@@ -24,6 +24,8 @@ struct MnSeqArgs {
     uint2 *res_ovf;
     int res_gcap;
     unsigned long long *counters;
+    int SB; // LDS entries of the selected-list buffer (>= M0)
+    int LW; // LDS entries of each prune array (>= longest list + 1, multiple of 64)
 };
 
 DEVI int *seq_row(const MnDevIndex &ix, int node, int level) {
@@ -39,11 +41,11 @@ __global__ void __launch_bounds__(64) k_insert_seq(MnDevIndex ix, MnSeqArgs a) {
     uint2 *cand_l = reinterpret_cast<uint2 *>(smem);
     uint2 *res_l = cand_l + MN_CAND_LDS;
     int *scratch = reinterpret_cast<int *>(res_l + MN_RES_LDS); // [64]
-    int *selbuf = scratch + 64;                                 // [128]
-    int *list = selbuf + 128;                                   // [192]
-    float *nd = reinterpret_cast<float *>(list + 192);          // [192]
-    int *mn = reinterpret_cast<int *>(nd + 192);                // [192]
-    float *q = reinterpret_cast<float *>(mn + 192);             // [ld]
+    int *selbuf = scratch + 64;                                 // [SB]
+    int *list = selbuf + a.SB;                                  // [LW]
+    float *nd = reinterpret_cast<float *>(list + a.LW);         // [LW]
+    int *mn = reinterpret_cast<int *>(nd + a.LW);               // [LW]
+    float *q = reinterpret_cast<float *>(mn + a.LW);            // [ld]
     float *tv = q + ix.ld;                                      // [ld]
 
     WaveCtx w;
@@ -85,7 +87,8 @@ __global__ void __launch_bounds__(64) k_insert_seq(MnDevIndex ix, MnSeqArgs a) {
 
         const int start = level < maxl ? level : maxl;
         for (int l = start; l >= 0; l--) { // :572-653
-            const int W = l == 0 ? ix.W0 : ix.WU;
+            const int W = l == 0 ? ix.W0 : ix.WU;     // capacity of a row
+            const int M_max = l == 0 ? ix.M0 : ix.MU; // what an over-full list is pruned back to
             unsigned *bm = l == 0 ? a.bitmap0 : a.bitmap_up;
             const long long words = l == 0 ? a.bm0_words : a.bmu_words;
             for (long long i = lane; i < words; i += 64)
@@ -95,7 +98,7 @@ __global__ void __launch_bounds__(64) k_insert_seq(MnDevIndex ix, MnSeqArgs a) {
 
             beam_layer<ORDER, NCH, true, WIDE>(ix, w, cand, res, bm, cur, l, a.ef, lane);
             const int count = res.size;
-            const int nsel = count < W ? count : W; // :511
+            const int nsel = count < M_max ? count : M_max; // :511
             int first = cur;
             for (int i = count - 1; i >= 0; i--) {
                 uint2 itx = heap_pop(res, lane);
@@ -128,25 +131,26 @@ __global__ void __launch_bounds__(64) k_insert_seq(MnDevIndex ix, MnSeqArgs a) {
                 }
                 if (already) // already a neighbour (:147-150)
                     continue;
-                if (cnt < W) {
+                if (cnt < M_max) {
                     if (lane == 0)
                         st_link(trow + cnt, s);
                     continue;
                 }
-                // ── over-full: MN-RU prune of t's list (:601-646) ──
-                const int nc = W + 1;
+                // ── over-full: MN-RU prune of t's list (:601-646).  A list that a delete's reconnection (or a loaded
+                //    database) left longer than M_max is cut back to M_max here, exactly as the reference does ──
+                const int nc = cnt + 1;
                 if (lane == 0)
-                    list[W] = s;
+                    list[cnt] = s;
                 const float *tsrc = ix.vectors + (size_t)t * ix.ld;
                 for (int e = lane; e < ix.ld; e += 64)
                     tv[e] = tsrc[e];
                 __builtin_amdgcn_s_waitcnt(0);
                 __builtin_amdgcn_wave_barrier();
                 const float tnorm = ix.metric == 1 ? ix.norms[t] : 0.0f;
-                prune_row<ORDER, NCH, true>(ix, tv, tnorm, list, nd, mn, nc, W, l, lane);
+                prune_any<ORDER, NCH, true>(ix, tv, tnorm, list, nd, mn, nc, M_max, l, lane);
                 w.n_dist += nc;
-                for (int i = lane; i < W; i += 64)
-                    st_link(trow + i, list[i]);
+                for (int i = lane; i < cnt; i += 64)
+                    st_link(trow + i, i < M_max ? list[i] : -1);
                 __builtin_amdgcn_wave_barrier();
             }
             if (count > 0) // :651-652
@@ -165,6 +169,14 @@ __global__ void __launch_bounds__(64) k_insert_seq(MnDevIndex ix, MnSeqArgs a) {
         if (cand.ovf || res.ovf)
             atomicAdd(&a.counters[2], 1ull);
     }
+}
+
+size_t mn_insert_seq_lds_bytes(const MnDevIndex &ix) {
+    int SB = (ix.M0 + 63) & ~63, LW = (ix.WX + 1 + 63) & ~63;
+    if (LW < 192)
+        LW = 192;
+    return (size_t)(MN_CAND_LDS + MN_RES_LDS) * sizeof(uint2) + (size_t)(64 + SB + 3 * LW) * sizeof(int) +
+           2 * (size_t)ix.ld * sizeof(float);
 }
 
 static int pick_nch_s(int ld) {
@@ -195,10 +207,14 @@ void mn_launch_insert_seq(const MnDevIndex &ix, const int *d_slots, int n, int e
     a.res_ovf = res_ovf;
     a.res_gcap = res_gcap;
     a.counters = counters;
-    size_t lds = (size_t)(MN_CAND_LDS + MN_RES_LDS) * sizeof(uint2) + (64 + 128 + 3 * 192) * sizeof(int) + 2 * (size_t)ix.ld * sizeof(float);
+    a.SB = (ix.M0 + 63) & ~63;
+    a.LW = (ix.WX + 1 + 63) & ~63;
+    if (a.LW < 192)
+        a.LW = 192;
+    const size_t lds = mn_insert_seq_lds_bytes(ix);
 #define MN_SQ(O, N)                                                                            \
     do {                                                                                       \
-        if (ix.W0 > 64)                                                                        \
+        if (ix.WX > 64)                                                                        \
             hipLaunchKernelGGL((k_insert_seq<O, N, true>), dim3(1), dim3(64), lds, st, ix, a); \
         else                                                                                   \
             hipLaunchKernelGGL((k_insert_seq<O, N>), dim3(1), dim3(64), lds, st, ix, a);       \

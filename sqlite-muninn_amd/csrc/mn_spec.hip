@@ -24,7 +24,7 @@ struct MnSpecArgs {
     const int *slots; // [W] the window's nodes in insertion order
     int W;
     int nlev;        // frozen max_level + 1
-    const int *sel;  // [W][nlev][W0]  first min(found, M_max) search results per layer
+    const int *sel;  // [W][nlev][M0]  first min(found, M_max) search results per layer (used only while W0 == M0 <= 64)
     const int *nsel; // [W][nlev]
     const int *readlog; // [W][readcap]
     int readcap;

@@ -453,8 +453,9 @@ static int load_from_shadow(VtabHnsw *v) {
         return rc;
     while (sqlite3_step(st) == SQLITE_ROW) {
         const float *vec = (const float *)sqlite3_column_blob(st, 1);
+        /* 1 = the reference's load loop would have gone on without this node too (node table full, src/hnsw_vtab.c:316) */
         if (!vec || sqlite3_column_bytes(st, 1) != v->dim * (int)sizeof(float) ||
-            mn_hnsw_load_node(v->index, sqlite3_column_int64(st, 0), vec, sqlite3_column_int(st, 2), sqlite3_column_int(st, 3)) != 0) {
+            mn_hnsw_load_node(v->index, sqlite3_column_int64(st, 0), vec, sqlite3_column_int(st, 2), sqlite3_column_int(st, 3)) < 0) {
             sqlite3_finalize(st);
             return SQLITE_ERROR;
         }
@@ -469,8 +470,11 @@ static int load_from_shadow(VtabHnsw *v) {
         int64_t dst = sqlite3_column_int64(st, 1);
         int64_t src = sqlite3_column_int64(st, 0);
         int lv = sqlite3_column_int(st, 2);
-        if (mn_hnsw_node_level(v->index, src) >= lv) /* :333-336 */
-            mn_hnsw_load_neighbors(v->index, src, lv, &dst, 1);
+        if (mn_hnsw_node_level(v->index, src) >= lv && /* :333-336 */
+            mn_hnsw_load_neighbors(v->index, src, lv, &dst, 1) != 0) { /* never drop an edge silently */
+            sqlite3_finalize(st);
+            return SQLITE_ERROR;
+        }
     }
     sqlite3_finalize(st);
     return SQLITE_OK;

@@ -71,6 +71,7 @@ SYMBOLS = [
     ("mn_hnsw_export_nodes", C.c_int, [C.c_void_p, _i64p, _i32p, _i32p]),
     ("mn_hnsw_export_vectors", C.c_int, [C.c_void_p, _f32p]),
     ("mn_hnsw_export_links", C.c_int, [C.c_void_p, C.c_int, _i32p, C.POINTER(C.c_int)]),
+    ("mn_hnsw_row_width", C.c_int, [C.c_void_p, C.c_int]),
     ("mn_hnsw_batch_stage", C.c_int, [C.c_void_p, _i64p, _f32p, C.c_int64]),
     ("mn_hnsw_batch_dims", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("mn_hnsw_batch_search", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -210,7 +211,7 @@ class HnswIndex:
         return self.L.mn_hnsw_node_deleted(self.h, int(id))
 
     def neighbors(self, id, level):
-        buf = np.empty(128, np.int64)
+        buf = np.empty(max(128, self.L.mn_hnsw_row_width(self.h, level)), np.int64)
         n = self.L.mn_hnsw_neighbors(self.h, int(id), level, buf, len(buf))
         return None if n < 0 else buf[:n].tolist()
 
@@ -269,12 +270,12 @@ class HnswIndex:
 
     def export_links(self, level):
         n = self.slot_count
-        M0 = 2 * self.M if level == 0 else self.M
-        out = np.empty((n, M0), np.int32)
+        W = self.L.mn_hnsw_row_width(self.h, level)  # 2M / M, or more once a delete or a loaded database grew a list
+        out = np.empty((n, W), np.int32)
         w = C.c_int(0)
         if self.L.mn_hnsw_export_links(self.h, level, out, C.byref(w)) != 0:
             raise MuninnHipError(_err())
-        assert w.value == M0
+        assert w.value == W
         return out
 
     def take_dirty(self):

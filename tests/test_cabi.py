@@ -27,7 +27,7 @@ def test_library_builds_and_exports_header_symbols(mn):
 
 def test_abi_version_and_metric_parse(mn):
     L = mn.lib()
-    assert L.mn_abi_version() == 1
+    assert L.mn_abi_version() == 2
     assert mn.vec_parse_metric("l2") == 0 and mn.vec_parse_metric("cosine") == 1
     assert mn.vec_parse_metric("inner_product") == 2 and mn.vec_parse_metric("nope") == -1
 

@@ -4,7 +4,7 @@ committed fixtures.  Skipped on the GPU box."""
 import numpy as np
 import pytest
 
-from util import gauss, same_bits
+from util import gauss, overgrown_case, same_bits
 
 
 @pytest.fixture(scope="module")
@@ -37,6 +37,53 @@ def test_random_build_search_delete(ref, seed):
     for k, ef in ((1, 1), (5, 3), (10, 50), (30, 200)):
         a, b = r.search_many(Q, k, ef), o.search_many(Q, k, ef)
         assert np.array_equal(a[0], b[0]) and same_bits(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def test_lists_grow_past_m_max_and_are_pruned_back_by_later_inserts(ref):
+    class R(ref.Ref):  # the reference behind the oracle's load surface
+        def load_neighbors(self, id, level, nbrs):
+            return self.add_neighbors(id, level, nbrs)
+
+    (r, ids, X, gr), (o, _, _, go) = overgrown_case(R), overgrown_case(ref.Oracle)
+    assert gr == go
+    assert max(len(v) for (_, l), v in gr["nbrs"].items() if l == 0) > 4  # grown naturally at layer 0 ...
+    assert max(len(v) for (_, l), v in gr["nbrs"].items() if l > 0) > 2   # ... and above
+    assert r.graph(ids[:1000]) == o.graph(ids[:1000])
+    Q = gauss(30, 2, 77)
+    a, b = r.search_many(Q, 5, 20), o.search_many(Q, 5, 20)
+    assert np.array_equal(a[0], b[0]) and same_bits(a[1], b[1])
+    assert r.insert_many(ids[1000:], X[1000:]) == 0 and o.insert_many(ids[1000:], X[1000:]) == 0
+    assert r.graph(ids) == o.graph(ids)
+    for v in ids[1000::3]:
+        assert r.delete(int(v)) == o.delete(int(v)) == 0
+    assert r.graph(ids) == o.graph(ids)
+
+
+def test_node_table_fills_under_churn_as_in_the_reference(ref):
+    """The table grows on the LIVE count (:527) while soft-deleted nodes keep their entries: delete + insert churn fills
+    the 256-entry table and hnsw_insert fails (ht_insert, :61-74) after consuming its level draw."""
+    d = 4
+    X = gauss(400, d, 5)
+    r, o = ref.Ref(d, "l2", 4, 20), ref.Oracle(d, "l2", 4, 20)
+    rc_r, rc_o = [], []
+    for i in range(150):
+        rc_r.append(r.insert(i + 1, X[i])); rc_o.append(o.insert(i + 1, X[i]))
+    for i in range(150):
+        rc_r.append(r.delete(i + 1)); rc_o.append(o.delete(i + 1))
+    for i in range(150, 400):
+        rc_r.append(r.insert(i + 1, X[i])); rc_o.append(o.insert(i + 1, X[i]))
+    assert rc_r == rc_o and -1 in rc_r[300:]
+    live = [i + 1 for i in range(150, 400) if rc_r[150 + i] == 0]
+    assert r.graph(live) == o.graph(live) and r.node_count == o.node_count
+
+
+def test_large_m_live(ref):
+    n, d, M = 500, 6, 80
+    X = gauss(n, d, 8)
+    ids = np.arange(1, n + 1, dtype=np.int64)
+    r, o = ref.Ref(d, "cosine", M, 150), ref.Oracle(d, "cosine", M, 150)
+    assert r.insert_many(ids, X) == 0 and o.insert_many(ids, X) == 0
+    assert r.graph(ids) == o.graph(ids)
 
 
 def test_pq_trace_live(ref):
