@@ -90,6 +90,48 @@ def gen_vectors(n, dim, seed, dataset, chunk=65536):
     return out
 
 
+def recall_of(found, truth, k):
+    return float(np.mean([len(set(found[i].tolist()) & set(truth[i].tolist())) / k for i in range(len(truth))]))
+
+
+def graph_quality_leg(pkg, args, dev_ord, order, M, EFC, n, datasets, efs):
+    """Is the graph of the batch-synchronous build as good as the reference's one-at-a-time graph?  Same vectors, same
+    parameters, two indexes: MN_BUILD_SEQUENTIAL (bit-identical to the reference's hnsw_insert loop — tests/golden) and
+    the batched schedule bench.py's headline index is built with; recall@k of both against exact ground truth
+    (k_brute_mfma) over ALL queries, at each ef."""
+    D, NQ, K = args.dim, args.nq, args.k
+    out = []
+    for ds in datasets:
+        X = gen_vectors(n, D, 42, ds)
+        Q = gen_vectors(NQ, D, 43, ds)
+        ids = np.arange(1, n + 1, dtype=np.int64)
+        row = {"dataset": ds, "n": n, "dim": D, "queries": NQ, "k": K}
+        truth = None
+        for name, mode in (("exact", "sequential"), ("batched", "batched")):
+            g = pkg.HnswIndex(D, args.metric, M, EFC, order=order, device=dev_ord)
+            t0 = time.perf_counter()
+            rc = g.insert_batch(ids, X, pkg.BUILD_SEQUENTIAL) if mode == "sequential" else g.build(ids, X, 16, 8192)
+            if rc != 0:
+                raise SystemExit("build failed: " + pkg.hnsw._err())
+            g.sync()
+            row[f"{name}_build_vectors_per_s"] = n / (time.perf_counter() - t0)
+            dq = g.dev_malloc(Q.nbytes)
+            g.dev_upload(dq, Q)
+            if truth is None:
+                truth = g.bruteforce_topk(dq, NQ, K)
+            d_ids, d_ds, d_cnt = g.dev_malloc(NQ * K * 8), g.dev_malloc(NQ * K * 4), g.dev_malloc(NQ * 4)
+            for ef in efs:
+                g.search_batch_dev(dq, NQ, K, ef, d_ids, d_ds, d_cnt)
+                g.sync()
+                o = np.empty((NQ, K), np.int64)
+                g.dev_download(o, d_ids)
+                row[f"{name}_recall_ef{ef}"] = recall_of(o, truth, K)
+            g.close()
+        row["max_abs_recall_gap"] = max(abs(row[f"exact_recall_ef{ef}"] - row[f"batched_recall_ef{ef}"]) for ef in efs)
+        out.append(row)
+    return out
+
+
 def recall_target_leg(pkg, args, dev_ord, order, M, EFC, target):
     """north_star's target reads "kNN queries/s at recall@10 >= 0.95": isotropic 768-d Gaussian data cannot reach that
     with the reference's algorithm at any practical ef, so the same measurement is repeated on
@@ -126,7 +168,7 @@ def recall_target_leg(pkg, args, dev_ord, order, M, EFC, target):
         wall = (time.perf_counter() - t0) / 5
         out = np.empty((NQ, K), np.int64)
         g.dev_download(out, d_ids)
-        rec = float(np.mean([len(set(out[i].tolist()) & set(truth[i].tolist())) / K for i in range(nrec)]))
+        rec = recall_of(out[:nrec], truth, K)
         alg = st["last_n_dist"] * D * 4 + st["last_n_expanded"] * (2 * M) * 4 + st["last_n_dist"] * 4
         row = {"ef": ef, "queries_per_s": NQ / wall, "recall_at_10": rec, "n_dist_per_query": st["last_n_dist"] / NQ,
                "kernel_ms": float(np.mean(kms)), "roofline_frac": alg / (np.mean(kms) * 1e-3) / 1e9 / HBM_PEAK_GBS}
@@ -153,7 +195,14 @@ def main():
     ap.add_argument("--metric", default="cosine")
     ap.add_argument("--order", default="sse", choices=["sse", "wave"])
     ap.add_argument("--dataset", default="gaussian", choices=["gaussian", "clustered", "lowrank"])
-    ap.add_argument("--recall-queries", type=int, default=500)
+    ap.add_argument("--recall-queries", type=int, default=-1,
+                    help="queries whose exact top-k (k_brute_mfma, the MFMA GEMM + fused top-k) recall is measured against; -1 = all")
+    ap.add_argument("--quality-n", type=int, default=50_000,
+                    help="N=1: size of the exact-vs-batched graph comparison (two extra builds; 0 = skip)")
+    ap.add_argument("--quality-datasets", default="lowrank", help="comma list of datasets for that comparison")
+    ap.add_argument("--exact-inserts", type=int, default=200,
+                    help="N=1: vectors inserted one at a time (reference semantics) into the full-size index, by the GPU and by "
+                         "the compiled reference on the same graph: build CPU baseline + full-size insert parity (0 = skip)")
     ap.add_argument("--cpu-queries", type=int, default=4000)
     ap.add_argument("--ref-queries", type=int, default=1500,
                     help="queries timed through the compiled reference (oracle/_ref) when it is present")
@@ -196,6 +245,8 @@ def main():
         raise SystemExit("bench.py: no gfx950 device visible")
 
     N, D, NQ, K, EF = args.n, args.dim, args.nq, args.k, args.ef
+    if args.recall_queries < 0:
+        args.recall_queries = NQ
     order = pkg.ORDER_SSE if args.order == "sse" else pkg.ORDER_WAVE
     M, EFC = 16, 200
 
@@ -226,6 +277,7 @@ def main():
     g.sync()
     build_s = time.perf_counter() - t0
     build_s_max = build_s
+    bst = g.build_stats()
     if dist is not None:  # slowest rank's build: the N-GPU build rate is (vectors built by all ranks) / that
         import torch
 
@@ -297,8 +349,11 @@ def main():
     nrec = min(args.recall_queries, NQ)
     recall = None
     if nrec > 0:
+        tb0 = time.perf_counter()
         truth = g.bruteforce_topk(dq, nrec, K)
-        recall = float(np.mean([len(set(out_ids[i].tolist()) & set(truth[i].tolist())) / K for i in range(nrec)]))
+        brute_s = time.perf_counter() - tb0
+        brute_ms = g.last_launch()["last_kernel_ms"]
+        recall = recall_of(out_ids[:nrec], truth, K)
 
     sweep = []
     for ef2 in [int(x) for x in args.ef_sweep.split(",") if x]:
@@ -307,13 +362,15 @@ def main():
         k2, nd2, ne2 = run_steps(3, ef2, collect=True)
         o2 = np.empty((NQ, K), np.int64)
         g.dev_download(o2, d_ids)
-        r2 = float(np.mean([len(set(o2[i].tolist()) & set(truth[i].tolist())) / K for i in range(nrec)])) if nrec else None
+        r2 = recall_of(o2[:nrec], truth, K) if nrec else None
         sweep.append({"ef": ef2, "queries_per_s": NQ / (np.mean(k2) * 1e-3), "recall_at_k": r2, "n_dist_per_query": nd2 / NQ})
 
     # ---- CPU baseline: the oracle (single-threaded port of the reference algorithm) on the SAME
     #      graph and the SAME queries; also a full-size parity check of the returned ids ----
     cpu = None
     parity = None
+    build_cpu = None
+    exact_at_size = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_queries > 0:  # N=1 only (contract)
         from oracle import orc
 
@@ -366,6 +423,30 @@ def main():
                              f"{ref_s:.1f}s of CPU work",
                    "port": {"value": nc / cpu_s, "unit": "queries/s", "cores": 1,
                             "sample": f"{nc} queries, oracle/mn_oracle.c (bitmap visited set), {cpu_s:.1f}s"}}
+            if args.exact_inserts > 0:
+                # the build half: the SAME new vectors inserted one at a time (reference semantics) into the SAME full-size
+                # graph by the compiled reference (1 core) and by the device (MN_BUILD_SEQUENTIAL); both level streams are
+                # re-seeded alike, so the two graphs must stay identical: every new node's lists are compared
+                ni = args.exact_inserts
+                Xn = gen_vectors(ni, D, 4444, args.dataset)
+                idn = np.arange(N + 1, N + 1 + ni, dtype=np.int64)
+                r.R.hnsw_seed_rng(r.h, 987654321)
+                g.seed_rng(987654321)
+                tr = time.perf_counter()
+                rc_ref = r.insert_many(idn, Xn)
+                ref_ins_s = time.perf_counter() - tr
+                tg = time.perf_counter()
+                rc_gpu = g.insert_batch(idn, Xn, pkg.BUILD_SEQUENTIAL)
+                g.sync()
+                gpu_ins_s = time.perf_counter() - tg
+                same = rc_ref == 0 and rc_gpu == 0 and r.graph(idn) == g.graph(idn)
+                build_cpu = {"value": ni / ref_ins_s, "unit": "vectors/s", "cores": 1, "kind": "reference",
+                             "sample": f"{ni} hnsw_insert calls of the compiled reference (src/hnsw_algo.c, gcc -O2) into the "
+                                       f"{N}-node graph built on the GPU, loaded through the reference's own load API; "
+                                       f"{ref_ins_s:.1f}s of CPU work"}
+                exact_at_size = {"inserts": ni, "gpu_exact_vectors_per_s": ni / gpu_ins_s,
+                                 "reference_vectors_per_s": ni / ref_ins_s,
+                                 "new_nodes_lists_identical_to_reference": bool(same)}
             del r
 
     # HBM traffic per launch from the committed PMC passes (profiles/traffic.json), when this exact workload was profiled
@@ -379,11 +460,15 @@ def main():
         pass
 
     at_target = None
+    quality = None
     if rank == 0 and world == 1 and args.recall_target > 0 and args.dataset == "gaussian":
         g.close()  # make room: the second index is the same size
         g = None
         del X
         at_target = recall_target_leg(pkg, args, dev_ord, order, M, EFC, args.recall_target)
+    if rank == 0 and world == 1 and args.quality_n > 0:
+        quality = graph_quality_leg(pkg, args, dev_ord, order, M, EFC, min(args.quality_n, N),
+                                    [d for d in args.quality_datasets.split(",") if d], (128, 256))
 
     if rank == 0:
         total_q = NQ * args.steps * (1 if sharded else world)
@@ -413,6 +498,19 @@ def main():
             # built once per GPU, which does not scale (a single sequential-semantics graph does not shard)
             "build_vectors_per_s_all_gpus": (N * world if sharded else N) / build_s_max,  # jointly built graph: N / time
             "build_s": build_s,
+            "build_exact_at_full_size": exact_at_size,
+            # build side of the roofline: the search half (k_beam<BUILD>) is the dominant kernel of a build; algorithmic bytes
+            # as for search (candidate rows + link rows + visited probes), counted on the device
+            "build_roofline": (lambda ab: {"bound": "hbm", "kernel": "k_beam<BUILD>", "kernel_ms_total": bst["search_ms"],
+                                           "link_ms_total": bst["link_ms"], "batches": bst["batches"],
+                                           "n_dist_per_insert": bst["n_dist"] / max(1, bst["nodes"]),
+                                           "algorithmic_bytes": ab, "achieved": ab / max(bst["search_ms"], 1e-9) / 1e6,
+                                           "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": ab / max(bst["search_ms"], 1e-9) / 1e6 / HBM_PEAK_GBS,
+                                           "search_share_of_build_wall": bst["search_ms"] * 1e-3 / build_s})(
+                bst["n_dist"] * D * 4 + bst["n_expanded"] * (2 * M) * 4 + bst["n_dist"] * 4) if bst["batches"] else None,
+            "build_cpu_baseline": build_cpu,
+            "graph_quality_exact_vs_batched": quality,
             "build_mode": "batch-synchronous (batch <= max(1, n/16), cap 8192); " +
                           ("one graph built jointly: search half of each batch split over the GPUs, selected lists all-gathered, "
                            "every replica links (bit-identical to the 1-GPU build)" if shared_build else
@@ -422,7 +520,13 @@ def main():
             "at_recall_target": at_target,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_beam",
-                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         # also against what a float4 copy kernel reaches on this part
+                         "frac_of_measured_copy_bw": achieved / HBM_COPY_GBS, "measured_copy_bw": HBM_COPY_GBS},
+            "ground_truth": None if recall is None else {
+                "kernel": "k_brute_mfma (v_mfma_f32_32x32x2_f32 GEMM tile + fused top-k)", "queries": nrec,
+                "kernel_ms": brute_ms, "wall_s": brute_s,
+                "tflops": 2.0 * nrec * N * D / (brute_ms * 1e-3) / 1e12 if brute_ms else None},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -176,6 +176,15 @@ typedef struct {
     int64_t last_n_overflow; /* queries whose heaps exceeded workspace (must be 0) */
 } mn_launch_stats;
 int mn_hnsw_last_launch(mn_index *idx, mn_launch_stats *out);
+/* Totals over the batch-synchronous inserts (MN_BUILD_BATCHED / mn_hnsw_build) since the last reset: HIP-event time of
+ * the search half (k_beam<BUILD>, the dominant kernel of a build) and of the link half, with the search half's device
+ * counters — what the build-side roofline of bench.py is computed from. */
+typedef struct {
+    double search_ms, link_ms;
+    int64_t n_dist, n_expanded; /* distance evaluations / neighbour rows read by the searches */
+    int64_t batches, nodes;
+} mn_build_stats;
+int mn_hnsw_build_stats(mn_index *idx, mn_build_stats *out, int reset);
 /* device malloc/free/copies so a non-HIP host (ctypes) can stage HBM-resident inputs */
 void *mn_dev_malloc(mn_index *idx, size_t bytes);
 void mn_dev_free(mn_index *idx, void *p);

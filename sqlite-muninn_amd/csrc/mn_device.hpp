@@ -89,6 +89,11 @@ int mn_launch_search(const MnDevIndex &ix, const MnSearchArgs &a, bool build, hi
 void mn_launch_bruteforce(const MnDevIndex &ix, const float *d_queries, long long nq, int k, long long *d_out_ids,
                           float *d_scratch, hipStream_t st);
 
+// MFMA brute force (mn_brute.hip): k <= 16; scratch = one allocation of mn_brute_mfma_scratch_bytes()
+size_t mn_brute_mfma_scratch_bytes(const MnDevIndex &ix, long long nq, int k, int *n_chunks_out, int *rows_per_chunk_out);
+int mn_launch_bruteforce_mfma(const MnDevIndex &ix, const float *d_queries, long long nq, int k, long long *d_out_ids,
+                              void *scratch, hipStream_t st);
+
 // link kernels for the batched build (mn_build.hip)
 struct MnLinkArgs {
     int level, M_max;

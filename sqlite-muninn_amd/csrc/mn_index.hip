@@ -72,7 +72,8 @@ template <typename T> struct DevBuf {
 struct mn_index {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    mn_build_stats bstats = {0, 0, 0, 0, 0, 0};
     int dim = 0, ld = 0, metric = 0, order = MN_ORDER_SSE, M = 0, M_max0 = 0, efc = 0;
     int W0 = 0, WU = 0; // row strides of links0 / links_up (>= M_max0 / M; grown when a list must exceed M_max)
     double level_mult = 0;
@@ -548,7 +549,7 @@ extern "C" mn_index *mn_hnsw_create_on(int dim, int metric, int M, int ef_constr
     x->level_mult = 1.0 / log((double)M); // :192
     x->ht.assign(256, -1);                // :197
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&x->ev0) != hipSuccess || hipEventCreate(&x->ev1) != hipSuccess) {
+        hipEventCreate(&x->ev0) != hipSuccess || hipEventCreate(&x->ev1) != hipSuccess || hipEventCreate(&x->ev2) != hipSuccess) {
         set_err("mn_hnsw_create: cannot create HIP stream/events on device %d", device);
         delete x;
         return nullptr;
@@ -578,6 +579,7 @@ extern "C" void mn_hnsw_destroy(mn_index *x) {
     x->ws_readlog.release(); x->ws_nread.release(); x->ws_ncommit.release(); x->d_stamp0.release(); x->d_stampU.release();
     if (x->ev0) (void)hipEventDestroy(x->ev0);
     if (x->ev1) (void)hipEventDestroy(x->ev1);
+    if (x->ev2) (void)hipEventDestroy(x->ev2);
     if (x->stream) (void)hipStreamDestroy(x->stream);
     delete x;
 }
@@ -851,6 +853,7 @@ static int link_batch(mn_index *x, const std::vector<int> &slots, const int *d_s
         mn_launch_link(v, la, mt, st);
     }
     HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(x->ev2, st));
     HIPCHK(hipStreamSynchronize(st)); // (the searches' heap workspace was checked before this step: run_batch / batch_search)
     x->host_links_valid = false;
     for (int j = 0; j < nq; j++) {
@@ -880,7 +883,17 @@ static int run_batch(mn_index *x, const std::vector<int> &slots, bool *links_tou
         return -1;
     }
     *links_touched = true;
-    return link_batch(x, slots, x->ws_qslots.p, nlev, x->ws_sel.p, x->ws_nsel.p);
+    x->bstats.search_ms += x->last.last_kernel_ms;
+    x->bstats.n_dist += x->last.last_n_dist;
+    x->bstats.n_expanded += x->last.last_n_expanded;
+    x->bstats.batches++;
+    x->bstats.nodes += nq;
+    if (link_batch(x, slots, x->ws_qslots.p, nlev, x->ws_sel.p, x->ws_nsel.p))
+        return -1;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, x->ev1, x->ev2) == hipSuccess)
+        x->bstats.link_ms += ms;
+    return 0;
 }
 
 static int run_sequential(mn_index *x, const std::vector<int> &slots) {
@@ -1609,6 +1622,13 @@ extern "C" int64_t mn_hnsw_edges_of(mn_index *x, const int64_t *ids, int n, int6
 
 // ───────────────────────── measurement hooks ─────────────────────────
 
+extern "C" int mn_hnsw_build_stats(mn_index *x, mn_build_stats *out, int reset) {
+    *out = x->bstats;
+    if (reset)
+        x->bstats = {0, 0, 0, 0, 0, 0};
+    return 0;
+}
+
 extern "C" int mn_hnsw_last_launch(mn_index *x, mn_launch_stats *out) {
     if (use_device(x))
         return -1;
@@ -1647,12 +1667,34 @@ extern "C" int mn_dev_download(mn_index *x, void *dst, const void *src, size_t b
 extern "C" int mn_hnsw_bruteforce_topk(mn_index *x, const float *d_queries, int64_t nq, int k, int64_t *out_ids) {
     if (use_device(x))
         return -1;
-    if (sync_meta(x))
+    if (push_links(x) || sync_meta(x))
         return -1;
     hipStream_t st = x->stream;
     if (x->ws_outi.reserve((size_t)nq * k, false, st)) return -1;
-    mn_launch_bruteforce(dev_view(x), d_queries, nq, k, x->ws_outi.p, nullptr, st);
-    HIPCHK(hipGetLastError());
+    const char *force = getenv("MN_BRUTE"); // "valu" = the index's own inner loop (any k <= 128); default: MFMA when k <= 16
+    MnDevIndex v = dev_view(x);
+    if (k <= 16 && nq > 0 && x->n_slots > 0 && !(force && !strcmp(force, "valu"))) {
+        int nc = 0, rpc = 0;
+        const size_t bytes = mn_brute_mfma_scratch_bytes(v, nq, k, &nc, &rpc);
+        DevBuf<unsigned char> scratch;
+        if (scratch.reserve(bytes, false, st))
+            return -1;
+        HIPCHK(hipEventRecord(x->ev0, st));
+        const int rc = mn_launch_bruteforce_mfma(v, d_queries, nq, k, x->ws_outi.p, scratch.p, st);
+        HIPCHK(hipEventRecord(x->ev1, st));
+        hipError_t e = hipStreamSynchronize(st);
+        scratch.release();
+        if (rc != 0 || e != hipSuccess) {
+            set_err("mn_hnsw_bruteforce_topk: MFMA kernel failed (%s)", hipGetErrorString(e));
+            return -1;
+        }
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, x->ev0, x->ev1) == hipSuccess)
+            x->last.last_kernel_ms = ms;
+    } else {
+        mn_launch_bruteforce(v, d_queries, nq, k, x->ws_outi.p, nullptr, st);
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipMemcpyAsync(out_ids, x->ws_outi.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return 0;

@@ -36,6 +36,11 @@ class LaunchStats(C.Structure):
                 ("last_n_overflow", C.c_int64)]
 
 
+class BuildStats(C.Structure):
+    _fields_ = [("search_ms", C.c_double), ("link_ms", C.c_double), ("n_dist", C.c_int64), ("n_expanded", C.c_int64),
+                ("batches", C.c_int64), ("nodes", C.c_int64)]
+
+
 # every symbol include/muninn_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("mn_abi_version", C.c_int, []),
@@ -79,6 +84,7 @@ SYMBOLS = [
     ("mn_hnsw_take_dirty", C.c_int64, [C.c_void_p, _i64p, C.c_int64]),
     ("mn_hnsw_edges_of", C.c_int64, [C.c_void_p, _i64p, C.c_int, _i64p, _i64p, _i32p, _f32p, C.c_int64]),
     ("mn_hnsw_last_launch", C.c_int, [C.c_void_p, C.POINTER(LaunchStats)]),
+    ("mn_hnsw_build_stats", C.c_int, [C.c_void_p, C.POINTER(BuildStats), C.c_int]),
     ("mn_dev_malloc", C.c_void_p, [C.c_void_p, C.c_size_t]),
     ("mn_dev_free", None, [C.c_void_p, C.c_void_p]),
     ("mn_dev_upload", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -155,6 +161,9 @@ class HnswIndex:
     __del__ = close
 
     # ---- hnsw_algo.h surface ----
+    def seed_rng(self, seed):
+        self.L.mn_hnsw_seed_rng(self.h, int(seed))
+
     def insert(self, id, vec) -> int:
         return self.L.mn_hnsw_insert(self.h, int(id), np.ascontiguousarray(vec, np.float32))
 
@@ -311,6 +320,11 @@ class HnswIndex:
         if self.L.mn_hnsw_last_launch(self.h, C.byref(s)) != 0:
             raise MuninnHipError(_err())
         return {n: getattr(s, n) for n, _ in LaunchStats._fields_}
+
+    def build_stats(self, reset=False):
+        s = BuildStats()
+        self.L.mn_hnsw_build_stats(self.h, C.byref(s), 1 if reset else 0)
+        return {n: getattr(s, n) for n, _ in BuildStats._fields_}
 
     def dev_malloc(self, nbytes):
         p = self.L.mn_dev_malloc(self.h, nbytes)

@@ -199,3 +199,46 @@ def test_build_shared_by_two_ranks_equals_one_gpu_build(gpu):
     for rank, l0, l1, ep, ml in res:
         assert np.array_equal(l0, want[0]) and np.array_equal(l1, want[1]), rank
         assert (ep, ml) == want[2:]
+
+
+def _run_entry(script, extra):
+    """`python <script> --gpus 2 ...` exactly as the driver starts it (no torchrun on the command line): the script
+    itself must start its two ranks; both share the box's one GPU (gloo exchange)."""
+    import json
+    import subprocess
+    import sys
+
+    cmd = [sys.executable, os.path.join(ROOT, script), "--gpus", "2", "--backend", "gloo"] + extra
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    return lines
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["replica", "sharded"])
+def test_bench_entry_starts_its_own_ranks(gpu, mode):
+    lines = _run_entry("bench.py", ["--steps", "2", "--warmup", "1", "--num-vectors", "20000", "--dim", "64", "--nq", "500",
+                                    "--recall-queries", "100", "--no-cpu-baseline", "--recall-target", "0", "--mode", mode])
+    assert len(lines) == 1  # rank 0 prints the one line
+    j = lines[0]
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["value"] > 0 and j["roofline"]["frac"] > 0
+    assert ("sharded" in j["config"]["parallelism"]) == (mode == "sharded")
+
+
+@pytest.mark.gpu
+def test_bench_graph_entry_runs_node2vec_data_parallel(gpu):
+    lines = _run_entry("bench_graph.py", ["--workload", "node2vec", "--steps", "1", "--warmup", "0", "--n2v-nodes", "20000",
+                                          "--n2v-edges", "200000", "--n2v-cpu-nodes", "300"])
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["value"] > 0
+    assert lines[0]["parity_vs_oracle"]["embedding_bits_identical"]
+
+
+def test_bench_refuses_a_gpus_flag_that_disagrees_with_the_launcher():
+    import subprocess
+    import sys
+
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and "disagrees with WORLD_SIZE" in r.stderr
