@@ -26,6 +26,14 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0
 
 
+def _traffic(key):
+    """HBM-side bytes of one run from the committed PMC passes (profiles/traffic.json), when this workload was profiled."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[key]["traffic_bytes"]
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def er_edges(n, m, seed=42):
     rng = np.random.default_rng(seed)
     s = rng.integers(0, n, m)
@@ -214,7 +222,8 @@ def bench_leiden(pkg, args):
         "parity_vs_oracle": {"graph": f"LFR-like n={pn}, batch 1024", "communities_identical": bool(np.array_equal(pc, oc2)),
                              "modularity_bits_identical": bool(np.float64(pq).view(np.int64) == np.float64(oq2).view(np.int64))},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "k_leiden_eval/cmin/win/apply rounds (whole run)", "kernel_ms": dev_ms,
+                     "traffic": _traffic("leiden_lfr500k_9.27M_batched_default") if n == 500_000 else None,
+                     "kernel": "k_leiden_eval / k_leiden_win / k_leiden_apply rounds (whole run_leiden)", "kernel_ms": dev_ms,
                      "algorithmic_bytes_per_launch": alg},
         "cpu_baseline": {"value": E / cpu_s, "unit": "edges/s", "cores": 1, "kind": "port",
                          "sample": f"the same graph, reference's sequential schedule (oracle/mn_graph_oracle.c, dedup by hashing "

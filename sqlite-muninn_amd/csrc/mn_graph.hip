@@ -11,16 +11,25 @@
 //   k_leiden_seq     MN_LEIDEN_SEQUENTIAL: ONE wavefront walks v = 0..N-1 with in-place updates
 //                    (agent-scope atomics for label/sum_tot: never a stale L1 line) — community
 //                    assignment and Q bit-identical to the reference
-//   k_leiden_eval/cmin/win/apply   MN_LEIDEN_BATCHED: a range of nodes evaluated in parallel against
+//   k_leiden_eval_sg / _big / win / apply   MN_LEIDEN_BATCHED: a range of nodes evaluated in parallel against
 //                    frozen state; a mover commits iff it is the smallest-index mover among the
 //                    movers touching its old/target community and its moving neighbours → committed
 //                    moves are pairwise independent, realise exactly their computed gain (Q strictly
-//                    increases) and the result does not depend on execution order
+//                    increases) and the result does not depend on execution order.
+//                    The evaluation is a chain of dependent gathers per node (offsets → targets → labels →
+//                    sum_tot), so what it needs is nodes in flight: a wavefront evaluates 64/SG nodes at once in
+//                    SG-lane sub-groups (3.3 KB of LDS per wavefront whatever the largest degree is); the few
+//                    nodes with more than LEI_SG_CAP edges take a whole wavefront each (k_leiden_eval_big over a
+//                    precomputed list).  The movers' per-community tallies are folded into the evaluation.
 // O(N) bookkeeping between phases (renumber :317-331, distinct counts :388-403, sum_tot rebuild
-// :413-416, the final per-community accumulation of :128-139) is done by the host in the
-// reference's order from arrays the kernels produce.
+// :413-416, m :344-350, the per-community accumulation of :128-139) stays on the device for unweighted graphs —
+// every such sum is then a sum of integers below 2^53, exact in any order, so atomics give the reference's bits;
+// first-seen renumbering = atomicMin of the first index per label + a prefix sum over the first-occurrence flags.
+// Weighted graphs keep those sums on the host in the reference's node order (f64 addition is not associative).
+// All device buffers are allocated once per graph (LeiWork) and reused by later calls.
 #include "../../include/muninn_hip.h"
 #include <hip/hip_runtime.h>
+#include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -32,6 +41,7 @@
 
 #define DEVI __device__ __forceinline__
 #define LEI_CAP 1024 // edges of one node staged in LDS; larger nodes use the global scratch path
+#define LEI_SG_CAP 64 // sub-group evaluation: edges staged per node (more → the node takes a whole wavefront)
 
 struct DevGraph {
     int n;
@@ -153,6 +163,201 @@ DEVI int best_move(const DevGraph &g, int v, const int *label, const double *sum
     return best;
 }
 
+
+// best_move for SG-lane sub-groups: the same decisions (staging in list order, in-order f64 sums, strict-gain
+// first-seen rule), 64/SG nodes per wavefront.  All lane exchange stays inside the aligned sub-group, so sub-groups
+// may diverge freely.  lane = absolute lane, sl = lane % SG.  Degree must be <= LEI_SG_CAP.
+template <int SG>
+DEVI int best_move_sg(const DevGraph &g, int v, const int *label, const double *sum_tot, const double *kdeg, double m,
+                      double resolution, int use_both, const int *elig_part, int *ec, double *ew, unsigned char *el, int lane,
+                      int sl, double *dk_out) {
+    const int o0 = g.off_out[v], d_out = g.off_out[v + 1] - o0;
+    const int i0 = use_both ? g.off_in[v] : 0, d_in = use_both ? g.off_in[v + 1] - i0 : 0;
+    const int d = d_out + d_in;
+    const int d4 = (d + 3) & ~3;
+    const int old = label[v];
+    const int mypart = elig_part ? elig_part[v] : 0;
+    for (int e = sl; e < d4; e += SG) {
+        int c = -2;
+        double w = 0.0;
+        unsigned char ok = 0;
+        if (e < d) {
+            int t;
+            if (e < d_out) {
+                t = g.tgt_out[o0 + e];
+                w = g.w_out ? g.w_out[o0 + e] : 1.0;
+            } else {
+                t = g.tgt_in[i0 + (e - d_out)];
+                w = g.w_in ? g.w_in[i0 + (e - d_out)] : 1.0;
+            }
+            c = label[t];
+            ok = (!elig_part || elig_part[t] == mypart) ? 1 : 0;
+        }
+        ec[e] = c;
+        ew[e] = w;
+        el[e] = ok;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    const double k_v = kdeg[v];
+    const int4 *ec4 = reinterpret_cast<const int4 *>(ec);
+    const double2 *ew2 = reinterpret_cast<const double2 *>(ew);
+    const uchar4 *el4 = reinterpret_cast<const uchar4 *>(el);
+    double k_v_to_old = 0.0;
+    for (int q = 0; q < (d4 >> 2); q++) {
+        const int4 cj = ec4[q];
+        const double2 wa = ew2[2 * q], wb = ew2[2 * q + 1];
+        if (cj.x == old) k_v_to_old += wa.x;
+        if (cj.y == old) k_v_to_old += wa.y;
+        if (cj.z == old) k_v_to_old += wb.x;
+        if (cj.w == old) k_v_to_old += wb.y;
+    }
+    const double st_old = sum_tot[old];
+    double best_gain = 0.0;
+    int best = old;
+    for (int base = 0; base < d; base += SG) {
+        const int e = base + sl;
+        const int c = e < d ? ec[e] : -3;
+        bool cand = e < d && el[e] && c != old;
+        double sacc = 0.0;
+        bool dup = false;
+        for (int q = 0; q < (d4 >> 2); q++) {
+            const int4 cj = ec4[q];
+            const double2 wa = ew2[2 * q], wb = ew2[2 * q + 1];
+            const uchar4 ej = el4[q];
+            const int j = q << 2;
+            if (cj.x == c) { sacc += wa.x; dup |= (j < e) && ej.x; }
+            if (cj.y == c) { sacc += wa.y; dup |= (j + 1 < e) && ej.y; }
+            if (cj.z == c) { sacc += wb.x; dup |= (j + 2 < e) && ej.z; }
+            if (cj.w == c) { sacc += wb.y; dup |= (j + 3 < e) && ej.w; }
+        }
+        cand = cand && !dup;
+        double gain = -1.0, dk = 0.0;
+        if (cand) {
+            const double st_c = sum_tot[c];
+            dk = sacc - k_v_to_old;
+            gain = (sacc - k_v_to_old) / m + resolution * k_v * (st_old - k_v - st_c) / (2.0 * m * m); // :209-210
+            if (!(gain > 0.0))
+                gain = -1.0;
+        }
+        double bg = gain;
+        int bl = lane;
+#pragma unroll
+        for (int mk = SG / 2; mk >= 1; mk >>= 1) {
+            double og = __shfl_xor(bg, mk);
+            int ol = __shfl_xor(bl, mk);
+            if (og > bg || (og == bg && ol < bl)) {
+                bg = og;
+                bl = ol;
+            }
+        }
+        if (bg > best_gain) {
+            best_gain = bg;
+            best = __shfl(c, bl);
+            *dk_out = __shfl(dk, bl);
+        }
+    }
+    return best;
+}
+
+
+// ── unweighted graphs: O(degree) evaluation ──
+// Every weight is 1.0, so weight_to_community(v, c) (:75-90) is the NUMBER of v's edges into c — an integer, exact in
+// any order — and the O(deg · #neighbour communities) rescans of the reference (and of best_move above, which keeps
+// them because weighted sums must be taken in list order) collapse into one pass: each edge is dropped into a small
+// open-addressing table in LDS keyed by community (count, position of the first eligible edge).  The candidates are
+// the occupied entries; the strict-gain first-seen rule (:212) = highest gain, lowest first position.  Same decisions
+// as best_move, bit for bit (the gain expression is evaluated on the same f64 operands).
+#define LEI_EMPTY (-1)
+DEVI unsigned lei_hash(int c, int log2h) { return ((unsigned)c * 2654435761u) >> (32 - log2h); }
+
+// SG lanes (lane = absolute lane, sl = lane % SG) evaluate node v; tk/tc/tp: the group's table of H = 1 << log2h entries
+template <int SG>
+DEVI int best_move_hash(const DevGraph &g, int v, const int *label, const double *sum_tot, const double *kdeg, double m,
+                        double resolution, int use_both, const int *elig_part, int *tk, int *tc, int *tp, int log2h, int lane,
+                        int sl, double *dk_out) {
+    const int H = 1 << log2h;
+    const int o0 = g.off_out[v], d_out = g.off_out[v + 1] - o0;
+    const int i0 = use_both ? g.off_in[v] : 0, d_in = use_both ? g.off_in[v + 1] - i0 : 0;
+    const int d = d_out + d_in;
+    const int old = label[v];
+    const int mypart = elig_part ? elig_part[v] : 0;
+    // issued now, consumed after the table is built: these round trips overlap the offsets → targets → labels chain
+    const double k_v = kdeg[v];
+    const double st_old = sum_tot[old];
+    for (int j = sl; j < H; j += SG) {
+        tk[j] = LEI_EMPTY;
+        tc[j] = 0;
+        tp[j] = 0x7fffffff;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int e = sl; e < d; e += SG) {
+        const int t = e < d_out ? g.tgt_out[o0 + e] : g.tgt_in[i0 + (e - d_out)];
+        const int c = label[t];
+        const bool ok = !elig_part || elig_part[t] == mypart;
+        unsigned h = lei_hash(c, log2h);
+        for (;;) {
+            const int prev = atomicCAS(&tk[h], LEI_EMPTY, c);
+            if (prev == LEI_EMPTY || prev == c)
+                break;
+            h = (h + 1) & (H - 1);
+        }
+        atomicAdd(&tc[h], 1);
+        if (ok)
+            atomicMin(&tp[h], e);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    double k_v_to_old = 0.0; // weight_to_community(v, old), :163
+    {
+        unsigned h = lei_hash(old, log2h);
+        for (int probe = 0; probe < H; probe++) {
+            const int key = tk[h];
+            if (key == old) {
+                k_v_to_old = (double)tc[h];
+                break;
+            }
+            if (key == LEI_EMPTY)
+                break;
+            h = (h + 1) & (H - 1);
+        }
+    }
+    double bg = -1.0, bdk = 0.0;
+    int bpos = 0x7fffffff, bc = old;
+    for (int j = sl; j < H; j += SG) {
+        const int c = tk[j];
+        const int pos = tp[j];
+        if (c == LEI_EMPTY || c == old || pos == 0x7fffffff)
+            continue;
+        const double sacc = (double)tc[j];
+        const double st_c = sum_tot[c];
+        double gain = (sacc - k_v_to_old) / m + resolution * k_v * (st_old - k_v - st_c) / (2.0 * m * m); // :209-210
+        if (!(gain > 0.0))
+            continue;
+        if (gain > bg || (gain == bg && pos < bpos)) {
+            bg = gain;
+            bpos = pos;
+            bc = c;
+            bdk = sacc - k_v_to_old;
+        }
+    }
+#pragma unroll
+    for (int mk = SG / 2; mk >= 1; mk >>= 1) {
+        const double og = __shfl_xor(bg, mk);
+        const int op = __shfl_xor(bpos, mk);
+        const int oc = __shfl_xor(bc, mk);
+        const double od = __shfl_xor(bdk, mk);
+        if (og > bg || (og == bg && op < bpos)) {
+            bg = og;
+            bpos = op;
+            bc = oc;
+            bdk = od;
+        }
+    }
+    *dk_out = bg > 0.0 ? bdk : 0.0;
+    return bg > 0.0 ? bc : old;
+}
+
 struct LeiArgs {
     DevGraph g;
     int *label;
@@ -174,7 +379,11 @@ struct LeiArgs {
     double *dk;
     unsigned long long *Jq, *Lq; // fixed-point (2^20) tallies of the movers' degrees per community
     int apply_on_device;         // 0: weighted graph → the host applies winners in node order
-    int lds_cap;                 // k_leiden_eval: edges staged in LDS per node (multiple of 16, ≤ LEI_CAP)
+    int lds_cap;                 // k_leiden_eval_big: edges staged in LDS per node (multiple of 16, ≤ LEI_CAP)
+    const int *biglist;          // nodes with more than LEI_SG_CAP edges, ascending
+    int big0, big1;              // the slice of biglist inside [b0, b1)
+    int parity;                  // round parity: out[1 + parity] counts this round's safe winners
+    int big_log2h;               // hash table size of a wide node (unweighted): 2^big_log2h >= 2 * lds_cap
 };
 
 #define LEI_FX 1048576.0
@@ -223,37 +432,10 @@ __global__ void __launch_bounds__(64) k_leiden_seq(LeiArgs a) {
     }
 }
 
-// LDS staging sized for the graph's largest node (a.lds_cap ≤ LEI_CAP edges, 13 B each) instead of LEI_CAP: with the
-// full 13 KB only 12 wavefronts fit a CU and the kernel, which is a chain of dependent gathers, starves.
-__global__ void __launch_bounds__(64) k_leiden_eval(LeiArgs a) {
-    extern __shared__ __align__(16) unsigned char lei_smem[];
-    double *lds_w = reinterpret_cast<double *>(lei_smem);
-    int *lds_c = reinterpret_cast<int *>(lds_w + a.lds_cap);
-    unsigned char *lds_e = reinterpret_cast<unsigned char *>(lds_c + a.lds_cap);
-    const int v = a.b0 + blockIdx.x;
-    if (v >= a.b1)
-        return;
-    double dk = 0.0;
-    int best;
-    if (node_degree(a, v) <= a.lds_cap) {
-        best = best_move<false>(a.g, v, a.label, a.sum_tot, a.kdeg, a.m, a.resolution, a.use_both, a.elig_part, lds_c, lds_w,
-                                lds_e, threadIdx.x, &dk);
-    } else {
-        const size_t o = (size_t)blockIdx.x * a.max_deg;
-        best = best_move<false>(a.g, v, a.label, a.sum_tot, a.kdeg, a.m, a.resolution, a.use_both, a.elig_part, a.scratch_c + o,
-                                a.scratch_w + o, a.scratch_e + o, threadIdx.x, &dk);
-    }
-    if (threadIdx.x == 0) {
-        a.dec[v - a.b0] = best;
-        a.dk[v - a.b0] = dk;
-    }
-}
-
-__global__ void k_leiden_cmin(LeiArgs a) {
-    const int v = a.b0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= a.b1)
-        return;
-    const int old = a.label[v], best = a.dec[v - a.b0];
+// a mover's tallies: smallest mover index per touched community, and the movers' degrees leaving / joining it
+DEVI void lei_tally(const LeiArgs &a, int v, int old, int best, double dk) {
+    a.dec[v - a.b0] = best;
+    a.dk[v - a.b0] = dk;
     if (best == old)
         return;
     atomicMin(a.cmin + old, v);
@@ -263,56 +445,137 @@ __global__ void k_leiden_cmin(LeiArgs a) {
     atomicAdd(a.Jq + best, q);
 }
 
-__global__ void k_leiden_win(LeiArgs a) {
-    const int v = a.b0 + blockIdx.x * blockDim.x + threadIdx.x;
+// One launch evaluates a whole round: blocks [0, nsmall) take 64/SG nodes each in SG-lane sub-groups (nodes with more
+// than LEI_SG_CAP edges are skipped there), blocks [nsmall, nsmall + big1 - big0) take one such wide node each
+// (biglist).  HASH = unweighted graph → best_move_hash; otherwise the list-order f64 sums of best_move(_sg).
+// Dynamic LDS: max(sub-group area, wide-node area) — sized by the host (lei_eval_lds).
+template <int SG, bool HASH> __global__ void __launch_bounds__(64) k_leiden_eval(LeiArgs a, int nsmall) {
+    extern __shared__ __align__(16) unsigned char lei_smem[];
+    constexpr int NG = 64 / SG;
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x < nsmall) {
+        const int grp = lane / SG, sl = lane % SG;
+        const int v = a.b0 + blockIdx.x * NG + grp;
+        if (v >= a.b1 || node_degree(a, v) > LEI_SG_CAP)
+            return;
+        double dk = 0.0;
+        int best;
+        if (HASH) {
+            int *tk = reinterpret_cast<int *>(lei_smem) + grp * 3 * (2 * LEI_SG_CAP);
+            best = best_move_hash<SG>(a.g, v, a.label, a.sum_tot, a.kdeg, a.m, a.resolution, a.use_both, a.elig_part, tk,
+                                      tk + 2 * LEI_SG_CAP, tk + 4 * LEI_SG_CAP, 7, lane, sl, &dk); // H = 128 = 2 * LEI_SG_CAP
+        } else {
+            double *lds_w = reinterpret_cast<double *>(lei_smem);
+            int *lds_c = reinterpret_cast<int *>(lds_w + NG * LEI_SG_CAP);
+            unsigned char *lds_e = reinterpret_cast<unsigned char *>(lds_c + NG * LEI_SG_CAP);
+            best = best_move_sg<SG>(a.g, v, a.label, a.sum_tot, a.kdeg, a.m, a.resolution, a.use_both, a.elig_part,
+                                    lds_c + grp * LEI_SG_CAP, lds_w + grp * LEI_SG_CAP, lds_e + grp * LEI_SG_CAP, lane, sl, &dk);
+        }
+        if (sl == 0)
+            lei_tally(a, v, a.label[v], best, dk);
+        return;
+    }
+    const int bi = blockIdx.x - nsmall;
+    if (bi >= a.big1 - a.big0)
+        return;
+    const int v = a.biglist[a.big0 + bi];
+    const int deg = node_degree(a, v);
+    double dk = 0.0;
+    int best;
+    if (HASH && deg <= a.lds_cap) {
+        int *tk = reinterpret_cast<int *>(lei_smem);
+        const int H = 1 << a.big_log2h;
+        best = best_move_hash<64>(a.g, v, a.label, a.sum_tot, a.kdeg, a.m, a.resolution, a.use_both, a.elig_part, tk, tk + H,
+                                  tk + 2 * H, a.big_log2h, lane, lane, &dk);
+    } else if (deg <= a.lds_cap) {
+        double *lds_w = reinterpret_cast<double *>(lei_smem);
+        int *lds_c = reinterpret_cast<int *>(lds_w + a.lds_cap);
+        unsigned char *lds_e = reinterpret_cast<unsigned char *>(lds_c + a.lds_cap);
+        best = best_move<false>(a.g, v, a.label, a.sum_tot, a.kdeg, a.m, a.resolution, a.use_both, a.elig_part, lds_c, lds_w,
+                                lds_e, lane, &dk);
+    } else { // more edges than fit in LDS: global scratch, list-order sums
+        const size_t o = (size_t)bi * a.max_deg;
+        best = best_move<false>(a.g, v, a.label, a.sum_tot, a.kdeg, a.m, a.resolution, a.use_both, a.elig_part, a.scratch_c + o,
+                                a.scratch_w + o, a.scratch_e + o, lane, &dk);
+    }
+    if (lane == 0)
+        lei_tally(a, v, a.label[v], best, dk);
+}
+
+// LDS bytes of one k_leiden_eval workgroup
+static size_t lei_eval_lds(int sg, bool hash, int lds_cap, int big_log2h) {
+    const int ng = 64 / sg;
+    const size_t small = hash ? (size_t)ng * 3 * (2 * LEI_SG_CAP) * sizeof(int) : (size_t)ng * LEI_SG_CAP * 13;
+    const size_t big = hash ? (size_t)3 * ((size_t)1 << big_log2h) * sizeof(int) : (size_t)lds_cap * 13;
+    return small > big ? small : big;
+}
+
+// movers whose smaller-index neighbours in the round do not move ("free"), gain re-checked in the worst order of
+// application; 8 lanes share a node's adjacency scan
+__global__ void __launch_bounds__(256) k_leiden_win(LeiArgs a) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int v = a.b0 + (tid >> 3), sl = tid & 7;
     if (v >= a.b1)
         return;
+    // (a chain of dependent gathers: everything whose address is known is requested at once)
     const int old = a.label[v], best = a.dec[v - a.b0];
+    const int xo0 = a.g.off_out[v], xo1 = a.g.off_out[v + 1];
+    const int xi0 = a.use_both ? a.g.off_in[v] : 0, xi1 = a.use_both ? a.g.off_in[v + 1] : 0;
+    const double k_v = a.kdeg[v], dkv = a.dk[v - a.b0];
     unsigned char win = 0;
-    if (best != old) {
-        int free_nb = 1;
-        for (int pass = 0; free_nb && pass < (a.use_both ? 2 : 1); pass++) {
-            const int *off = pass ? a.g.off_in : a.g.off_out;
-            const int *tgt = pass ? a.g.tgt_in : a.g.tgt_out;
-            for (int x = off[v]; x < off[v + 1]; x++) {
-                const int w = tgt[x];
-                if (w >= a.b0 && w < v && a.dec[w - a.b0] != a.label[w]) {
-                    free_nb = 0;
-                    break;
-                }
-            }
+    if (best != old) { // (uniform over the node's 8 lanes)
+        const unsigned long long Lq = a.Lq[old], Jq = a.Jq[best];
+        const double st_o = a.sum_tot[old], st_b = a.sum_tot[best];
+        const int cm_o = a.cmin[old], cm_b = a.cmin[best];
+        int blocked = 0;
+        for (int x = xo0 + sl; x < xo1; x += 8) {
+            const int w = a.g.tgt_out[x];
+            if (w >= a.b0 && w < v && a.dec[w - a.b0] != a.label[w])
+                blocked = 1;
         }
-        if (free_nb) {
-            const double k_v = a.kdeg[v];
+        for (int x = xi0 + sl; x < xi1; x += 8) {
+            const int w = a.g.tgt_in[x];
+            if (w >= a.b0 && w < v && a.dec[w - a.b0] != a.label[w])
+                blocked = 1;
+        }
+        blocked |= __shfl_xor(blocked, 1);
+        blocked |= __shfl_xor(blocked, 2);
+        blocked |= __shfl_xor(blocked, 4);
+        if (!blocked && sl == 0) {
             const unsigned long long q = fx_up(k_v);
-            const double Lo = (double)(a.Lq[old] - q) / LEI_FX, Jc = (double)(a.Jq[best] - q) / LEI_FX;
-            const double gain2 = a.dk[v - a.b0] / a.m +
-                                 a.resolution * k_v * (a.sum_tot[old] - Lo - k_v - a.sum_tot[best] - Jc) / (2.0 * a.m * a.m);
-            const int strict = a.cmin[old] == v && a.cmin[best] == v;
+            const double Lo = (double)(Lq - q) / LEI_FX, Jc = (double)(Jq - q) / LEI_FX;
+            const double gain2 = dkv / a.m + a.resolution * k_v * (st_o - Lo - k_v - st_b - Jc) / (2.0 * a.m * a.m);
+            const int strict = cm_o == v && cm_b == v;
             win = (unsigned char)((gain2 > 0.0 ? 1 : 0) | (strict ? 2 : 0));
             if (gain2 > 0.0)
-                atomicAdd(a.out + 1, 1); // safe winners in this round
+                atomicAdd(a.out + 1 + a.parity, 1); // safe winners in this round
         }
     }
-    a.win[v - a.b0] = win;
+    if (sl == 0)
+        a.win[v - a.b0] = win;
 }
 
 __global__ void k_leiden_apply(LeiArgs a) {
     const int v = a.b0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        a.out[1 + (a.parity ^ 1)] = 0; // the next round's counter (this round reads the other one)
     if (v >= a.b1)
         return;
     const int old = a.label[v], best = a.dec[v - a.b0];
+    const unsigned char wbits = a.win[v - a.b0];
+    const int safe = a.out[1 + a.parity];
+    const double k_v = a.kdeg[v];
     if (best == old)
         return;
     a.cmin[old] = 0x7fffffff;
     a.cmin[best] = 0x7fffffff;
     a.Lq[old] = 0;
     a.Jq[best] = 0;
-    const int use_bit = a.out[1] > 0 ? 1 : 2;
-    if (a.apply_on_device && (a.win[v - a.b0] & use_bit)) {
+    const int use_bit = safe > 0 ? 1 : 2;
+    if (a.apply_on_device && (wbits & use_bit)) {
         // unweighted graph: degrees are integers, f64 atomic adds are exact → order-free
-        atomicAdd(a.sum_tot + old, -a.kdeg[v]);
-        atomicAdd(a.sum_tot + best, a.kdeg[v]);
+        atomicAdd(a.sum_tot + old, -k_v);
+        atomicAdd(a.sum_tot + best, k_v);
         a.label[v] = best;
         atomicAdd(a.out, 1);
     }
@@ -394,6 +657,8 @@ struct mn_graph {
     double *w_out = nullptr, *w_in = nullptr;
     double last_ms = 0;
     mn_leiden_stats stats = {};
+    std::vector<int> h_off_out, h_off_in; // host copies of the offsets (degrees: list of wide nodes, scratch sizing)
+    struct LeiWork *work = nullptr;       // run_leiden's device buffers, allocated on first use and kept
 };
 
 template <typename T> static int up(T **dst, const T *src, size_t n) {
@@ -438,6 +703,8 @@ extern "C" mn_graph *mn_graph_create(int n_nodes, const int *off_out, const int 
         mn_graph_destroy(g);
         return nullptr;
     }
+    g->h_off_out.assign(off_out, off_out + n_nodes + 1);
+    g->h_off_in.assign(off_in, off_in + n_nodes + 1);
     return g;
 }
 
@@ -548,8 +815,38 @@ extern "C" mn_graph *mn_graph_create_blocked(int n_nodes, const mn_csr_block *fw
         mn_graph_destroy(g);
         return nullptr;
     }
+    g->h_off_out.swap(oo);
+    g->h_off_in.swap(oi);
     return g;
 }
+
+// ───────────────────────── run_leiden workspace (one per graph, reused) ─────────────────────────
+
+struct LeiWork {
+    int n = 0, batch_cap = 0, scratch_slots = 0, scratch_deg = 0, big_mode = -1;
+    int *label = nullptr, *refined = nullptr, *out = nullptr, *dec = nullptr, *cmin = nullptr, *sc = nullptr, *sidx = nullptr,
+        *sival = nullptr, *first = nullptr, *flag = nullptr, *rank = nullptr, *biglist = nullptr, *counts = nullptr;
+    unsigned char *win = nullptr, *se = nullptr;
+    double *sum_tot = nullptr, *kdeg = nullptr, *tmp = nullptr, *sw = nullptr, *dk = nullptr, *sdval = nullptr, *scal = nullptr,
+           *s_in = nullptr;
+    unsigned long long *Jq = nullptr, *Lq = nullptr;
+    void *scan_tmp = nullptr;
+    size_t scan_bytes = 0;
+    int *h_out = nullptr;          // pinned: per-sweep move counts read back without stalling the launch queue
+    hipEvent_t ev_rd[2] = {nullptr, nullptr};
+    std::vector<int> h_big; // nodes with more than LEI_SG_CAP edges (for big_mode = use_both)
+    void release() {
+        void *ps[] = {label, refined, out, dec, cmin, sc, sidx, sival, first, flag, rank, biglist, counts, win, se, sum_tot, kdeg,
+                      tmp, sw, dk, sdval, scal, s_in, Jq, Lq, scan_tmp};
+        for (void *q : ps)
+            (void)hipFree(q);
+        if (h_out)
+            (void)hipHostFree(h_out);
+        for (hipEvent_t e : ev_rd)
+            if (e)
+                (void)hipEventDestroy(e);
+    }
+};
 
 extern "C" void mn_graph_destroy(mn_graph *g) {
     if (!g)
@@ -559,6 +856,10 @@ extern "C" void mn_graph_destroy(mn_graph *g) {
         (void)hipStreamSynchronize(g->stream);
     (void)hipFree(g->off_out); (void)hipFree(g->tgt_out); (void)hipFree(g->off_in); (void)hipFree(g->tgt_in);
     (void)hipFree(g->w_out); (void)hipFree(g->w_in);
+    if (g->work) {
+        g->work->release();
+        delete g->work;
+    }
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
     if (g->stream) (void)hipStreamDestroy(g->stream);
@@ -588,19 +889,154 @@ static int distinct(const std::vector<int> &c) {
     return n;
 }
 
-struct LeiDev {
-    int *label = nullptr, *refined = nullptr, *out = nullptr, *dec = nullptr, *cmin = nullptr, *sc = nullptr, *sidx = nullptr,
-        *sival = nullptr;
-    unsigned char *win = nullptr, *se = nullptr;
-    double *sum_tot = nullptr, *kdeg = nullptr, *tmp = nullptr, *sw = nullptr, *dk = nullptr, *sdval = nullptr;
-    unsigned long long *Jq = nullptr, *Lq = nullptr;
-    ~LeiDev() {
-        (void)hipFree(label); (void)hipFree(refined); (void)hipFree(out); (void)hipFree(dec); (void)hipFree(cmin);
-        (void)hipFree(win); (void)hipFree(sc); (void)hipFree(sum_tot); (void)hipFree(kdeg); (void)hipFree(tmp);
-        (void)hipFree(sw); (void)hipFree(se); (void)hipFree(dk); (void)hipFree(Jq); (void)hipFree(Lq); (void)hipFree(sidx);
-        (void)hipFree(sival); (void)hipFree(sdval);
+template <typename T> static int wmalloc(T **p, size_t n) {
+    if (*p)
+        (void)hipFree(*p);
+    *p = nullptr;
+    GCHK(hipMalloc(p, (n ? n : 1) * sizeof(T)));
+    return 0;
+}
+
+// (re)size the workspace for this call; everything is kept for the next one
+static int lei_prepare(mn_graph *g, int mode, int batch, int use_both, int max_deg) {
+    if (!g->work)
+        g->work = new LeiWork();
+    LeiWork &w = *g->work;
+    if (!w.h_out) {
+        GCHK(hipHostMalloc(&w.h_out, 8 * sizeof(int)));
+        GCHK(hipEventCreateWithFlags(&w.ev_rd[0], hipEventDisableTiming));
+        GCHK(hipEventCreateWithFlags(&w.ev_rd[1], hipEventDisableTiming));
     }
-};
+    const int N = g->n;
+    hipStream_t st = g->stream;
+    if (w.n != N) {
+        if (wmalloc(&w.label, (size_t)N) || wmalloc(&w.refined, (size_t)N) || wmalloc(&w.sum_tot, (size_t)N) ||
+            wmalloc(&w.kdeg, (size_t)N) || wmalloc(&w.tmp, (size_t)N) || wmalloc(&w.out, 8) || wmalloc(&w.cmin, (size_t)N) ||
+            wmalloc(&w.Jq, (size_t)N) || wmalloc(&w.Lq, (size_t)N) || wmalloc(&w.first, (size_t)N) || wmalloc(&w.flag, (size_t)N) ||
+            wmalloc(&w.rank, (size_t)N) || wmalloc(&w.counts, 8) || wmalloc(&w.scal, 8) || wmalloc(&w.s_in, (size_t)N))
+            return -1;
+        size_t bytes = 0;
+        if (rocprim::exclusive_scan(nullptr, bytes, w.flag, w.rank, 0, (size_t)N, rocprim::plus<int>(), st) != hipSuccess) {
+            gset_err("rocprim::exclusive_scan (size query) failed");
+            return -1;
+        }
+        if (w.scan_tmp)
+            (void)hipFree(w.scan_tmp);
+        w.scan_tmp = nullptr;
+        GCHK(hipMalloc(&w.scan_tmp, bytes ? bytes : 16));
+        w.scan_bytes = bytes;
+        w.n = N;
+        w.big_mode = -1;
+    }
+    // every round leaves the tallies clean (k_leiden_apply); a call that failed half-way may not have
+    GCHK(hipMemsetAsync(w.cmin, 0x7f, (size_t)N * sizeof(int), st)); // 0x7f7f7f7f > any node index
+    GCHK(hipMemsetAsync(w.Jq, 0, (size_t)N * sizeof(unsigned long long), st));
+    GCHK(hipMemsetAsync(w.Lq, 0, (size_t)N * sizeof(unsigned long long), st));
+    if (w.big_mode != use_both) { // nodes the sub-group kernel leaves to the one-wavefront-per-node kernel
+        w.h_big.clear();
+        for (int v = 0; v < N; v++) {
+            const int d = g->h_off_out[v + 1] - g->h_off_out[v] + (use_both ? g->h_off_in[v + 1] - g->h_off_in[v] : 0);
+            if (d > LEI_SG_CAP)
+                w.h_big.push_back(v);
+        }
+        if (wmalloc(&w.biglist, w.h_big.size()))
+            return -1;
+        if (!w.h_big.empty())
+            GCHK(hipMemcpyAsync(w.biglist, w.h_big.data(), w.h_big.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        w.big_mode = use_both;
+    }
+    if (mode == MN_LEIDEN_BATCHED && batch > w.batch_cap) {
+        if (wmalloc(&w.dec, (size_t)batch) || wmalloc(&w.dk, (size_t)batch) || wmalloc(&w.win, (size_t)batch) ||
+            wmalloc(&w.sidx, (size_t)2 * batch + 2) || wmalloc(&w.sival, (size_t)2 * batch + 2) ||
+            wmalloc(&w.sdval, (size_t)2 * batch + 2))
+            return -1;
+        w.batch_cap = batch;
+    }
+    const int nslots = mode == MN_LEIDEN_SEQUENTIAL ? 1 : batch;
+    if (max_deg > LEI_CAP && (nslots > w.scratch_slots || max_deg > w.scratch_deg)) {
+        if (wmalloc(&w.sc, (size_t)nslots * max_deg) || wmalloc(&w.sw, (size_t)nslots * max_deg) ||
+            wmalloc(&w.se, (size_t)nslots * max_deg))
+            return -1;
+        w.scratch_slots = nslots;
+        w.scratch_deg = max_deg;
+    }
+    return 0;
+}
+
+// ───────────────────────── device bookkeeping (unweighted graphs: all sums are exact integers) ─────────────────────────
+
+__global__ void k_iota(int *p, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        p[i] = i;
+}
+__global__ void k_sum_d(const double *x, int n, double *out) { // integer-valued terms: exact in any order
+    __shared__ double sh[256];
+    double acc = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        acc += x[i];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if ((int)threadIdx.x < s2)
+            sh[threadIdx.x] += sh[threadIdx.x + s2];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        atomicAdd(out, sh[0]);
+}
+__global__ void k_first_seen(const int *label, int n, int *first) { // first[c] = smallest i with label[i] == c
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        atomicMin(first + label[i], i);
+}
+__global__ void k_first_flag(const int *label, const int *first, int n, int *flag, int *count) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int f = 0;
+    if (i < n) {
+        f = first[label[i]] == i;
+        flag[i] = f;
+    }
+    const unsigned long long b = __ballot(f);
+    if (count && (threadIdx.x & 63) == 0 && b)
+        atomicAdd(count, __popcll(b));
+}
+// renumber_communities (:317-331): new id = number of distinct labels first seen before this one's first member
+__global__ void k_relabel(int *label, const int *first, const int *rank, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        label[i] = rank[first[label[i]]];
+}
+__global__ void k_scatter_add(const int *label, const double *val, int n, double *acc) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        atomicAdd(acc + label[i], val[i]);
+}
+
+// distinct labels of `label` → counts[slot] (device), leaves first[] / flag[] describing `label`
+static int dev_distinct(mn_graph *g, const int *label, int slot) {
+    LeiWork &w = *g->work;
+    const int N = g->n, nb = (N + 255) / 256;
+    hipStream_t st = g->stream;
+    GCHK(hipMemsetAsync(w.first, 0x7f, (size_t)N * sizeof(int), st));
+    GCHK(hipMemsetAsync(w.counts + slot, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_first_seen, dim3(nb), dim3(256), 0, st, label, N, w.first);
+    hipLaunchKernelGGL(k_first_flag, dim3(nb), dim3(256), 0, st, label, w.first, N, w.flag, w.counts + slot);
+    return 0;
+}
+// renumber `label` in place in first-seen order (first[] / flag[] must describe it: dev_distinct)
+static int dev_renumber(mn_graph *g, int *label) {
+    LeiWork &w = *g->work;
+    const int N = g->n, nb = (N + 255) / 256;
+    hipStream_t st = g->stream;
+    size_t bytes = w.scan_bytes;
+    if (rocprim::exclusive_scan(w.scan_tmp, bytes, w.flag, w.rank, 0, (size_t)N, rocprim::plus<int>(), st) != hipSuccess) {
+        gset_err("rocprim::exclusive_scan failed");
+        return -1;
+    }
+    hipLaunchKernelGGL(k_relabel, dim3(nb), dim3(256), 0, st, label, w.first, w.rank, N);
+    return 0;
+}
 
 // host mirrors of the phase's label / sum_tot (weighted graphs: winners are applied here in node order)
 struct HostState {
@@ -628,24 +1064,50 @@ static long long run_phase(mn_graph *g, LeiArgs a, int mode, int batch, int64_t 
         }
         return out[0];
     }
+    const std::vector<int> &big = g->work->h_big;
     long long total = 0;
-    int improved = 1, sweeps = 0;
+    int improved = 1, sweeps = 0, parity = 0;
     std::vector<int> h_dec((size_t)batch), ch_idx, ch_ival, touched;
     std::vector<unsigned char> h_win((size_t)batch);
     std::vector<double> ch_dval;
+    const bool hashed = !g->weighted; // every weight 1.0 → counts (best_move_hash)
+    int sg = (double)(a.use_both ? g->e_out + g->e_in : g->e_out) / std::max(1, g->n) > 48.0 ? 32 : 16;
+    if (const char *e = getenv("MN_LEIDEN_SG")) // tuning knob: 16 or 32 lanes per node
+        sg = atoi(e) == 16 ? 16 : 32;
+    int *const out_base = a.out; // two counter blocks of 4 ints: sweep s uses block s & 1
+    int pending = -1;            // sweep whose move count is still on its way to the host (device-applied moves only)
     while (improved && sweeps < a.max_sweeps) {
         improved = 0;
         sweeps++;
+        const int blk = sweeps & 1;
+        a.out = out_base + 4 * blk;
         GCHK(hipMemsetAsync(a.out, 0, 3 * sizeof(int), st));
+        parity = 0;
         long long sweep_moves = 0;
+        size_t bigpos = 0;
         for (int b = 0; b < g->n; b += batch) {
             a.b0 = b;
             a.b1 = b + batch < g->n ? b + batch : g->n;
+            a.parity = parity;
             const int nb = a.b1 - a.b0;
-            GCHK(hipMemsetAsync(a.out + 1, 0, sizeof(int), st)); // safe winners of this round
-            hipLaunchKernelGGL(k_leiden_eval, dim3(nb), dim3(64), (size_t)a.lds_cap * 13, st, a);
-            hipLaunchKernelGGL(k_leiden_cmin, dim3((nb + 255) / 256), dim3(256), 0, st, a);
-            hipLaunchKernelGGL(k_leiden_win, dim3((nb + 255) / 256), dim3(256), 0, st, a);
+            a.big0 = (int)bigpos;
+            while (bigpos < big.size() && big[bigpos] < a.b1)
+                bigpos++;
+            a.big1 = (int)bigpos;
+            {
+                const int nsmall = (nb + (64 / sg) - 1) / (64 / sg);
+                const dim3 grid((unsigned)(nsmall + a.big1 - a.big0));
+                const size_t lds = lei_eval_lds(sg, hashed, a.lds_cap, a.big_log2h);
+                if (sg == 32 && hashed)
+                    hipLaunchKernelGGL((k_leiden_eval<32, true>), grid, dim3(64), lds, st, a, nsmall);
+                else if (sg == 32)
+                    hipLaunchKernelGGL((k_leiden_eval<32, false>), grid, dim3(64), lds, st, a, nsmall);
+                else if (hashed)
+                    hipLaunchKernelGGL((k_leiden_eval<16, true>), grid, dim3(64), lds, st, a, nsmall);
+                else
+                    hipLaunchKernelGGL((k_leiden_eval<16, false>), grid, dim3(64), lds, st, a, nsmall);
+            }
+            hipLaunchKernelGGL(k_leiden_win, dim3((nb * 8 + 255) / 256), dim3(256), 0, st, a);
             ch_idx.clear();
             ch_ival.clear();
             touched.clear();
@@ -654,9 +1116,9 @@ static long long run_phase(mn_graph *g, LeiArgs a, int mode, int batch, int64_t 
                 // associative → apply them here, in node order, on the host mirrors
                 GCHK(hipMemcpyAsync(h_dec.data(), a.dec, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, st));
                 GCHK(hipMemcpyAsync(h_win.data(), a.win, (size_t)nb, hipMemcpyDeviceToHost, st));
-                GCHK(hipMemcpyAsync(out, a.out, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+                GCHK(hipMemcpyAsync(out, a.out, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
                 GCHK(hipStreamSynchronize(st));
-                const int use_bit = out[1] > 0 ? 1 : 2;
+                const int use_bit = out[1 + parity] > 0 ? 1 : 2;
                 std::vector<int> &L = *hs->label;
                 std::vector<double> &S = *hs->sum_tot;
                 for (int v = a.b0; v < a.b1; v++) {
@@ -674,6 +1136,7 @@ static long long run_phase(mn_graph *g, LeiArgs a, int mode, int batch, int64_t 
                 }
             }
             hipLaunchKernelGGL(k_leiden_apply, dim3((nb + 255) / 256), dim3(256), 0, st, a); // resets tallies (+ applies)
+            parity ^= 1;
             if (!ch_idx.empty()) {
                 int nc = (int)ch_idx.size();
                 GCHK(hipMemcpyAsync(hs->d_sidx, ch_idx.data(), (size_t)nc * sizeof(int), hipMemcpyHostToDevice, st));
@@ -693,15 +1156,40 @@ static long long run_phase(mn_graph *g, LeiArgs a, int mode, int batch, int64_t 
             }
         }
         GCHK(hipGetLastError());
-        GCHK(hipMemcpyAsync(out, a.out, sizeof(int), hipMemcpyDeviceToHost, st));
-        GCHK(hipStreamSynchronize(st));
-        if (!a.apply_on_device)
-            out[0] = (int)sweep_moves;
-        if (out[0]) {
-            improved = 1;
-            total += out[0];
+        if (!a.apply_on_device) {
+            if (sweep_moves) {
+                improved = 1;
+                total += sweep_moves;
+            }
+            continue;
         }
+        // Moves applied on the device: the count of this sweep travels to pinned memory behind the sweep, and the NEXT sweep
+        // is queued before the host looks at the PREVIOUS one — the launch queue never drains.  If that previous sweep
+        // moved nothing the state is a fixed point: the sweep just queued moves nothing either and is not counted.
+        int *h = g->work->h_out + 4 * blk;
+        GCHK(hipMemcpyAsync(h, a.out, sizeof(int), hipMemcpyDeviceToHost, st));
+        GCHK(hipEventRecord(g->work->ev_rd[blk], st));
+        improved = 1;
+        if (pending >= 0) {
+            const int pb = pending & 1;
+            GCHK(hipEventSynchronize(g->work->ev_rd[pb]));
+            const int mv = g->work->h_out[4 * pb];
+            if (mv == 0) { // `pending` was the last real sweep; the one queued above is redundant
+                sweeps = pending;
+                improved = 0;
+                pending = -1;
+                break;
+            }
+            total += mv;
+        }
+        pending = sweeps;
     }
+    if (pending >= 0) { // stopped by max_sweeps
+        GCHK(hipEventSynchronize(g->work->ev_rd[pending & 1]));
+        total += g->work->h_out[4 * (pending & 1)];
+    }
+    a.out = out_base;
+    GCHK(hipStreamSynchronize(st));
     *sweeps_out += sweeps;
     return total;
 }
@@ -716,61 +1204,58 @@ extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int
     if (N == 0)
         return 0;
     if (mode == MN_LEIDEN_BATCHED && batch <= 1) {
-        // A round costs about the same wall time up to a few full waves of the chip (8192 resident wavefronts), and
-        // larger rounds need more sweeps.  Measured on the cfg5 graph (N = 500k, <k> = 37): round size 6 250 → 205 ms,
-        // 12 500 → 124 ms, 25 000 → 107 ms, 50 000 → 121 ms, 100 000 → 170 ms, modularity 0.668–0.674 throughout.
-        batch = (int)std::min<long long>(32768, std::max<long long>(256, N / 16));
+        // A round costs about the same wall time up to a few full waves of the chip, and larger rounds need more sweeps.
+        // Measured on the cfg5 graph (N = 500k, <k> = 37): modularity 0.668–0.674 for round sizes 6 250 … 100 000.
+        // (round 2: a round is now three launches of ≈ 10 µs whatever its size; measured on the same graph, ms per run_leiden
+        //  for rounds of 15 625 / 31 250 / 62 500 / 125 000 nodes: 32.9 / 34.1 / 42.6 / 93.4 — smaller rounds need fewer sweeps)
+        batch = (int)std::min<long long>(16384, std::max<long long>(256, N / 32));
+        if (const char *e = getenv("MN_LEIDEN_BATCH")) // tuning knob
+            batch = std::max(256, atoi(e));
     }
     hipStream_t st = g->stream;
     DevGraph dg = {N, g->off_out, g->tgt_out, g->w_out, g->off_in, g->tgt_in, g->w_in};
-    LeiDev d;
     const int max_deg = ((use_both ? g->max_deg_both : g->max_deg_out) + 7) & ~3; // int4-aligned scratch stride
-    const int nslots = mode == MN_LEIDEN_SEQUENTIAL ? 1 : batch;
-    GCHK(hipMalloc(&d.label, (size_t)N * sizeof(int)));
-    GCHK(hipMalloc(&d.refined, (size_t)N * sizeof(int)));
-    GCHK(hipMalloc(&d.sum_tot, (size_t)N * sizeof(double)));
-    GCHK(hipMalloc(&d.kdeg, (size_t)N * sizeof(double)));
-    GCHK(hipMalloc(&d.tmp, (size_t)N * sizeof(double)));
-    GCHK(hipMalloc(&d.out, 4 * sizeof(int)));
-    if (mode == MN_LEIDEN_BATCHED) {
-        GCHK(hipMalloc(&d.dec, (size_t)batch * sizeof(int)));
-        GCHK(hipMalloc(&d.dk, (size_t)batch * sizeof(double)));
-        GCHK(hipMalloc(&d.win, (size_t)batch));
-        GCHK(hipMalloc(&d.cmin, (size_t)N * sizeof(int)));
-        GCHK(hipMalloc(&d.Jq, (size_t)N * sizeof(unsigned long long)));
-        GCHK(hipMalloc(&d.Lq, (size_t)N * sizeof(unsigned long long)));
-        GCHK(hipMalloc(&d.sidx, (size_t)(2 * batch + 2) * sizeof(int)));
-        GCHK(hipMalloc(&d.sival, (size_t)(2 * batch + 2) * sizeof(int)));
-        GCHK(hipMalloc(&d.sdval, (size_t)(2 * batch + 2) * sizeof(double)));
-        GCHK(hipMemsetAsync(d.cmin, 0x7f, (size_t)N * sizeof(int), st)); // 0x7f7f7f7f > any node index
-        GCHK(hipMemsetAsync(d.Jq, 0, (size_t)N * sizeof(unsigned long long), st));
-        GCHK(hipMemsetAsync(d.Lq, 0, (size_t)N * sizeof(unsigned long long), st));
-    }
-    if (max_deg > LEI_CAP) {
-        GCHK(hipMalloc(&d.sc, (size_t)nslots * max_deg * sizeof(int)));
-        GCHK(hipMalloc(&d.sw, (size_t)nslots * max_deg * sizeof(double)));
-        GCHK(hipMalloc(&d.se, (size_t)nslots * max_deg));
-    }
+    if (lei_prepare(g, mode, batch, use_both, max_deg))
+        return -1;
+    LeiWork &d = *g->work;
+    const int nbN = (N + 255) / 256;
+    // Unweighted: every per-community / per-graph sum is a sum of integers (exact in any order) → all bookkeeping on the
+    // device.  Weighted: the reference's node-order f64 sums are kept on the host.
+    const bool on_dev = !g->weighted && mode == MN_LEIDEN_BATCHED;
     GCHK(hipEventRecord(g->ev0, st));
-    // k[i], m (:344-350) — per-node sums on the device, the running total in node order on the host
-    hipLaunchKernelGGL(k_wdeg, dim3((N + 255) / 256), dim3(256), 0, st, dg, use_both, d.kdeg);
-    std::vector<double> k((size_t)N);
-    GCHK(hipMemcpyAsync(k.data(), d.kdeg, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, st));
-    GCHK(hipStreamSynchronize(st));
+    // k[i], m (:344-350)
+    hipLaunchKernelGGL(k_wdeg, dim3(nbN), dim3(256), 0, st, dg, use_both, d.kdeg);
+    std::vector<double> k;
     double m = 0.0;
-    for (int i = 0; i < N; i++)
-        m += k[i];
+    if (on_dev) {
+        GCHK(hipMemsetAsync(d.scal, 0, sizeof(double), st));
+        hipLaunchKernelGGL(k_sum_d, dim3(std::min(nbN, 1024)), dim3(256), 0, st, d.kdeg, N, d.scal);
+        GCHK(hipMemcpyAsync(&m, d.scal, sizeof(double), hipMemcpyDeviceToHost, st));
+        GCHK(hipStreamSynchronize(st));
+    } else {
+        k.resize((size_t)N);
+        GCHK(hipMemcpyAsync(k.data(), d.kdeg, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, st));
+        GCHK(hipStreamSynchronize(st));
+        for (int i = 0; i < N; i++) // the running total in node order
+            m += k[i];
+    }
     m /= 2.0;
-    std::vector<int> community((size_t)N), refined((size_t)N);
-    for (int i = 0; i < N; i++)
-        community[i] = i;
+    std::vector<int> community, refined;
     if (m <= 0.0) { // :351-356
-        memcpy(community_out, community.data(), (size_t)N * sizeof(int));
+        for (int i = 0; i < N; i++)
+            community_out[i] = i;
         return 0;
     }
-    std::vector<double> sum_tot(k);
-    GCHK(hipMemcpyAsync(d.label, community.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, st));
-    GCHK(hipMemcpyAsync(d.sum_tot, sum_tot.data(), (size_t)N * sizeof(double), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_iota, dim3(nbN), dim3(256), 0, st, d.label, N);
+    GCHK(hipMemcpyAsync(d.sum_tot, d.kdeg, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, st));
+    std::vector<double> sum_tot, r_sum_tot;
+    if (!on_dev) {
+        community.resize((size_t)N);
+        refined.resize((size_t)N);
+        for (int i = 0; i < N; i++)
+            community[i] = i;
+        sum_tot = k;
+    }
 
     LeiArgs a;
     memset(&a, 0, sizeof(a));
@@ -793,7 +1278,10 @@ extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int
     a.Lq = d.Lq;
     a.apply_on_device = g->weighted ? 0 : 1;
     a.lds_cap = std::min(LEI_CAP, std::max(64, (max_deg + 15) & ~15));
-    std::vector<double> r_sum_tot;
+    a.big_log2h = 7;
+    while ((1 << a.big_log2h) < 2 * a.lds_cap)
+        a.big_log2h++;
+    a.biglist = d.biglist;
     HostState hs = {&community, &sum_tot, &k, d.sidx, d.sival, d.sdval};
 
     for (int iter = 0; iter < 100; iter++) { // :368-417
@@ -810,46 +1298,93 @@ extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int
         if (moves == 0)
             break;
         // refinement (:238-312): singletons, r_sum_tot = k
-        GCHK(hipMemcpyAsync(community.data(), d.label, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, st));
-        for (int i = 0; i < N; i++)
-            refined[i] = i;
-        GCHK(hipMemcpyAsync(d.refined, refined.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_iota, dim3(nbN), dim3(256), 0, st, d.refined, N);
         GCHK(hipMemcpyAsync(d.tmp, d.kdeg, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, st));
         a.label = d.refined;
         a.sum_tot = d.tmp;
         a.elig_part = d.label;
-        r_sum_tot = k;
-        hs.label = &refined;
-        hs.sum_tot = &r_sum_tot;
+        if (!on_dev) {
+            GCHK(hipMemcpyAsync(community.data(), d.label, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, st));
+            for (int i = 0; i < N; i++)
+                refined[i] = i;
+            r_sum_tot = k;
+            hs.label = &refined;
+            hs.sum_tot = &r_sum_tot;
+        }
         if (run_phase(g, a, mode, batch, &g->stats.refine_sweeps, &hs) < 0)
             return -1;
-        GCHK(hipMemcpyAsync(refined.data(), d.refined, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, st));
+        if (on_dev) {
+            // :388-408 adopt the refinement iff it has no more communities than phase 1; then renumber (:317-331)
+            // and rebuild sum_tot (:413-416) — on the device
+            int cnt[2] = {0, 0};
+            if (dev_distinct(g, d.label, 0) || dev_distinct(g, d.refined, 1))
+                return -1;
+            GCHK(hipMemcpyAsync(cnt, d.counts, sizeof(cnt), hipMemcpyDeviceToHost, st));
+            GCHK(hipStreamSynchronize(st));
+            if (cnt[1] <= cnt[0]) { // first[] / flag[] describe `refined` (the later of the two calls)
+                GCHK(hipMemcpyAsync(d.label, d.refined, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, st));
+            } else if (dev_distinct(g, d.label, 0)) {
+                return -1;
+            }
+            if (dev_renumber(g, d.label))
+                return -1;
+            GCHK(hipMemsetAsync(d.sum_tot, 0, (size_t)N * sizeof(double), st));
+            hipLaunchKernelGGL(k_scatter_add, dim3(nbN), dim3(256), 0, st, d.label, d.kdeg, N, d.sum_tot);
+        } else {
+            GCHK(hipMemcpyAsync(refined.data(), d.refined, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, st));
+            GCHK(hipStreamSynchronize(st));
+            if (distinct(refined) <= distinct(community)) // :388-408
+                community = refined;
+            renumber(community);
+            std::fill(sum_tot.begin(), sum_tot.end(), 0.0); // :413-416, node order
+            for (int i = 0; i < N; i++)
+                sum_tot[community[i]] += k[i];
+            GCHK(hipMemcpyAsync(d.label, community.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, st));
+            GCHK(hipMemcpyAsync(d.sum_tot, sum_tot.data(), (size_t)N * sizeof(double), hipMemcpyHostToDevice, st));
+        }
+    }
+    int K = 0;
+    std::vector<double> s_in, s_tot;
+    if (on_dev) {
+        int cnt = 0;
+        if (dev_distinct(g, d.label, 0) || dev_renumber(g, d.label)) // :420
+            return -1;
+        // compute_modularity (:109-142): per-node terms and per-community sums (integers) on the device
+        hipLaunchKernelGGL(k_w2c_self, dim3(nbN), dim3(256), 0, st, dg, use_both, d.label, d.tmp);
+        GCHK(hipMemsetAsync(d.s_in, 0, (size_t)N * sizeof(double), st));
+        GCHK(hipMemsetAsync(d.sum_tot, 0, (size_t)N * sizeof(double), st));
+        hipLaunchKernelGGL(k_scatter_add, dim3(nbN), dim3(256), 0, st, d.label, d.tmp, N, d.s_in);
+        hipLaunchKernelGGL(k_scatter_add, dim3(nbN), dim3(256), 0, st, d.label, d.kdeg, N, d.sum_tot);
+        GCHK(hipMemcpyAsync(&cnt, d.counts, sizeof(int), hipMemcpyDeviceToHost, st));
+        GCHK(hipMemcpyAsync(community_out, d.label, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, st));
         GCHK(hipStreamSynchronize(st));
-        if (distinct(refined) <= distinct(community)) // :388-408
-            community = refined;
-        renumber(community);
-        std::fill(sum_tot.begin(), sum_tot.end(), 0.0); // :413-416, node order
-        for (int i = 0; i < N; i++)
-            sum_tot[community[i]] += k[i];
+        K = cnt;
+        s_in.resize((size_t)K);
+        s_tot.resize((size_t)K);
+        GCHK(hipMemcpyAsync(s_in.data(), d.s_in, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, st));
+        GCHK(hipMemcpyAsync(s_tot.data(), d.sum_tot, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, st));
+        GCHK(hipEventRecord(g->ev1, st));
+        GCHK(hipStreamSynchronize(st));
+    } else {
+        GCHK(hipMemcpyAsync(community.data(), d.label, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, st));
+        GCHK(hipStreamSynchronize(st));
+        K = renumber(community); // :420
+        // compute_modularity (:109-142): per-node terms on the device, accumulation in node order here
         GCHK(hipMemcpyAsync(d.label, community.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, st));
-        GCHK(hipMemcpyAsync(d.sum_tot, sum_tot.data(), (size_t)N * sizeof(double), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_w2c_self, dim3(nbN), dim3(256), 0, st, dg, use_both, d.label, d.tmp);
+        std::vector<double> w2c((size_t)N);
+        GCHK(hipMemcpyAsync(w2c.data(), d.tmp, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, st));
+        GCHK(hipEventRecord(g->ev1, st));
+        GCHK(hipStreamSynchronize(st));
+        s_in.assign((size_t)K, 0.0);
+        s_tot.assign((size_t)K, 0.0);
+        for (int i = 0; i < N; i++) {
+            s_tot[community[i]] += k[i];
+            s_in[community[i]] += w2c[i];
+        }
+        memcpy(community_out, community.data(), (size_t)N * sizeof(int));
     }
-    GCHK(hipMemcpyAsync(community.data(), d.label, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, st));
-    GCHK(hipStreamSynchronize(st));
-    const int K = renumber(community); // :420
-    // compute_modularity (:109-142): per-node terms on the device, accumulation in node order here
-    GCHK(hipMemcpyAsync(d.label, community.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_w2c_self, dim3((N + 255) / 256), dim3(256), 0, st, dg, use_both, d.label, d.tmp);
-    std::vector<double> w2c((size_t)N);
-    GCHK(hipMemcpyAsync(w2c.data(), d.tmp, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, st));
-    GCHK(hipEventRecord(g->ev1, st));
-    GCHK(hipStreamSynchronize(st));
-    std::vector<double> s_in((size_t)K, 0.0), s_tot((size_t)K, 0.0);
-    for (int i = 0; i < N; i++) {
-        s_tot[community[i]] += k[i];
-        s_in[community[i]] += w2c[i];
-    }
-    double Q = 0.0;
+    double Q = 0.0; // :128-139, communities in order (K terms)
     for (int c = 0; c < K; c++)
         if (s_tot[c] > 0)
             Q += s_in[c] / (2.0 * m) - resolution * (s_tot[c] / (2.0 * m)) * (s_tot[c] / (2.0 * m));
@@ -857,7 +1392,6 @@ extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int
     if (hipEventElapsedTime(&ms, g->ev0, g->ev1) == hipSuccess)
         g->stats.device_ms = ms;
     g->stats.n_communities = K;
-    memcpy(community_out, community.data(), (size_t)N * sizeof(int));
     if (modularity_out)
         *modularity_out = Q;
     return 0;
