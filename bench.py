@@ -265,13 +265,17 @@ def main():
     dev_ord = args.device if args.device >= 0 else local_rank
     g = pkg.HnswIndex(D, args.metric, M, EFC, order=order, device=dev_ord)
     shared_build = world > 1 and not sharded and os.environ.get("MN_BENCH_SHARED_BUILD", "1") != "0"
+    comm = None
     if dist is not None:
+        # the exchange itself runs below the C-ABI (mn_comm: RCCL all-gather on the library's stream, or the host transport
+        # of the gloo rehearsal); torch.distributed only hands rank 0's RCCL id to the others and provides barriers
+        comm = pkg.parallel.Comm(dev_ord)
         dist.barrier()
     t0 = time.perf_counter()
     if shared_build:
         # replicas of ONE graph: every batch's search half is split over the ranks, the selected lists are all-gathered
         # (RCCL), every replica links the whole batch → the graph of a one-GPU build, on every GPU (parallel.py)
-        pkg.parallel.build_distributed(g, ids, X, 16, 8192)
+        pkg.parallel.build_distributed(g, ids, X, 16, 8192, comm=comm)
     elif g.build(ids, X, 16, 8192) != 0:
         raise SystemExit("build failed: " + pkg.hnsw._err())
     g.sync()
@@ -288,17 +292,9 @@ def main():
     # ---- HBM-resident inputs / outputs ----
     dq = g.dev_malloc(Q.nbytes)
     g.dev_upload(dq, Q)
-    if sharded:  # outputs live in torch tensors so that RCCL can all-gather them in place
-        import torch
-
-        t_ids = torch.empty((NQ, K), dtype=torch.int64, device="cuda")
-        t_ds = torch.empty((NQ, K), dtype=torch.float32, device="cuda")
-        t_cnt = torch.empty((NQ,), dtype=torch.int32, device="cuda")
-        d_ids, d_ds, d_cnt = t_ids.data_ptr(), t_ds.data_ptr(), t_cnt.data_ptr()
-    else:
-        d_ids = g.dev_malloc(NQ * K * 8)
-        d_ds = g.dev_malloc(NQ * K * 4)
-        d_cnt = g.dev_malloc(NQ * 4)
+    d_ids = g.dev_malloc(NQ * K * 8)
+    d_ds = g.dev_malloc(NQ * K * 4)
+    d_cnt = g.dev_malloc(NQ * 4)
 
     def barrier():
         if dist is not None:
@@ -311,10 +307,10 @@ def main():
     def run_steps(nsteps, ef, collect=False, merge=True):
         kms, nd, ne = [], 0, 0
         for _ in range(nsteps):
-            g.search_batch_dev(dq, NQ, K, ef, d_ids, d_ds, d_cnt)
-            if sharded and merge:  # the one exchange step of the sharded index: per-shard top-k → global top-k
-                g.sync()
-                pkg.parallel.allgather_merge_topk(t_ids, t_ds, t_cnt, K)
+            if sharded and merge:  # shard search + the one exchange step (all-gather of per-shard top-k) + device merge
+                pkg.parallel.search_sharded_dev(g, comm, dq, NQ, K, ef, d_ids, d_ds, d_cnt)
+            else:
+                g.search_batch_dev(dq, NQ, K, ef, d_ids, d_ds, d_cnt)
             if collect:  # per-launch HIP-event time on the kernel's own stream (syncs that launch)
                 st = g.last_launch()
                 kms.append(st["last_kernel_ms"])
@@ -488,7 +484,7 @@ def main():
             "config": {"workload": f"{N}x{D} f32 {args.dataset}, HNSW M={M} efC={EFC} {args.metric}, build on GPU + "
                                    f"{NQ}-query batched kNN k={K} ef={EF}",
                        "n": N, "dim": D, "nq": NQ, "k": K, "ef": EF, "order": args.order, "dataset": args.dataset,
-                       "parallelism": ("sharded index (rowid mod N) + RCCL all-gather top-k merge" if sharded else
+                       "parallelism": (f"sharded index (rowid mod N) + all-gather of per-shard top-k ({args.backend}) + device merge, below the C-ABI" if sharded else
                                        "replica per GPU, queries sharded") if world > 1 else "single GPU"},
             "recall_at_10": recall,
             "recall_queries": nrec,
@@ -532,6 +528,7 @@ def main():
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
+        comm.close()
         dist.destroy_process_group()
     if g is not None:
         g.close()

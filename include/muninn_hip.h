@@ -283,6 +283,48 @@ int mn_n2v_sync(mn_n2v_session *s);
 int mn_n2v_finish(mn_n2v_session *s, float *out, mn_n2v_stats *stats); /* L2 normalise, download [n][dim] */
 void mn_n2v_end(mn_n2v_session *s);
 
+/* ---- multi-GPU: one rank per GPU of a node, processes or threads; RCCL over xGMI ----
+ * The reference is single-device; these entry points are what its host (hnsw_vtab.c / node2vec.c) would call to use the
+ * node's other GPUs.  The only collective is an all-gather of equal-sized device buffers:
+ *   RCCL transport: rank 0 calls mn_comm_unique_id and hands the 128 bytes to the other ranks by whatever means the
+ *     host has (a file, a socket, MPI, torch.distributed's store); every rank then calls mn_comm_init_rccl.  librccl is
+ *     loaded on first use, so single-GPU users never touch it.
+ *   host transport: the caller provides the all-gather over HOST buffers (recv = world x bytes_per_rank, rank order) —
+ *     rehearsals where several ranks share one GPU (RCCL refuses that), or a host with its own fabric. */
+typedef struct mn_comm mn_comm;
+#define MN_COMM_ID_BYTES 128
+typedef int (*mn_host_allgather_fn)(void *user, const void *send, void *recv, size_t bytes_per_rank);
+int mn_comm_unique_id(void *id128);
+mn_comm *mn_comm_init_rccl(int world, int rank, const void *id128, int device);
+mn_comm *mn_comm_init_host(int world, int rank, mn_host_allgather_fn fn, void *user, int device);
+int mn_comm_world(mn_comm *c);
+int mn_comm_rank(mn_comm *c);
+void mn_comm_destroy(mn_comm *c);
+const char *mn_comm_last_error(void);
+
+/* mn_hnsw_build on `world` GPUs that each hold a replica of ONE index: the batches are those of mn_hnsw_build; inside a
+ * batch rank r searches a contiguous slice of the batch's nodes against its replica (k_beam<BUILD>, the dominant cost),
+ * the selected-neighbour lists are all-gathered and every replica links the whole batch.  Every replica ends with the
+ * graph a single GPU builds, bit for bit.  ids / vectors: the SAME host arrays on every rank.  Batches below min_split
+ * nodes (<= 0 -> 256) are searched whole by every rank (no exchange).  0 / -1. */
+int mn_hnsw_build_shared(mn_index *idx, mn_comm *c, const int64_t *ids, const float *vectors, int64_t n, int grow_div,
+                         int max_batch, int min_split);
+/* BASELINE config 3: the index is sharded (rowid mod world -> one HNSW graph per GPU, built independently); every rank
+ * searches the SAME queries on its shard, the per-shard top-k — k x (int64 id, f32 distance) per query — are all-gathered
+ * and merged on the device in the total order (distance, shard rank, position).  Every rank receives the merged result.
+ * Device buffers on idx's device; asynchronous on the index's stream like mn_hnsw_search_batch_dev. */
+int mn_hnsw_search_sharded_dev(mn_index *idx, mn_comm *c, const float *d_queries, int64_t nq, int k, int ef_search,
+                               int64_t *d_out_ids, float *d_out_dists, int *d_out_counts);
+/* the same with host buffers */
+int mn_hnsw_search_sharded(mn_index *idx, mn_comm *c, const float *queries, int64_t nq, int k, int ef_search, int64_t *out_ids,
+                           float *out_dists, int *out_counts);
+/* MN_N2V_BATCHED data-parallel over the ranks (BASELINE config 4): every rank holds a replica of both matrices, computes
+ * the samples of its contiguous slice of each batch's walks, the samples are all-gathered in rank order (= walk order) and
+ * every replica applies the whole batch: the embeddings are bit-identical to mn_node2vec_train(.., MN_N2V_BATCHED) on
+ * one GPU.  stats->pairs is this rank's share.  Returns n / -1. */
+int mn_node2vec_train_shared(mn_comm *c, int n_nodes, const int *off, const int *adj, const mn_n2v_params *prm, int device,
+                             float *out, mn_n2v_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif

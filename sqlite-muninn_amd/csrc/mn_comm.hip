@@ -1,0 +1,164 @@
+// mn_comm.hip — communicator of the multi-GPU paths: RCCL over xGMI (one rank per GPU, processes or threads), or a
+// caller-supplied host all-gather for rehearsals.  See mn_comm.hpp.
+#include "mn_comm.hpp"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <dlfcn.h>
+#include <mutex>
+#include <string>
+
+static thread_local std::string g_cerr;
+static void cset_err(const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_cerr = buf;
+}
+const char *mn_comm_last_error_str() { return g_cerr.c_str(); }
+extern "C" const char *mn_comm_last_error(void) { return g_cerr.c_str(); }
+
+// the five RCCL entry points used, resolved from librccl.so.1 on first use (signatures: rccl/rccl.h)
+namespace {
+struct RcclUniqueId { char internal[128]; };
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(RcclUniqueId *) = nullptr;
+    int (*CommInitRank)(void **, int, RcclUniqueId, int) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+bool rccl_load() {
+    std::call_once(g_rccl_once, [] {
+        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h)
+            h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h)
+            return;
+        Rccl r;
+        r.lib = h;
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(h, "ncclAllGather"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        if (r.GetUniqueId && r.CommInitRank && r.AllGather && r.CommDestroy && r.GetErrorString)
+            g_rccl = r;
+    });
+    return g_rccl.lib != nullptr;
+}
+} // namespace
+
+extern "C" int mn_comm_unique_id(void *id128) {
+    if (!rccl_load()) {
+        cset_err("mn_comm_unique_id: librccl.so.1 could not be loaded");
+        return -1;
+    }
+    RcclUniqueId id;
+    const int rc = g_rccl.GetUniqueId(&id);
+    if (rc != 0) {
+        cset_err("ncclGetUniqueId: %s", g_rccl.GetErrorString(rc));
+        return -1;
+    }
+    memcpy(id128, id.internal, MN_COMM_ID_BYTES);
+    return 0;
+}
+
+extern "C" mn_comm *mn_comm_init_rccl(int world, int rank, const void *id128, int device) {
+    if (world < 1 || rank < 0 || rank >= world || !id128) {
+        cset_err("mn_comm_init_rccl: bad arguments");
+        return nullptr;
+    }
+    if (!rccl_load()) {
+        cset_err("mn_comm_init_rccl: librccl.so.1 could not be loaded");
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        cset_err("mn_comm_init_rccl: HIP device %d not available", device);
+        return nullptr;
+    }
+    RcclUniqueId id;
+    memcpy(id.internal, id128, MN_COMM_ID_BYTES);
+    void *nc = nullptr;
+    const int rc = g_rccl.CommInitRank(&nc, world, id, rank); // (collective: returns when every rank has called it)
+    if (rc != 0) {
+        cset_err("ncclCommInitRank(world %d, rank %d): %s", world, rank, g_rccl.GetErrorString(rc));
+        return nullptr;
+    }
+    mn_comm *c = new mn_comm();
+    c->world = world;
+    c->rank = rank;
+    c->device = device;
+    c->nccl = nc;
+    return c;
+}
+
+extern "C" mn_comm *mn_comm_init_host(int world, int rank, mn_host_allgather_fn fn, void *user, int device) {
+    if (world < 1 || rank < 0 || rank >= world || (world > 1 && !fn)) {
+        cset_err("mn_comm_init_host: bad arguments");
+        return nullptr;
+    }
+    mn_comm *c = new mn_comm();
+    c->world = world;
+    c->rank = rank;
+    c->device = device;
+    c->host_fn = fn;
+    c->host_user = user;
+    return c;
+}
+
+extern "C" int mn_comm_world(mn_comm *c) { return c->world; }
+extern "C" int mn_comm_rank(mn_comm *c) { return c->rank; }
+
+extern "C" void mn_comm_destroy(mn_comm *c) {
+    if (!c)
+        return;
+    if (c->nccl && g_rccl.lib) {
+        (void)hipSetDevice(c->device);
+        (void)g_rccl.CommDestroy(c->nccl);
+    }
+    delete c;
+}
+
+int mn_comm_allgather_dev(mn_comm *c, const void *d_send, void *d_recv, size_t bytes, hipStream_t st) {
+    if (bytes == 0)
+        return 0;
+    if (c->world == 1 && !c->nccl) { // nothing to exchange
+        if (d_send != d_recv && hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            cset_err("mn_comm: device copy failed");
+            return -1;
+        }
+        return 0;
+    }
+    if (c->nccl) {
+        const int rc = g_rccl.AllGather(d_send, d_recv, bytes, /* ncclChar */ 0, c->nccl, st);
+        if (rc != 0) {
+            cset_err("ncclAllGather(%zu bytes per rank): %s", bytes, g_rccl.GetErrorString(rc));
+            return -1;
+        }
+        return 0;
+    }
+    c->h_send.resize(bytes);
+    c->h_recv.resize(bytes * (size_t)c->world);
+    if (hipMemcpyAsync(c->h_send.data(), d_send, bytes, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+        cset_err("mn_comm: staging to the host failed");
+        return -1;
+    }
+    if (c->host_fn(c->host_user, c->h_send.data(), c->h_recv.data(), bytes) != 0) {
+        cset_err("mn_comm: the host all-gather callback failed");
+        return -1;
+    }
+    if (hipMemcpyAsync(d_recv, c->h_recv.data(), bytes * (size_t)c->world, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+        cset_err("mn_comm: staging from the host failed");
+        return -1;
+    }
+    return 0;
+}

@@ -1,0 +1,23 @@
+// mn_comm.hpp — the one exchange primitive of the multi-GPU paths: an all-gather of equal-sized device
+// buffers between the ranks of a node, one rank per GPU.
+//   RCCL transport  ncclAllGather on the caller's HIP stream (xGMI); librccl is loaded on first use (dlopen), so a
+//                   single-GPU user never pays for it and the library has no link-time dependency on it
+//   host transport  the caller supplies the all-gather over HOST buffers (the world-2 gloo rehearsals, where both
+//                   ranks share the one GPU of the box — which RCCL refuses — and any host that has its own fabric)
+#pragma once
+#include "../../include/muninn_hip.h"
+#include <hip/hip_runtime.h>
+#include <vector>
+
+struct mn_comm {
+    int world = 1, rank = 0, device = 0;
+    void *nccl = nullptr; // ncclComm_t
+    mn_host_allgather_fn host_fn = nullptr;
+    void *host_user = nullptr;
+    std::vector<unsigned char> h_send, h_recv;
+};
+
+// d_recv[r * bytes .. (r+1) * bytes) = rank r's d_send, for every r; in place (d_send == d_recv + rank * bytes) allowed.
+// Stream-ordered for RCCL; the host transport synchronises the stream.  0 / -1 (message via mn_comm_last_error).
+int mn_comm_allgather_dev(mn_comm *c, const void *d_send, void *d_recv, size_t bytes, hipStream_t st);
+const char *mn_comm_last_error_str();

@@ -94,6 +94,11 @@ size_t mn_brute_mfma_scratch_bytes(const MnDevIndex &ix, long long nq, int k, in
 int mn_launch_bruteforce_mfma(const MnDevIndex &ix, const float *d_queries, long long nq, int k, long long *d_out_ids,
                               void *scratch, hipStream_t st);
 
+// sharded index (config 3): per-shard top-k lists gathered as [world][nq][k] → global top-k per query in the total order
+// (distance, shard rank, position)  (mn_kernels.hip)
+void mn_launch_merge_topk(const long long *g_ids, const float *g_dists, const int *g_counts, int world, long long nq, int k,
+                          long long *out_ids, float *out_dists, int *out_counts, hipStream_t st);
+
 // link kernels for the batched build (mn_build.hip)
 struct MnLinkArgs {
     int level, M_max;

@@ -4,6 +4,7 @@
 // per-node metadata, the level RNG (src/hnsw_algo.c:19-30,240-248) and the cold delete path.
 #include "../../include/muninn_hip.h"
 #include "mn_device.hpp"
+#include "mn_comm.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -122,6 +123,10 @@ struct mn_index {
     int spec_epoch = 0;
     std::vector<int> staged; // mn_hnsw_batch_stage: slots added but not yet searched / linked
     DevBuf<int> d_staged;
+    // multi-GPU exchange buffers (mn_hnsw_build_shared / mn_hnsw_search_sharded)
+    DevBuf<int> sh_sel, sh_nsel, sh_gcnt, sh_lcnt;
+    DevBuf<long long> sh_gids, sh_lids;
+    DevBuf<float> sh_gd, sh_ld;
     long long last_spec_searched = 0; // searches the last speculative build ran (≥ nodes inserted)
     bool broken = false; // an insert failed after its kernels had begun to rewrite link rows: nothing can be trusted
     mn_launch_stats last = {0, 0, 0, 0};
@@ -576,6 +581,8 @@ extern "C" void mn_hnsw_destroy(mn_index *x) {
     x->lk_newrows.release(); x->ws_counters.release(); x->ws_state.release();
     x->er_slot.release(); x->er_level.release(); x->er_nbr.release(); x->er_dist.release();
     x->d_staged.release();
+    x->sh_sel.release(); x->sh_nsel.release(); x->sh_gcnt.release(); x->sh_lcnt.release(); x->sh_gids.release();
+    x->sh_lids.release(); x->sh_gd.release(); x->sh_ld.release();
     x->ws_readlog.release(); x->ws_nread.release(); x->ws_ncommit.release(); x->d_stamp0.release(); x->d_stampU.release();
     if (x->ev0) (void)hipEventDestroy(x->ev0);
     if (x->ev1) (void)hipEventDestroy(x->ev1);
@@ -1241,6 +1248,110 @@ extern "C" int mn_hnsw_batch_link(mn_index *x, const int *d_sel, const int *d_ns
     if (slots.empty())
         return 0;
     return link_batch(x, slots, x->d_staged.p, x->max_level + 1, d_sel, d_nsel);
+}
+
+// ───────────────────────── multi-GPU: shared build, sharded search ─────────────────────────
+
+extern "C" int mn_hnsw_build_shared(mn_index *x, mn_comm *c, const int64_t *ids, const float *vectors, int64_t n, int grow_div,
+                                    int max_batch, int min_split) {
+    MN_STAGE_CHECK(x)
+    if (grow_div <= 0)
+        grow_div = 16;
+    if (max_batch <= 0)
+        max_batch = 8192;
+    if (min_split <= 0)
+        min_split = 256;
+    const int world = c ? c->world : 1, rank = c ? c->rank : 0;
+    hipStream_t st = x->stream;
+    int64_t pos = 0;
+    while (pos < n) {
+        int64_t b = std::max<int64_t>(1, x->node_count / grow_div); // the batches of mn_hnsw_build
+        b = std::min<int64_t>(b, max_batch);
+        b = std::min<int64_t>(b, n - pos);
+        const int m = mn_hnsw_batch_stage(x, ids + pos, vectors + (size_t)pos * x->dim, b);
+        if (m < 0)
+            return -1;
+        pos += b;
+        if (m == 0)
+            continue;
+        const int nlev = x->max_level + 1, w0 = x->M_max0;
+        const bool split = world > 1 && m >= min_split;
+        const int per = split ? (m + world - 1) / world : m;
+        const int rows = split ? per * world : m;
+        const size_t row_sel = (size_t)nlev * w0;
+        if (x->sh_sel.reserve((size_t)rows * row_sel, false, st) || x->sh_nsel.reserve((size_t)rows * nlev, false, st))
+            return -1;
+        HIPCHK(hipMemsetAsync(x->sh_sel.p, 0xFF, (size_t)rows * row_sel * sizeof(int), st));
+        HIPCHK(hipMemsetAsync(x->sh_nsel.p, 0, (size_t)rows * nlev * sizeof(int), st));
+        const int lo = split ? std::min(m, rank * per) : 0, hi = split ? std::min(m, rank * per + per) : m;
+        if (mn_hnsw_batch_search(x, lo, hi, x->sh_sel.p, x->sh_nsel.p)) // this rank's slice of the batch's searches
+            return -1;
+        if (split) { // in place: rank r's rows already sit at r * per
+            if (mn_comm_allgather_dev(c, x->sh_sel.p + (size_t)rank * per * row_sel, x->sh_sel.p, (size_t)per * row_sel * sizeof(int), st) ||
+                mn_comm_allgather_dev(c, x->sh_nsel.p + (size_t)rank * per * nlev, x->sh_nsel.p, (size_t)per * nlev * sizeof(int), st)) {
+                set_err("mn_hnsw_build_shared: %s", mn_comm_last_error_str());
+                return -1;
+            }
+        }
+        if (mn_hnsw_batch_link(x, x->sh_sel.p, x->sh_nsel.p)) // every replica links the whole batch
+            return -1;
+    }
+    return 0;
+}
+
+extern "C" int mn_hnsw_search_sharded_dev(mn_index *x, mn_comm *c, const float *d_queries, int64_t nq, int k, int ef,
+                                          int64_t *d_ids, float *d_dists, int *d_counts) {
+    if (use_device(x))
+        return -1;
+    if (nq <= 0)
+        return 0;
+    const int world = c ? c->world : 1, rank = c ? c->rank : 0;
+    if (world > 64) {
+        set_err("mn_hnsw_search_sharded: more than 64 shards");
+        return -1;
+    }
+    hipStream_t st = x->stream;
+    const size_t per = (size_t)nq * k;
+    if (x->sh_gids.reserve(per * world, false, st) || x->sh_gd.reserve(per * world, false, st) ||
+        x->sh_gcnt.reserve((size_t)nq * world, false, st))
+        return -1;
+    // this shard's top-k straight into its slot of the gather buffers, then the one exchange step, then the merge
+    long long *my_ids = x->sh_gids.p + per * rank;
+    float *my_d = x->sh_gd.p + per * rank;
+    int *my_c = x->sh_gcnt.p + (size_t)nq * rank;
+    if (mn_hnsw_search_batch_dev(x, d_queries, nq, k, ef, (int64_t *)my_ids, my_d, my_c))
+        return -1;
+    if (world > 1 || (c && c->nccl)) {
+        if (mn_comm_allgather_dev(c, my_ids, x->sh_gids.p, per * sizeof(long long), st) ||
+            mn_comm_allgather_dev(c, my_d, x->sh_gd.p, per * sizeof(float), st) ||
+            mn_comm_allgather_dev(c, my_c, x->sh_gcnt.p, (size_t)nq * sizeof(int), st)) {
+            set_err("mn_hnsw_search_sharded: %s", mn_comm_last_error_str());
+            return -1;
+        }
+    }
+    mn_launch_merge_topk(x->sh_gids.p, x->sh_gd.p, x->sh_gcnt.p, world, nq, k, (long long *)d_ids, d_dists, d_counts, st);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mn_hnsw_search_sharded(mn_index *x, mn_comm *c, const float *queries, int64_t nq, int k, int ef, int64_t *out_ids,
+                                      float *out_dists, int *out_counts) {
+    if (use_device(x))
+        return -1;
+    if (nq <= 0)
+        return 0;
+    hipStream_t st = x->stream;
+    if (x->ws_q.reserve((size_t)nq * x->dim, false, st) || x->sh_lids.reserve((size_t)nq * k, false, st) ||
+        x->sh_ld.reserve((size_t)nq * k, false, st) || x->sh_lcnt.reserve((size_t)nq, false, st))
+        return -1;
+    HIPCHK(hipMemcpyAsync(x->ws_q.p, queries, (size_t)nq * x->dim * sizeof(float), hipMemcpyHostToDevice, st));
+    if (mn_hnsw_search_sharded_dev(x, c, x->ws_q.p, nq, k, ef, (int64_t *)x->sh_lids.p, x->sh_ld.p, x->sh_lcnt.p))
+        return -1;
+    HIPCHK(hipMemcpyAsync(out_ids, x->sh_lids.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out_dists, x->sh_ld.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out_counts, x->sh_lcnt.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
 }
 
 // ───────────────────────── delete (cold path, host-side list surgery) ─────────────────────────

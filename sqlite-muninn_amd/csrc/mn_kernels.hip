@@ -418,3 +418,49 @@ void mn_launch_edge_rows(const MnDevIndex &ix, const int *d_row_slot, const int 
     }
 #undef MN_ER
 }
+
+// ───────────────────────── k_merge_topk ─────────────────────────
+// The exchange step of a sharded index: every shard returned its k nearest in ascending order; the global k nearest
+// are the first k of the merge.  Equal distances: lower shard rank first, then position in the shard's list (the same
+// total order as a stable sort of the shard-major concatenation).  One thread per query; world <= 64.
+__global__ void k_merge_topk(const long long *g_ids, const float *g_dists, const int *g_counts, int world, long long nq, int k,
+                             long long *out_ids, float *out_dists, int *out_counts) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq)
+        return;
+    int pos[64];
+    for (int w = 0; w < world; w++)
+        pos[w] = 0;
+    int n = 0;
+    for (; n < k; n++) {
+        int bw = -1;
+        float bd = 0.0f;
+        for (int w = 0; w < world; w++) {
+            if (pos[w] >= g_counts[(size_t)w * nq + q])
+                continue;
+            const float d = g_dists[((size_t)w * nq + q) * k + pos[w]];
+            if (bw < 0 || d < bd) { // strict: ties keep the lower shard
+                bw = w;
+                bd = d;
+            }
+        }
+        if (bw < 0)
+            break;
+        out_ids[q * k + n] = g_ids[((size_t)bw * nq + q) * k + pos[bw]];
+        out_dists[q * k + n] = bd;
+        pos[bw]++;
+    }
+    out_counts[q] = n;
+    for (int i = n; i < k; i++) {
+        out_ids[q * k + i] = -1;
+        out_dists[q * k + i] = 0.0f;
+    }
+}
+
+void mn_launch_merge_topk(const long long *g_ids, const float *g_dists, const int *g_counts, int world, long long nq, int k,
+                          long long *out_ids, float *out_dists, int *out_counts, hipStream_t st) {
+    if (nq <= 0)
+        return;
+    hipLaunchKernelGGL(k_merge_topk, dim3((unsigned)((nq + 127) / 128)), dim3(128), 0, st, g_ids, g_dists, g_counts, world, nq, k,
+                       out_ids, out_dists, out_counts);
+}

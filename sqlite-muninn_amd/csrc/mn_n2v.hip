@@ -300,6 +300,7 @@ static unsigned h_xs32(unsigned *s) {
 }
 
 #include "mn_n2v_batched.hpp"
+#include "mn_comm.hpp"
 
 static int valid_params(const mn_n2v_params *prm) { // src/node2vec.c:443-464
     return prm && prm->dim > 0 && prm->dim <= 1024 && prm->p > 0 && prm->q > 0 && prm->num_walks > 0 && prm->walk_length > 0 &&
@@ -489,6 +490,79 @@ extern "C" void mn_n2v_end(mn_n2v_session *S) {
     (void)hipSetDevice(S->device);
     (void)hipDeviceSynchronize();
     delete S;
+}
+
+// MN_N2V_BATCHED over several GPUs (config 4), see muninn_hip.h.  The slices are contiguous and gathered in rank order, so
+// the sample order every replica applies is the single-GPU order.
+extern "C" int mn_node2vec_train_shared(mn_comm *c, int n, const int *off, const int *adj, const mn_n2v_params *prm, int device,
+                                        float *out, mn_n2v_stats *stats) {
+    if (stats)
+        memset(stats, 0, sizeof(*stats));
+    if (n == 0)
+        return 0;
+    if (!valid_params(prm)) {
+        nset_err("mn_node2vec_train_shared: invalid parameters (src/node2vec.c:443-464)");
+        return -1;
+    }
+    const int world = c ? c->world : 1, rank = c ? c->rank : 0;
+    mn_n2v_session *S = mn_n2v_begin(n, off, adj, prm, device);
+    if (!S)
+        return -1;
+    const int B = S->B, cap = S->cap, pcap = prm->walk_length, dim = prm->dim;
+    const int per_max = (B + world - 1) / world;
+    int *lc = nullptr, *lt = nullptr, *lpc = nullptr, *gc = nullptr, *gt = nullptr, *gpc = nullptr;
+    float *le = nullptr, *lpn = nullptr, *ge = nullptr, *gpn = nullptr;
+    auto cleanup = [&](int rc) {
+        (void)hipDeviceSynchronize();
+        void *ps[] = {lc, lt, lpc, gc, gt, gpc, le, lpn, ge, gpn};
+        for (void *q : ps)
+            (void)hipFree(q);
+        mn_n2v_end(S);
+        return rc;
+    };
+    const size_t ls = (size_t)per_max * cap, lp = (size_t)per_max * pcap;
+    if (hipMalloc(&lc, ls * 4) != hipSuccess || hipMalloc(&lt, ls * 4) != hipSuccess || hipMalloc(&le, ls * 4) != hipSuccess ||
+        hipMalloc(&lpc, lp * 4) != hipSuccess || hipMalloc(&lpn, lp * dim * 4) != hipSuccess ||
+        hipMalloc(&gc, ls * world * 4) != hipSuccess || hipMalloc(&gt, ls * world * 4) != hipSuccess ||
+        hipMalloc(&ge, ls * world * 4) != hipSuccess || hipMalloc(&gpc, lp * world * 4) != hipSuccess ||
+        hipMalloc(&gpn, lp * world * dim * 4) != hipSuccess) {
+        nset_err("mn_node2vec_train_shared: out of device memory for the exchange buffers");
+        return cleanup(-1);
+    }
+    int rc = 0;
+    for (int epoch = 0; epoch < prm->epochs && rc == 0; epoch++)
+        for (int w = 0; w < prm->num_walks && rc == 0; w++)
+            for (int b0 = 0; b0 < n && rc == 0; b0 += B) {
+                const int b1 = std::min(n, b0 + B);
+                const int per = (b1 - b0 + world - 1) / world;
+                const int lo = std::min(b1, b0 + rank * per), hi = std::min(b1, lo + per);
+                // unused slots carry -1 (ranks with a short or empty slice still contribute `per` walks' worth of slots)
+                if (hipMemsetAsync(lc, 0xFF, (size_t)per * cap * 4, nullptr) != hipSuccess ||
+                    hipMemsetAsync(lt, 0xFF, (size_t)per * cap * 4, nullptr) != hipSuccess ||
+                    hipMemsetAsync(le, 0, (size_t)per * cap * 4, nullptr) != hipSuccess ||
+                    hipMemsetAsync(lpc, 0xFF, (size_t)per * pcap * 4, nullptr) != hipSuccess) {
+                    nset_err("mn_node2vec_train_shared: memset failed");
+                    rc = -1;
+                    break;
+                }
+                if (hi > lo)
+                    rc = n2v_samples(S, epoch, w, lo, hi, lc, lt, le, lpc, lpn);
+                if (rc)
+                    break;
+                if (mn_comm_allgather_dev(c, lc, gc, (size_t)per * cap * 4, nullptr) ||
+                    mn_comm_allgather_dev(c, lt, gt, (size_t)per * cap * 4, nullptr) ||
+                    mn_comm_allgather_dev(c, le, ge, (size_t)per * cap * 4, nullptr) ||
+                    mn_comm_allgather_dev(c, lpc, gpc, (size_t)per * pcap * 4, nullptr) ||
+                    mn_comm_allgather_dev(c, lpn, gpn, (size_t)per * pcap * dim * 4, nullptr)) {
+                    nset_err("mn_node2vec_train_shared: %s", mn_comm_last_error_str());
+                    rc = -1;
+                    break;
+                }
+                rc = n2v_apply(S, gc, gt, ge, (int64_t)world * per * cap, gpc, gpn, (int64_t)world * per * pcap);
+            }
+    if (rc == 0)
+        rc = mn_n2v_finish(S, out, stats);
+    return cleanup(rc < 0 ? -1 : n);
 }
 
 extern "C" int mn_node2vec_train(int n, const int *off, const int *adj, const mn_n2v_params *prm, int mode, int device,

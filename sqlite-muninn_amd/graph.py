@@ -34,6 +34,8 @@ GRAPH_SYMBOLS = [
     ("mn_node2vec_train", C.c_int, [C.c_int, _i32p, _i32p, C.POINTER(N2vParams), C.c_int, C.c_int,
                                     np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS"), C.POINTER(N2vStats)]),
     ("mn_node2vec_last_error", C.c_char_p, []),
+    ("mn_node2vec_train_shared", C.c_int, [C.c_void_p, C.c_int, _i32p, _i32p, C.POINTER(N2vParams), C.c_int,
+                                           np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS"), C.POINTER(N2vStats)]),
     ("mn_n2v_begin", C.c_void_p, [C.c_int, _i32p, _i32p, C.POINTER(N2vParams), C.c_int]),
     ("mn_n2v_batch_walks", C.c_int, [C.c_void_p]),
     ("mn_n2v_sample_slots", C.c_int, [C.c_void_p]),

@@ -90,6 +90,18 @@ SYMBOLS = [
     ("mn_dev_upload", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     ("mn_dev_download", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     ("mn_hnsw_bruteforce_topk", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, _i64p]),
+    # multi-GPU
+    ("mn_comm_unique_id", C.c_int, [C.c_void_p]),
+    ("mn_comm_init_rccl", C.c_void_p, [C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    ("mn_comm_init_host", C.c_void_p, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    ("mn_comm_world", C.c_int, [C.c_void_p]),
+    ("mn_comm_rank", C.c_int, [C.c_void_p]),
+    ("mn_comm_destroy", None, [C.c_void_p]),
+    ("mn_comm_last_error", C.c_char_p, []),
+    ("mn_hnsw_build_shared", C.c_int, [C.c_void_p, C.c_void_p, _i64p, _f32p, C.c_int64, C.c_int, C.c_int, C.c_int]),
+    ("mn_hnsw_search_sharded_dev", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]),
+    ("mn_hnsw_search_sharded", C.c_int, [C.c_void_p, C.c_void_p, _f32p, C.c_int64, C.c_int, C.c_int, _i64p, _f32p, _i32p]),
 ]
 
 _lib = None

@@ -242,3 +242,108 @@ def test_bench_refuses_a_gpus_flag_that_disagrees_with_the_launcher():
     env = dict(os.environ, WORLD_SIZE="4", RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env)
     assert r.returncode != 0 and "disagrees with WORLD_SIZE" in r.stderr
+
+
+def _cfg3_worker(rank, world, port, q):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import muninn_amd
+
+    pkg = muninn_amd.pkg
+    n, d, k = 4000, 16, 10
+    X = np.random.default_rng(42).standard_normal((n, d), dtype=np.float32)
+    X[7] = X[6]  # the same vector in both shards: the merge's tie rule (distance, shard, position) is exercised
+    ids = np.arange(n, dtype=np.int64)
+    Q = np.random.default_rng(43).standard_normal((64, d), dtype=np.float32)
+    Q[0] = X[6]
+    mine = ids % world == rank  # config 3: shard = rowid mod world
+    g = pkg.HnswIndex(d, "l2", 8, 60)
+    assert g.insert_batch(ids[mine], X[mine], pkg.BUILD_SEQUENTIAL) == 0  # the reference's graph of this shard
+    comm = pkg.parallel.Comm(0)
+    out = [pkg.parallel.search_sharded(g, comm, Q, k, ef) for ef in (10, 80)]
+    q.put((rank, out))
+    comm.close()
+    g.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_config3_sharded_index_on_the_hip_path_equals_the_reference_built_per_shard(gpu, orc):
+    """BASELINE config 3 at a size the oracle finishes: 2 shards by rowid mod 2, each rank's HIP index searched on the
+    device, per-shard top-k all-gathered and merged below the C-ABI (mn_hnsw_search_sharded).  Expected = the oracle
+    (= the reference's hnsw_insert / hnsw_search, pinned) built once per shard on the same vectors + the merge in the
+    total order (distance, shard, position) — SURVEY §8(e)'s oracle for this configuration.  Ids and distance bits."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cfg3_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(_collect(procs, q, world, 300), key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    n, d, k = 4000, 16, 10
+    X = np.random.default_rng(42).standard_normal((n, d), dtype=np.float32)
+    X[7] = X[6]
+    ids = np.arange(n, dtype=np.int64)
+    Q = np.random.default_rng(43).standard_normal((64, d), dtype=np.float32)
+    Q[0] = X[6]
+    shards = []
+    for r in range(world):
+        o = orc.Oracle(d, "l2", 8, 60)
+        assert o.insert_many(ids[ids % world == r], X[ids % world == r]) == 0
+        shards.append(o)
+    for j, ef in enumerate((10, 80)):
+        per = [o.search_many(Q, k, ef) for o in shards]
+        wi = np.full((len(Q), k), -1, np.int64)
+        wd = np.zeros((len(Q), k), np.float32)
+        wc = np.zeros(len(Q), np.int32)
+        for qi in range(len(Q)):
+            cand = [(per[r][1][qi][p], r, p, per[r][0][qi][p]) for r in range(world) for p in range(per[r][2][qi])]
+            cand.sort(key=lambda t: (t[0], t[1], t[2]))
+            for p, c in enumerate(cand[:k]):
+                wi[qi, p], wd[qi, p] = c[3], c[0]
+            wc[qi] = min(k, len(cand))
+        for rank, out in res:  # every rank holds the merged result
+            gi, gd, gc = out[j]
+            assert np.array_equal(gi, wi) and np.array_equal(gd.view(np.int32), wd.view(np.int32)) and np.array_equal(gc, wc), (rank, ef)
+    assert set(res[0][1][0][0][0][:2].tolist()) == {6, 7}  # the duplicated vector: shard 0's copy (rowid 6) first
+    assert res[0][1][0][0][0][0] == 6
+
+
+@pytest.mark.gpu
+def test_rccl_transport_single_rank(gpu):
+    """The production transport on real hardware as far as one GPU allows: librccl is loaded on demand, a world-1
+    communicator is created from a unique id, and the shared build / sharded search run their all-gathers through
+    ncclAllGather on the index's stream — results equal to the plain single-GPU entry points."""
+    import ctypes as C
+
+    L = gpu.lib()
+    idb = C.create_string_buffer(128)
+    assert L.mn_comm_unique_id(idb) == 0, L.mn_comm_last_error()
+    c = L.mn_comm_init_rccl(1, 0, idb, 0)
+    assert c, L.mn_comm_last_error()
+    assert L.mn_comm_world(c) == 1 and L.mn_comm_rank(c) == 0
+    X = np.random.default_rng(3).standard_normal((3000, 24)).astype(np.float32)
+    ids = np.arange(1, 3001, dtype=np.int64)
+    Q = np.random.default_rng(4).standard_normal((50, 24)).astype(np.float32)
+    a, b = gpu.HnswIndex(24, "cosine", 8, 60), gpu.HnswIndex(24, "cosine", 8, 60)
+    assert a.build(ids, X, 16, 512) == 0
+    assert L.mn_hnsw_build_shared(b.h, c, ids, X, len(ids), 16, 512, 64) == 0, gpu.hnsw._err()
+    assert np.array_equal(a.export_links(0), b.export_links(0)) and a.entry_point == b.entry_point
+    wi, wd, wc = a.search_batch(Q, 10, 64)
+    gi = np.empty((50, 10), np.int64)
+    gd = np.empty((50, 10), np.float32)
+    gc = np.empty(50, np.int32)
+    assert L.mn_hnsw_search_sharded(b.h, c, Q, 50, 10, 64, gi, gd, gc) == 0, gpu.hnsw._err()
+    assert np.array_equal(gi, wi) and np.array_equal(gd.view(np.int32), wd.view(np.int32)) and np.array_equal(gc, wc)
+    a.close()
+    b.close()
+    L.mn_comm_destroy(c)
