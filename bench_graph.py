@@ -73,7 +73,7 @@ def _max_over_ranks(dist, args, x):
 
 def bench_node2vec(pkg, args):
     n, m, dim = args.n2v_nodes, args.n2v_edges, 128
-    rank, world, dist, dev = _dist_ctx(args)
+    rank, world, dist, dev = args.ctx
     prm = dict(p=1.0, q=1.0, num_walks=10, walk_length=80, window=5, neg_samples=5, learning_rate=0.025, epochs=1)
     t0 = time.perf_counter()
     off, adj = pkg.graph.n2v_csr_from_edges(n, *er_edges(n, m))
@@ -160,7 +160,7 @@ def bench_node2vec(pkg, args):
 
 def bench_leiden(pkg, args):
     n = args.leiden_nodes
-    rank, world, dist, dev = _dist_ctx(args)  # run_leiden does not shard (1 GPU): N > 1 = N independent replicas
+    rank, world, dist, dev = args.ctx  # run_leiden does not shard (1 GPU): N > 1 = N independent replicas
     t0 = time.perf_counter()
     s, d, truth = pkg.lfr.lfr_like(n, 40, min(200, n // 10), 0.3)
     g = pkg.graph.graph_from_edges(n, s, d, device=dev)
@@ -249,6 +249,9 @@ def main():
     from bench import spawn_ranks_if_needed
 
     spawn_ranks_if_needed(args.gpus, os.path.abspath(__file__), sys.argv[1:])
+    # N > 1: torch selects its device BEFORE libmuninn_hip.so touches HIP (torch carries its own HIP runtime; initialised
+    # second, it reports "No HIP GPUs are available")
+    args.ctx = _dist_ctx(args)
     import muninn_amd
 
     pkg = muninn_amd.pkg

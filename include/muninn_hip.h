@@ -283,6 +283,28 @@ int mn_n2v_sync(mn_n2v_session *s);
 int mn_n2v_finish(mn_n2v_session *s, float *out, mn_n2v_stats *stats); /* L2 normalise, download [n][dim] */
 void mn_n2v_end(mn_n2v_session *s);
 
+/* ---- graph_tvf.c's remaining edge-list algorithms ----
+ * Nodes are first-seen indices (src of row 0, dst of row 0, src of row 1, ... as pr_adj_find_or_add / uf_find_or_add
+ * number them, src/graph_tvf.c:1591-1613,1231-1247); src[e] -> dst[e] are the edge table's rows in order, duplicates and
+ * self loops kept as the reference keeps them.  Host arrays. */
+typedef struct {
+    double device_ms;
+    int iterations; /* PageRank: iterations run; components: hook rounds */
+    int64_t aux;    /* PageRank: dangling nodes */
+} mn_graph_algo_stats;
+/* run_pagerank (src/graph_tvf.c:1631-1797): rank_out[n] f64, bit-identical to the reference's sequential push loop
+ * (the same additions in the same order, pulled per target).  0 / -1. */
+int mn_graph_pagerank(int n_nodes, int64_t n_edges, const int *src, const int *dst, double damping, int iterations, int device,
+                      double *rank_out, mn_graph_algo_stats *stats);
+typedef enum {
+    MN_COMPONENTS_EXACT = 0, /* the reference's union sequence replayed: component_id = its union-find root */
+    MN_COMPONENTS_FAST = 1   /* parallel hooking: same partition and sizes, component_id = smallest node index */
+} mn_components_mode;
+/* run_components (src/graph_tvf.c:1314-1366): component_id[n], component_size[n].  0 / -1. */
+int mn_graph_components(int n_nodes, int64_t n_edges, const int *src, const int *dst, int mode, int device, int *component_id,
+                        int *component_size, mn_graph_algo_stats *stats);
+const char *mn_graph_algo_last_error(void);
+
 /* ---- multi-GPU: one rank per GPU of a node, processes or threads; RCCL over xGMI ----
  * The reference is single-device; these entry points are what its host (hnsw_vtab.c / node2vec.c) would call to use the
  * node's other GPUs.  The only collective is an all-gather of equal-sized device buffers:

@@ -66,3 +66,22 @@ def n2v_cases():
         "karate_pq": (KARATE, (12, 0.25, 4.0, 3, 30, 4, 3, 0.025, 2)),
         "er60_dim70": ([(int(a), int(b)) for a, b in zip(er_s, er_d)], (70, 2.0, 0.5, 2, 25, 3, 4, 0.03, 1)),
     }
+
+
+def tvf_cases():
+    """name -> (rows of (src, dst) text ids or None, damping or None, iterations or None) for graph_pagerank /
+    graph_components: dangling nodes, duplicate rows, self loops, NULLs, isolated pairs, a chain, a star."""
+    r = np.random.default_rng(11)
+    c = {}
+    c["karate"] = ([(str(a), str(b)) for a, b in KARATE], None, None)
+    rows = [(f"n{a}", f"n{b}") for a, b in r.integers(0, 40, (120, 2))]
+    rows += [("x", "x"), ("y", None), (None, "z"), ("iso1", "iso2"), ("n3", "sink"), ("n3", "sink"), ("sink2", "n5")]
+    c["messy"] = (rows, None, None)
+    c["messy_d50_i7"] = (rows, 0.5, 7)
+    c["chain"] = ([(f"c{i}", f"c{i + 1}") for i in range(60)], 0.85, 30)
+    c["star_in"] = ([(f"leaf{i}", "hub") for i in range(50)], None, None)  # 50 sources, one dangling hub
+    rows = [(f"v{a}", f"v{b}") for a, b in r.integers(0, 600, (1500, 2))]
+    c["sparse600"] = (rows, 0.9, 15)  # many dangling nodes, many components
+    c["two_rows"] = ([("a", "b"), ("b", "a")], 0.85, 1)
+    c["zero_iterations"] = ([("a", "b"), ("c", "a")], 0.85, 0)
+    return c

@@ -789,3 +789,90 @@ int orc_node2vec_train_batched(const orc_n2v_graph *g, const orc_n2v_params *p, 
     free(smp);
     return N;
 }
+
+
+/* ───────────────────────── f-4: PageRank, components (src/graph_tvf.c) ───────────────────────── */
+
+int orc_pagerank(int n, int n_edges, const int *src, const int *dst, double damping, int iterations, double *rank_out) {
+    if (n <= 0)
+        return 0;
+    /* pr_adj_add_edge (:1615-1622): out lists in row order */
+    int *cnt = (int *)calloc((size_t)n, sizeof(int)), *off = (int *)calloc((size_t)n + 1, sizeof(int));
+    int *tgt = (int *)malloc((size_t)(n_edges ? n_edges : 1) * sizeof(int)), *cur = (int *)malloc((size_t)n * sizeof(int));
+    double *a = (double *)malloc((size_t)n * sizeof(double)), *b = (double *)malloc((size_t)n * sizeof(double));
+    if (!cnt || !off || !tgt || !cur || !a || !b)
+        return -1;
+    for (int e = 0; e < n_edges; e++)
+        cnt[src[e]]++;
+    for (int i = 0; i < n; i++)
+        off[i + 1] = off[i] + cnt[i];
+    memcpy(cur, off, (size_t)n * sizeof(int));
+    for (int e = 0; e < n_edges; e++)
+        tgt[cur[src[e]]++] = dst[e];
+    double init_rank = 1.0 / n; /* :1684-1686 */
+    for (int i = 0; i < n; i++)
+        a[i] = init_rank;
+    double teleport = (1.0 - damping) / n; /* :1689 */
+    for (int it = 0; it < iterations; it++) {
+        for (int i = 0; i < n; i++)
+            b[i] = teleport;
+        for (int i = 0; i < n; i++) {
+            if (cnt[i] == 0) { /* dangling: its rank goes to every node (:1694-1698) */
+                double share = damping * a[i] / n;
+                for (int j = 0; j < n; j++)
+                    b[j] += share;
+            } else {
+                double share = damping * a[i] / cnt[i];
+                for (int e = off[i]; e < off[i + 1]; e++)
+                    b[tgt[e]] += share;
+            }
+        }
+        double *t = a;
+        a = b;
+        b = t;
+    }
+    memcpy(rank_out, a, (size_t)n * sizeof(double));
+    free(cnt); free(off); free(tgt); free(cur); free(a); free(b);
+    return 0;
+}
+
+static int ouf_find(int *parent, int x) { /* :1249-1256 */
+    while (parent[x] != x) {
+        parent[x] = parent[parent[x]];
+        x = parent[x];
+    }
+    return x;
+}
+
+int orc_components(int n, int n_edges, const int *src, const int *dst, int *component_id, int *component_size) {
+    if (n <= 0)
+        return 0;
+    int *parent = (int *)malloc((size_t)n * sizeof(int)), *rank = (int *)calloc((size_t)n, sizeof(int));
+    int *size = (int *)calloc((size_t)n, sizeof(int));
+    if (!parent || !rank || !size)
+        return -1;
+    for (int i = 0; i < n; i++)
+        parent[i] = i;
+    for (int e = 0; e < n_edges; e++) { /* uf_union (:1258-1273) */
+        int ra = ouf_find(parent, src[e]), rb = ouf_find(parent, dst[e]);
+        if (ra == rb)
+            continue;
+        if (rank[ra] < rank[rb]) {
+            int t = ra;
+            ra = rb;
+            rb = t;
+        }
+        parent[rb] = ra;
+        if (rank[ra] == rank[rb])
+            rank[ra]++;
+    }
+    for (int i = 0; i < n; i++)
+        size[ouf_find(parent, i)]++;
+    for (int i = 0; i < n; i++) {
+        int r = ouf_find(parent, i);
+        component_id[i] = r;
+        component_size[i] = size[r];
+    }
+    free(parent); free(rank); free(size);
+    return 0;
+}

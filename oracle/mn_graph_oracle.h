@@ -56,6 +56,12 @@ int orc_biased_walk(const orc_n2v_graph *g, int start, double p, double q, int w
  * returns n; off must hold n_max+1 ints, adj 2*n_edges ints, index_of_id n_ids ints (or NULL). */
 int orc_n2v_build_graph(int n_edges, const int *src, const int *dst, int n_ids, int *off, int *adj, int *index_of_id);
 
+/* run_pagerank's power iteration (src/graph_tvf.c:1676-1716) over first-seen node indices; edges src[e] -> dst[e] in
+ * edge-table row order (duplicates and self loops kept).  rank_out[n]. */
+int orc_pagerank(int n, int n_edges, const int *src, const int *dst, double damping, int iterations, double *rank_out);
+/* run_components (src/graph_tvf.c:1314-1366) with the union-find of :1231-1273: component_id = root, component_size */
+int orc_components(int n, int n_edges, const int *src, const int *dst, int *component_id, int *component_size);
+
 #ifdef __cplusplus
 }
 #endif

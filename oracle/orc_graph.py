@@ -217,3 +217,65 @@ def ref_node2vec_sql(edges, dim, p, q, num_walks, walk_length, window, neg, lr, 
     c.close()
     assert n == len(rows)
     return np.array([np.frombuffer(r[1], np.float32) for r in rows], np.float32).reshape(n, dim)
+
+
+# ───────────────────────── f-4: PageRank, components ─────────────────────────
+
+def first_seen_edges(rows):
+    """rows: iterable of (src, dst) node ids as the edge table holds them (None = SQL NULL, skipped as the reference
+    skips it).  Returns (ids in first-seen order — src of a row before its dst — , src idx, dst idx)."""
+    idx, ids, s, d = {}, [], [], []
+    for a, b in rows:
+        if a is None or b is None:
+            continue
+        for x in (a, b):
+            if x not in idx:
+                idx[x] = len(ids)
+                ids.append(x)
+        s.append(idx[a])
+        d.append(idx[b])
+    return ids, np.asarray(s, np.int32), np.asarray(d, np.int32)
+
+
+def pagerank(n, src, dst, damping=0.85, iterations=20):
+    L = _lib()
+    L.orc_pagerank.argtypes = [C.c_int, C.c_int, _i32p, _i32p, C.c_double, C.c_int, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")]
+    src, dst = np.ascontiguousarray(src, np.int32), np.ascontiguousarray(dst, np.int32)
+    out = np.zeros(max(n, 1), np.float64)
+    assert L.orc_pagerank(n, len(src), src if len(src) else np.zeros(1, np.int32), dst if len(dst) else np.zeros(1, np.int32),
+                          float(damping), int(iterations), out) == 0
+    return out[:n]
+
+
+def components(n, src, dst):
+    L = _lib()
+    L.orc_components.argtypes = [C.c_int, C.c_int, _i32p, _i32p, _i32p, _i32p]
+    src, dst = np.ascontiguousarray(src, np.int32), np.ascontiguousarray(dst, np.int32)
+    cid, csz = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+    assert L.orc_components(n, len(src), src if len(src) else np.zeros(1, np.int32), dst if len(dst) else np.zeros(1, np.int32),
+                            cid, csz) == 0
+    return cid[:n], csz[:n]
+
+
+def ref_graph_tvf(rows, damping=None, iterations=None):
+    """The reference's own graph_pagerank / graph_components through its SQL surface (oracle/_ref/muninn.so, build
+    container only).  rows: (src, dst) text ids or None.  Returns {"pagerank": [(node, rank)], "components": [(node, id, size)]}
+    in the order the TVFs emit them."""
+    import sqlite3
+
+    c = sqlite3.connect(":memory:")
+    c.enable_load_extension(True)
+    c.load_extension(REF_EXT_SO[:-3])
+    c.execute("CREATE TABLE e(s TEXT, d TEXT)")
+    c.executemany("INSERT INTO e VALUES (?, ?)", list(rows))
+    extra, args = "", []
+    if damping is not None:
+        extra += " AND damping = ?"
+        args.append(damping)
+    if iterations is not None:
+        extra += " AND iterations = ?"
+        args.append(iterations)
+    pr = c.execute("SELECT node, rank FROM graph_pagerank WHERE edge_table='e' AND src_col='s' AND dst_col='d'" + extra, args).fetchall()
+    cc = c.execute("SELECT node, component_id, component_size FROM graph_components WHERE edge_table='e' AND src_col='s' AND dst_col='d'").fetchall()
+    c.close()
+    return {"pagerank": pr, "components": cc}

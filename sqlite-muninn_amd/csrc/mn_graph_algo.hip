@@ -1,0 +1,353 @@
+// mn_graph_algo.hip — the reference's remaining edge-list algorithms on the device, gfx950:
+//   mn_graph_pagerank     run_pagerank  (src/graph_tvf.c:1631-1797)
+//   mn_graph_components   run_components (src/graph_tvf.c:1314-1366, union-find :1231-1273)
+//
+// PageRank.  The reference PUSHES: for i = 0..N-1 in order, rank_new[target] += share_i for every out-edge of i, and a
+// node without out-edges adds its share to EVERY node.  f64 addition is not associative, so the value of rank_new[j] is
+// defined by that order: teleport, then the shares of j's in-neighbours and of all dangling nodes interleaved by
+// ascending source index (edges of one source carry the same share, so their mutual order is immaterial).  The device
+// PULLS the same sequence: one thread owns a target j and walks its in-list (sources ascending, one entry per edge —
+// multi-edges count as often as in the reference) merged with the dangling list, which a workgroup stages through LDS
+// 256 entries at a time (every thread consumes the same dangling entries in the same order).  Bit-identical ranks.
+// HBM traffic per iteration: E·(4 + 8) B of in-list gathers + N·16 B; the N·D dangling term lives in LDS.
+//
+// Components.  The reference's component_id is the union-find root, which depends on the order of the unions (union by
+// rank, path halving): MN_COMPONENTS_EXACT replays that sequence (one lane, latency-bound — the mode the SQL surface
+// uses for inputs of the reference's own test sizes); MN_COMPONENTS_FAST hooks roots in parallel (atomicMin) until
+// nothing changes and compresses: the same partition and sizes, component_id = smallest node index of the component.
+#include "../../include/muninn_hip.h"
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_aerr;
+static void aset_err(const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_aerr = buf;
+}
+extern "C" const char *mn_graph_algo_last_error(void) { return g_aerr.c_str(); }
+
+#define ACHK(expr)                                                                                 \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess) {                                                                   \
+            aset_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return -1;                                                                             \
+        }                                                                                          \
+    } while (0)
+
+namespace {
+struct Bufs { // frees on scope exit
+    std::vector<void *> p;
+    template <typename T> T *alloc(size_t n) {
+        void *q = nullptr;
+        if (hipMalloc(&q, (n ? n : 1) * sizeof(T)) != hipSuccess)
+            return nullptr;
+        p.push_back(q);
+        return static_cast<T *>(q);
+    }
+    ~Bufs() {
+        for (void *q : p)
+            (void)hipFree(q);
+    }
+};
+} // namespace
+
+// ───────────────────────── PageRank ─────────────────────────
+
+// share_i (:1692-1704): damping * rank / N for a dangling node, damping * rank / out_count otherwise
+__global__ void k_pr_share(const double *rank, const int *outc, int n, double damping, double *share) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const int oc = outc[i];
+    share[i] = damping * rank[i] / (double)(oc == 0 ? n : oc);
+}
+
+#define PR_CHUNK 256
+__global__ void __launch_bounds__(PR_CHUNK)
+    k_pr_pull(const int *in_off, const int *in_src, const double *share, const int *dang, int n_dang, int n, double teleport,
+              double *rank_new) {
+    __shared__ int d_idx[PR_CHUNK];
+    __shared__ double d_sh[PR_CHUNK];
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int p = 0, pe = 0;
+    if (j < n) {
+        p = in_off[j];
+        pe = in_off[j + 1];
+    }
+    double acc = teleport; // :1689
+    int next_src = p < pe ? in_src[p] : 0x7fffffff;
+    for (int base = 0; base < n_dang; base += PR_CHUNK) {
+        __syncthreads();
+        if (base + (int)threadIdx.x < n_dang) {
+            const int di = dang[base + threadIdx.x];
+            d_idx[threadIdx.x] = di;
+            d_sh[threadIdx.x] = share[di];
+        }
+        __syncthreads();
+        const int cnt = n_dang - base < PR_CHUNK ? n_dang - base : PR_CHUNK;
+        for (int q = 0; q < cnt; q++) {
+            const int di = d_idx[q];
+            while (next_src < di) { // in-neighbours with a smaller index come first
+                acc += share[next_src];
+                p++;
+                next_src = p < pe ? in_src[p] : 0x7fffffff;
+            }
+            acc += d_sh[q];
+        }
+    }
+    while (p < pe) {
+        acc += share[in_src[p]];
+        p++;
+    }
+    if (j < n)
+        rank_new[j] = acc;
+}
+
+extern "C" int mn_graph_pagerank(int n, int64_t n_edges, const int *src, const int *dst, double damping, int iterations,
+                                 int device, double *rank_out, mn_graph_algo_stats *stats) {
+    if (stats)
+        memset(stats, 0, sizeof(*stats));
+    if (n < 0 || n_edges < 0 || (n_edges && (!src || !dst)) || n_edges > 0x7fffffffLL) {
+        aset_err("mn_graph_pagerank: bad arguments");
+        return -1;
+    }
+    if (n == 0)
+        return 0; // :1671-1674
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        aset_err("mn_graph_pagerank: HIP device %d not available (no CPU fallback)", device);
+        return -1;
+    }
+    ACHK(hipSetDevice(device));
+    // host preparation of the device input (as the reference builds its adjacency lists on the host): out-degrees, the
+    // dangling list, and the in-lists with sources ascending — a stable counting sort of the edges by source, then by target
+    const int E = (int)n_edges;
+    std::vector<int> outc((size_t)n, 0), in_off((size_t)n + 1, 0), in_src((size_t)(E ? E : 1));
+    for (int e = 0; e < E; e++) {
+        if (src[e] < 0 || src[e] >= n || dst[e] < 0 || dst[e] >= n) {
+            aset_err("mn_graph_pagerank: edge %d names a node outside [0, %d)", e, n);
+            return -1;
+        }
+        outc[src[e]]++;
+        in_off[dst[e] + 1]++;
+    }
+    for (int i = 0; i < n; i++)
+        in_off[i + 1] += in_off[i];
+    {
+        std::vector<int> out_off((size_t)n + 1, 0), by_src((size_t)(E ? E : 1)), cur((size_t)n);
+        for (int i = 0; i < n; i++)
+            out_off[i + 1] = out_off[i] + outc[i];
+        std::copy(out_off.begin(), out_off.begin() + n, cur.begin());
+        for (int e = 0; e < E; e++)
+            by_src[cur[src[e]]++] = dst[e];
+        std::copy(in_off.begin(), in_off.begin() + n, cur.begin());
+        for (int i = 0; i < n; i++)
+            for (int x = out_off[i]; x < out_off[i + 1]; x++)
+                in_src[cur[by_src[x]]++] = i;
+    }
+    std::vector<int> dang;
+    for (int i = 0; i < n; i++)
+        if (outc[i] == 0)
+            dang.push_back(i);
+    Bufs b;
+    int *d_outc = b.alloc<int>(n), *d_inoff = b.alloc<int>((size_t)n + 1), *d_insrc = b.alloc<int>(E), *d_dang = b.alloc<int>(dang.size());
+    double *d_r0 = b.alloc<double>(n), *d_r1 = b.alloc<double>(n), *d_share = b.alloc<double>(n);
+    if (!d_outc || !d_inoff || !d_insrc || !d_dang || !d_r0 || !d_r1 || !d_share) {
+        aset_err("mn_graph_pagerank: out of device memory");
+        return -1;
+    }
+    ACHK(hipMemcpy(d_outc, outc.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    ACHK(hipMemcpy(d_inoff, in_off.data(), ((size_t)n + 1) * sizeof(int), hipMemcpyHostToDevice));
+    if (E)
+        ACHK(hipMemcpy(d_insrc, in_src.data(), (size_t)E * sizeof(int), hipMemcpyHostToDevice));
+    if (!dang.empty())
+        ACHK(hipMemcpy(d_dang, dang.data(), dang.size() * sizeof(int), hipMemcpyHostToDevice));
+    std::vector<double> init((size_t)n, 1.0 / n); // :1684-1686
+    ACHK(hipMemcpy(d_r0, init.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    ACHK(hipEventCreate(&e0));
+    ACHK(hipEventCreate(&e1));
+    const double teleport = (1.0 - damping) / n; // :1689
+    const int nb = (n + PR_CHUNK - 1) / PR_CHUNK;
+    ACHK(hipEventRecord(e0, nullptr));
+    double *cur = d_r0, *nxt = d_r1;
+    for (int it = 0; it < iterations; it++) {
+        hipLaunchKernelGGL(k_pr_share, dim3(nb), dim3(PR_CHUNK), 0, nullptr, cur, d_outc, n, damping, d_share);
+        hipLaunchKernelGGL(k_pr_pull, dim3(nb), dim3(PR_CHUNK), 0, nullptr, d_inoff, d_insrc, d_share, d_dang, (int)dang.size(), n,
+                           teleport, nxt);
+        std::swap(cur, nxt);
+    }
+    ACHK(hipEventRecord(e1, nullptr));
+    ACHK(hipGetLastError());
+    ACHK(hipMemcpy(rank_out, cur, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (stats) {
+        stats->device_ms = ms;
+        stats->iterations = iterations;
+        stats->aux = (int64_t)dang.size();
+    }
+    return 0;
+}
+
+// ───────────────────────── connected components ─────────────────────────
+
+// uf_find (:1249-1256) / uf_union (:1258-1273), verbatim, one lane: the root ids depend on this very sequence
+__global__ void k_uf_seq(const int *src, const int *dst, long long n_edges, int *parent, int *rnk) {
+    if (threadIdx.x != 0 || blockIdx.x != 0)
+        return;
+    for (long long e = 0; e < n_edges; e++) {
+        int a = src[e], bq = dst[e];
+        while (parent[a] != a) { // path halving
+            parent[a] = parent[parent[a]];
+            a = parent[a];
+        }
+        while (parent[bq] != bq) {
+            parent[bq] = parent[parent[bq]];
+            bq = parent[bq];
+        }
+        if (a == bq)
+            continue;
+        if (rnk[a] < rnk[bq]) { // union by rank
+            const int t = a;
+            a = bq;
+            bq = t;
+        }
+        parent[bq] = a;
+        if (rnk[a] == rnk[bq])
+            rnk[a]++;
+    }
+}
+
+__global__ void k_uf_init(int *parent, int *rnk, int *size, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        parent[i] = i;
+        rnk[i] = 0;
+        size[i] = 0;
+    }
+}
+
+static __device__ __forceinline__ int uf_root(const int *parent, int x) { // read-only walk to the root
+    while (true) {
+        const int p = __hip_atomic_load(parent + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p == x)
+            return x;
+        x = p;
+    }
+}
+
+// FAST: hook the larger root under the smaller one (atomicMin keeps the forest acyclic: parents only ever decrease)
+__global__ void k_cc_hook(const int *src, const int *dst, long long n_edges, int *parent, int *changed) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_edges)
+        return;
+    int a = uf_root(parent, src[e]), b = uf_root(parent, dst[e]);
+    while (a != b) {
+        const int hi = a > b ? a : b, lo = a > b ? b : a;
+        const int old = atomicMin(parent + hi, lo);
+        if (old == hi) { // hooked a root
+            *changed = 1;
+            break;
+        }
+        // someone hooked `hi` meanwhile: carry on from where it points now
+        a = uf_root(parent, old);
+        b = lo;
+    }
+}
+
+__global__ void k_cc_root(const int *parent, int n, int *root, int *size) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const int r = uf_root(parent, i);
+    root[i] = r;
+    atomicAdd(size + r, 1);
+}
+
+__global__ void k_cc_out(const int *root, const int *size, int n, int *comp_size) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        comp_size[i] = size[root[i]];
+}
+
+extern "C" int mn_graph_components(int n, int64_t n_edges, const int *src, const int *dst, int mode, int device, int *component_id,
+                                   int *component_size, mn_graph_algo_stats *stats) {
+    if (stats)
+        memset(stats, 0, sizeof(*stats));
+    if (n < 0 || n_edges < 0 || (n_edges && (!src || !dst)) || (mode != MN_COMPONENTS_EXACT && mode != MN_COMPONENTS_FAST)) {
+        aset_err("mn_graph_components: bad arguments");
+        return -1;
+    }
+    if (n == 0)
+        return 0;
+    for (int64_t e = 0; e < n_edges; e++)
+        if (src[e] < 0 || src[e] >= n || dst[e] < 0 || dst[e] >= n) {
+            aset_err("mn_graph_components: edge %lld names a node outside [0, %d)", (long long)e, n);
+            return -1;
+        }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        aset_err("mn_graph_components: HIP device %d not available (no CPU fallback)", device);
+        return -1;
+    }
+    ACHK(hipSetDevice(device));
+    Bufs b;
+    int *d_src = b.alloc<int>((size_t)n_edges), *d_dst = b.alloc<int>((size_t)n_edges), *d_parent = b.alloc<int>(n), *d_rank = b.alloc<int>(n),
+        *d_size = b.alloc<int>(n), *d_root = b.alloc<int>(n), *d_out = b.alloc<int>(n), *d_changed = b.alloc<int>(1);
+    if (!d_src || !d_dst || !d_parent || !d_rank || !d_size || !d_root || !d_out || !d_changed) {
+        aset_err("mn_graph_components: out of device memory");
+        return -1;
+    }
+    if (n_edges) {
+        ACHK(hipMemcpy(d_src, src, (size_t)n_edges * sizeof(int), hipMemcpyHostToDevice));
+        ACHK(hipMemcpy(d_dst, dst, (size_t)n_edges * sizeof(int), hipMemcpyHostToDevice));
+    }
+    hipEvent_t e0, e1;
+    ACHK(hipEventCreate(&e0));
+    ACHK(hipEventCreate(&e1));
+    const int nb = (n + 255) / 256;
+    ACHK(hipEventRecord(e0, nullptr));
+    hipLaunchKernelGGL(k_uf_init, dim3(nb), dim3(256), 0, nullptr, d_parent, d_rank, d_size, n);
+    int rounds = 0;
+    if (mode == MN_COMPONENTS_EXACT) {
+        hipLaunchKernelGGL(k_uf_seq, dim3(1), dim3(64), 0, nullptr, d_src, d_dst, (long long)n_edges, d_parent, d_rank);
+        rounds = 1;
+    } else if (n_edges) {
+        for (int changed = 1; changed && rounds < 64; rounds++) { // (one round settles everything; the loop is the safety net)
+            changed = 0;
+            ACHK(hipMemsetAsync(d_changed, 0, sizeof(int), nullptr));
+            hipLaunchKernelGGL(k_cc_hook, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, nullptr, d_src, d_dst, (long long)n_edges,
+                               d_parent, d_changed);
+            ACHK(hipMemcpy(&changed, d_changed, sizeof(int), hipMemcpyDeviceToHost));
+        }
+    }
+    hipLaunchKernelGGL(k_cc_root, dim3(nb), dim3(256), 0, nullptr, d_parent, n, d_root, d_size); // :1347-1356
+    hipLaunchKernelGGL(k_cc_out, dim3(nb), dim3(256), 0, nullptr, d_root, d_size, n, d_out);
+    ACHK(hipEventRecord(e1, nullptr));
+    ACHK(hipGetLastError());
+    ACHK(hipMemcpy(component_id, d_root, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    ACHK(hipMemcpy(component_size, d_out, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (stats) {
+        stats->device_ms = ms;
+        stats->iterations = rounds;
+    }
+    return 0;
+}

@@ -29,6 +29,12 @@ class N2vStats(C.Structure):
 
 
 N2V_SEQUENTIAL, N2V_BATCHED = 0, 1
+COMPONENTS_EXACT, COMPONENTS_FAST = 0, 1
+
+
+class AlgoStats(C.Structure):
+    _fields_ = [("device_ms", C.c_double), ("iterations", C.c_int), ("aux", C.c_int64)]
+
 
 GRAPH_SYMBOLS = [
     ("mn_node2vec_train", C.c_int, [C.c_int, _i32p, _i32p, C.POINTER(N2vParams), C.c_int, C.c_int,
@@ -52,6 +58,10 @@ GRAPH_SYMBOLS = [
     ("mn_graph_last_error", C.c_char_p, []),
     ("mn_graph_leiden", C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, _i32p, C.POINTER(C.c_double)]),
     ("mn_graph_leiden_stats", C.c_int, [C.c_void_p, C.POINTER(LeidenStats)]),
+    ("mn_graph_pagerank", C.c_int, [C.c_int, C.c_int64, _i32p, _i32p, C.c_double, C.c_int, C.c_int,
+                                    np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"), C.POINTER(AlgoStats)]),
+    ("mn_graph_components", C.c_int, [C.c_int, C.c_int64, _i32p, _i32p, C.c_int, C.c_int, _i32p, _i32p, C.POINTER(AlgoStats)]),
+    ("mn_graph_algo_last_error", C.c_char_p, []),
 ]
 
 
@@ -193,3 +203,33 @@ def n2v_csr_from_edges(n, src, dst):
     off = np.zeros(n + 1, np.int64)
     np.add.at(off, a + 1, 1)
     return np.cumsum(off).astype(np.int32), b[o].astype(np.int32)
+
+
+# ───────────── f-4: graph_tvf.c's edge-list algorithms (nodes = first-seen indices, edges in row order) ─────────────
+
+def _edges(src, dst):
+    src, dst = np.ascontiguousarray(src, np.int32), np.ascontiguousarray(dst, np.int32)
+    pad = np.zeros(1, np.int32)
+    return (src if len(src) else pad), (dst if len(dst) else pad), len(src)
+
+
+def pagerank(n, src, dst, damping=0.85, iterations=20, device=0):
+    """run_pagerank (src/graph_tvf.c:1631-1797) → (rank[n] float64, stats)"""
+    L = _glib()
+    s, d, ne = _edges(src, dst)
+    out = np.zeros(max(n, 1), np.float64)
+    st = AlgoStats()
+    if L.mn_graph_pagerank(n, ne, s, d, float(damping), int(iterations), device, out, C.byref(st)) != 0:
+        raise MuninnHipError((L.mn_graph_algo_last_error() or b"").decode())
+    return out[:n], {"device_ms": st.device_ms, "iterations": st.iterations, "dangling": st.aux}
+
+
+def components(n, src, dst, mode=COMPONENTS_EXACT, device=0):
+    """run_components (src/graph_tvf.c:1314-1366) → (component_id[n], component_size[n], stats)"""
+    L = _glib()
+    s, d, ne = _edges(src, dst)
+    cid, csz = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+    st = AlgoStats()
+    if L.mn_graph_components(n, ne, s, d, mode, device, cid, csz, C.byref(st)) != 0:
+        raise MuninnHipError((L.mn_graph_algo_last_error() or b"").decode())
+    return cid[:n], csz[:n], {"device_ms": st.device_ms, "rounds": st.iterations}

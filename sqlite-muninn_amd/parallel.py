@@ -51,7 +51,8 @@ class Comm:
                     src = torch.frombuffer((C.c_ubyte * nbytes).from_address(send), dtype=torch.uint8).clone()
                     out = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
                     dist.all_gather(out, src, group=group)
-                    C.memmove(recv, torch.cat(out).numpy().ctypes.data, nbytes * self.world)
+                    joined = torch.cat(out)  # (named: it must outlive the copy)
+                    C.memmove(recv, joined.data_ptr(), nbytes * self.world)
                     return 0
                 except Exception:  # never let an exception cross the C boundary
                     return -1

@@ -37,3 +37,19 @@ def gpu(mn):
     mn.lib()
     assert mn.device_count() >= 1, "no gfx950 device visible: GPU tests cannot run"
     return mn
+
+
+@pytest.fixture
+def ext_conn(mn):
+    """A connection with the SQLite extension (sqlite-muninn_amd/ext/muninn.so) loaded, as the reference is loaded."""
+    import sqlite3
+    import subprocess
+
+    ext_dir = os.path.join(ROOT, "sqlite-muninn_amd", "ext")
+    mn.build()
+    subprocess.run(["make", "-s", "-C", ext_dir], check=True)
+    c = sqlite3.connect(":memory:")
+    c.enable_load_extension(True)
+    c.load_extension(os.path.join(ext_dir, "muninn"))
+    yield c
+    c.close()

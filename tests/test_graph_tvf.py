@@ -1,0 +1,132 @@
+"""graph_pagerank / graph_components (src/graph_tvf.c): the oracle against what the reference's own SQL
+functions returned (CPU), the HIP kernels against the oracle and those goldens (GPU, rank bits / root ids exact), and
+the two table-valued functions of the extension against the same goldens through SQL."""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import orc_graph as og
+from oracle.graph_cases import tvf_cases
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = tvf_cases()
+
+
+def golden():
+    with gzip.open(os.path.join(G, "graph_tvf.json.gz"), "rt") as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_matches_reference_golden(name):
+    rows, damping, iterations = CASES[name]
+    z = golden()[name]
+    ids, s, d = og.first_seen_edges(rows)
+    assert ids == z["nodes"] == z["comp_nodes"]  # first-seen order: src of a row before its dst, NULL rows skipped
+    pr = og.pagerank(len(ids), s, d, 0.85 if damping is None else damping, 20 if iterations is None else iterations)
+    assert pr.view(np.int64).tolist() == z["rank_bits"]
+    cid, csz = og.components(len(ids), s, d)
+    assert cid.tolist() == z["comp_id"] and csz.tolist() == z["comp_size"]
+
+
+def test_oracle_vs_live_reference_random():
+    """Beyond the committed cases, where the compiled reference is available (build container)."""
+    if not og.have_ref_graph():
+        pytest.skip("oracle/_ref not built (reference sources absent)")
+    rng = np.random.default_rng(5)
+    for trial in range(4):
+        n = int(rng.integers(5, 300))
+        rows = [(f"k{a}", f"k{b}") for a, b in rng.integers(0, n, (int(rng.integers(1, 4 * n)), 2))]
+        damping, iters = float(rng.choice([0.5, 0.85, 0.99])), int(rng.integers(0, 25))
+        ref = og.ref_graph_tvf(rows, damping, iters)
+        ids, s, d = og.first_seen_edges(rows)
+        pr = og.pagerank(len(ids), s, d, damping, iters)
+        assert [r[0] for r in ref["pagerank"]] == ids
+        assert np.array([r[1] for r in ref["pagerank"]], np.float64).view(np.int64).tolist() == pr.view(np.int64).tolist()
+        cid, csz = og.components(len(ids), s, d)
+        assert [r[1] for r in ref["components"]] == cid.tolist() and [r[2] for r in ref["components"]] == csz.tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_device_matches_reference_golden(gpu, name):
+    rows, damping, iterations = CASES[name]
+    z = golden()[name]
+    ids, s, d = og.first_seen_edges(rows)
+    pr, st = gpu.graph.pagerank(len(ids), s, d, 0.85 if damping is None else damping, 20 if iterations is None else iterations)
+    assert pr.view(np.int64).tolist() == z["rank_bits"], name  # the same f64 additions in the same order
+    cid, csz, _ = gpu.graph.components(len(ids), s, d, gpu.graph.COMPONENTS_EXACT)
+    assert cid.tolist() == z["comp_id"] and csz.tolist() == z["comp_size"]  # the reference's union-find roots
+    fid, fsz, _ = gpu.graph.components(len(ids), s, d, gpu.graph.COMPONENTS_FAST)
+    assert fsz.tolist() == z["comp_size"]
+    # same partition; the parallel mode names a component by its smallest node index
+    groups = {}
+    for i, c in enumerate(z["comp_id"]):
+        groups.setdefault(c, []).append(i)
+    for members in groups.values():
+        assert {int(fid[i]) for i in members} == {min(members)}
+
+
+@pytest.mark.gpu
+def test_device_vs_oracle_larger(gpu):
+    """50k nodes / 400k edge rows with ~10 % dangling nodes, multi-edges and self loops: rank bits, roots and sizes."""
+    rng = np.random.default_rng(9)
+    n, m = 50_000, 400_000
+    s = rng.integers(0, int(n * 0.9), m).astype(np.int32)  # the last 10 % of the ids never appear as a source
+    d = rng.integers(0, n, m).astype(np.int32)
+    remap = -np.ones(n, np.int64)  # first-seen renumbering, as the SQL ingest does
+    order = np.stack([s, d], 1).reshape(-1)
+    _, first = np.unique(order, return_index=True)
+    seen = order[np.sort(first)]
+    remap[seen] = np.arange(len(seen))
+    s2, d2 = remap[s].astype(np.int32), remap[d].astype(np.int32)
+    nn = len(seen)
+    want = og.pagerank(nn, s2, d2, 0.85, 10)
+    got, st = gpu.graph.pagerank(nn, s2, d2, 0.85, 10)
+    assert st["dangling"] > 1000
+    assert np.array_equal(got.view(np.int64), want.view(np.int64))
+    assert abs(float(got.sum()) - 1.0) < 1e-9  # rank is conserved (dangling mass is redistributed)
+    wc, ws = og.components(nn, s2[:60_000], d2[:60_000])
+    gc, gs, _ = gpu.graph.components(nn, s2[:60_000], d2[:60_000], gpu.graph.COMPONENTS_EXACT)
+    assert np.array_equal(gc, wc) and np.array_equal(gs, ws)
+    fc, fs, _ = gpu.graph.components(nn, s2, d2, gpu.graph.COMPONENTS_FAST)
+    wc2, ws2 = og.components(nn, s2, d2)
+    assert np.array_equal(fs, ws2)
+    assert len(set(zip(fc.tolist(), wc2.tolist()))) == len(set(fc.tolist())) == len(set(wc2.tolist()))  # a bijection of ids
+
+
+@pytest.mark.gpu
+def test_sql_table_valued_functions_equal_the_reference(gpu, ext_conn):
+    c = ext_conn
+    z = golden()
+    for name, (rows, damping, iterations) in sorted(CASES.items()):
+        c.execute("DROP TABLE IF EXISTS e")
+        c.execute("CREATE TABLE e(s TEXT, d TEXT)")
+        c.executemany("INSERT INTO e VALUES (?, ?)", rows)
+        extra, args = "", []
+        if damping is not None:
+            extra += " AND damping = ?"
+            args.append(damping)
+        if iterations is not None:
+            extra += " AND iterations = ?"
+            args.append(iterations)
+        pr = c.execute("SELECT node, rank FROM graph_pagerank WHERE edge_table='e' AND src_col='s' AND dst_col='d'" + extra, args).fetchall()
+        assert [r[0] for r in pr] == z[name]["nodes"]
+        assert np.array([r[1] for r in pr], np.float64).view(np.int64).tolist() == z[name]["rank_bits"], name
+        cc = c.execute("SELECT node, component_id, component_size FROM graph_components WHERE edge_table='e' AND src_col='s' AND dst_col='d'").fetchall()
+        assert [r[0] for r in cc] == z[name]["comp_nodes"] and [r[1] for r in cc] == z[name]["comp_id"]
+        assert [r[2] for r in cc] == z[name]["comp_size"]
+    # the reference's error behaviour (src/graph_tvf.c:1453-1456, :1814-1817 and its un-compacted argvIndex)
+    import sqlite3
+
+    with pytest.raises(sqlite3.OperationalError, match="graph_pagerank: invalid table/column identifier"):
+        c.execute("SELECT * FROM graph_pagerank WHERE edge_table='e;x' AND src_col='s' AND dst_col='d'").fetchall()
+    with pytest.raises(sqlite3.OperationalError, match="graph_components: invalid table/column identifier"):
+        c.execute("SELECT * FROM graph_components WHERE edge_table='e' AND src_col='s s' AND dst_col='d'").fetchall()
+    with pytest.raises(sqlite3.OperationalError, match="xBestIndex malfunction"):
+        c.execute("SELECT * FROM graph_pagerank WHERE edge_table='e' AND src_col='s' AND dst_col='d' AND iterations = 3").fetchall()
+    c.execute("CREATE TABLE empty_e(s TEXT, d TEXT)")
+    assert c.execute("SELECT * FROM graph_pagerank WHERE edge_table='empty_e' AND src_col='s' AND dst_col='d'").fetchall() == []

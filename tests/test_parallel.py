@@ -224,7 +224,7 @@ def test_bench_entry_starts_its_own_ranks(gpu, mode):
     assert len(lines) == 1  # rank 0 prints the one line
     j = lines[0]
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["value"] > 0 and j["roofline"]["frac"] > 0
-    assert ("sharded" in j["config"]["parallelism"]) == (mode == "sharded")
+    assert j["config"]["parallelism"].startswith("sharded index") == (mode == "sharded")
 
 
 @pytest.mark.gpu
