@@ -305,6 +305,22 @@ int mn_graph_components(int n_nodes, int64_t n_edges, const int *src, const int 
                         int *component_size, mn_graph_algo_stats *stats);
 const char *mn_graph_algo_last_error(void);
 
+/* csr_apply_delta (src/graph_csr.c:175-325), the merge step of graph_adjacency's incremental rebuild
+ * (src/graph_adjacency.c:721-1005): old CSR + delta log -> new CSR; per node the log is replayed in order (INSERT appends,
+ * DELETE removes the first occurrence by moving the last element into its place), so lists come out in the reference's
+ * order.  Host arrays in; new_offsets[max(new_node_count, old_node_count) + 1] is the caller's, *new_targets /
+ * *new_weights are malloc'ed here (NULL when the result has no edges; release with mn_host_free).  mn_csr_delta has the
+ * layout of CsrDelta (src/graph_csr.h:37-42).  0 / -1. */
+typedef struct {
+    int32_t src_idx, dst_idx;
+    double weight;
+    int op; /* 1 = INSERT, 2 = DELETE */
+} mn_csr_delta;
+int mn_csr_apply_delta(int old_node_count, const int *old_offsets, const int *old_targets, const double *old_weights,
+                       int has_weights, const mn_csr_delta *deltas, int delta_count, int new_node_count, int device,
+                       int *new_offsets, int **new_targets, double **new_weights, int *new_edge_count);
+void mn_host_free(void *p);
+
 /* ---- multi-GPU: one rank per GPU of a node, processes or threads; RCCL over xGMI ----
  * The reference is single-device; these entry points are what its host (hnsw_vtab.c / node2vec.c) would call to use the
  * node's other GPUs.  The only collective is an all-gather of equal-sized device buffers:

@@ -876,3 +876,73 @@ int orc_components(int n, int n_edges, const int *src, const int *dst, int *comp
     free(parent); free(rank); free(size);
     return 0;
 }
+
+
+/* ───────────────────────── f-2: csr_apply_delta (src/graph_csr.c:175-325) ───────────────────────── */
+
+int orc_csr_apply_delta(int old_n, const int *off, const int *tgt, const double *w, int has_weights, int nd, const int *dsrc,
+                        const int *ddst, const double *dw, const int *dop, int new_n, int *new_off, int *new_tgt, double *new_w) {
+    if (new_n < old_n)
+        new_n = old_n; /* :179-180 */
+    /* every node's list with room for all its inserts */
+    int *cap = (int *)calloc((size_t)new_n + 1, sizeof(int)), *cnt = (int *)calloc((size_t)new_n + 1, sizeof(int));
+    int *start = (int *)calloc((size_t)new_n + 1, sizeof(int));
+    if (!cap || !cnt || !start)
+        return -1;
+    for (int i = 0; i < old_n; i++)
+        cap[i] = off[i + 1] - off[i];
+    for (int d = 0; d < nd; d++)
+        if (dsrc[d] >= 0 && dsrc[d] < new_n && dop[d] == 1)
+            cap[dsrc[d]]++;
+    int total = 0;
+    for (int i = 0; i < new_n; i++) {
+        start[i] = total;
+        total += cap[i];
+    }
+    int *lt = (int *)malloc((size_t)(total ? total : 1) * sizeof(int));
+    double *lw = (double *)malloc((size_t)(total ? total : 1) * sizeof(double));
+    if (!lt || !lw)
+        return -1;
+    for (int i = 0; i < old_n; i++) { /* step 1 */
+        cnt[i] = off[i + 1] - off[i];
+        for (int j = 0; j < cnt[i]; j++) {
+            lt[start[i] + j] = tgt[off[i] + j];
+            lw[start[i] + j] = (has_weights && w) ? w[off[i] + j] : 0.0;
+        }
+    }
+    for (int d = 0; d < nd; d++) { /* step 2, log order */
+        int s = dsrc[d], t = ddst[d];
+        if (s < 0 || s >= new_n || t < 0 || t >= new_n)
+            continue;
+        int *row = lt + start[s];
+        double *wr = lw + start[s];
+        if (dop[d] == 2) {
+            for (int j = 0; j < cnt[s]; j++)
+                if (row[j] == t) {
+                    cnt[s]--;
+                    if (j < cnt[s]) {
+                        row[j] = row[cnt[s]];
+                        wr[j] = wr[cnt[s]];
+                    }
+                    break;
+                }
+        } else if (dop[d] == 1) {
+            row[cnt[s]] = t;
+            wr[cnt[s]] = dw ? dw[d] : 0.0;
+            cnt[s]++;
+        }
+    }
+    int o = 0; /* step 3 */
+    for (int i = 0; i < new_n; i++) {
+        new_off[i] = o;
+        for (int j = 0; j < cnt[i]; j++) {
+            new_tgt[o + j] = lt[start[i] + j];
+            if (has_weights && new_w)
+                new_w[o + j] = lw[start[i] + j];
+        }
+        o += cnt[i];
+    }
+    new_off[new_n] = o;
+    free(cap); free(cnt); free(start); free(lt); free(lw);
+    return o;
+}

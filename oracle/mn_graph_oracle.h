@@ -56,6 +56,11 @@ int orc_biased_walk(const orc_n2v_graph *g, int start, double p, double q, int w
  * returns n; off must hold n_max+1 ints, adj 2*n_edges ints, index_of_id n_ids ints (or NULL). */
 int orc_n2v_build_graph(int n_edges, const int *src, const int *dst, int n_ids, int *off, int *adj, int *index_of_id);
 
+/* csr_apply_delta (src/graph_csr.c:175-325): per-node replay of the delta log.  delta arrays are parallel
+ * (src, dst, weight, op: 1 INSERT, 2 DELETE).  new_off must hold max(new_n, old_n) + 1 ints, new_tgt / new_w room for
+ * old edges + delta count.  Returns the new edge count, -1 on error. */
+int orc_csr_apply_delta(int old_n, const int *off, const int *tgt, const double *w, int has_weights, int nd, const int *dsrc,
+                        const int *ddst, const double *dw, const int *dop, int new_n, int *new_off, int *new_tgt, double *new_w);
 /* run_pagerank's power iteration (src/graph_tvf.c:1676-1716) over first-seen node indices; edges src[e] -> dst[e] in
  * edge-table row order (duplicates and self loops kept).  rank_out[n]. */
 int orc_pagerank(int n, int n_edges, const int *src, const int *dst, double damping, int iterations, double *rank_out);

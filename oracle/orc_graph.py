@@ -279,3 +279,57 @@ def ref_graph_tvf(rows, damping=None, iterations=None):
     cc = c.execute("SELECT node, component_id, component_size FROM graph_components WHERE edge_table='e' AND src_col='s' AND dst_col='d'").fetchall()
     c.close()
     return {"pagerank": pr, "components": cc}
+
+
+# ───────────────────────── f-2: csr_apply_delta ─────────────────────────
+
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+
+
+def _delta_call(fn, off, tgt, w, dsrc, ddst, dw, dop, new_n):
+    off = np.ascontiguousarray(off, np.int32)
+    old_n = len(off) - 1
+    tgt = np.ascontiguousarray(tgt if len(tgt) else np.zeros(1, np.int32), np.int32)
+    has_w = w is not None
+    wv = np.ascontiguousarray(w if has_w and len(w) else np.zeros(1), np.float64)
+    nd = len(dsrc)
+    pad = lambda a, t: np.ascontiguousarray(a if len(a) else np.zeros(1, t), t)  # noqa: E731
+    n_out = max(new_n, old_n)
+    new_off = np.zeros(n_out + 1, np.int32)
+    cap = int(off[-1]) + nd + 1
+    new_tgt, new_w = np.zeros(cap, np.int32), np.zeros(cap, np.float64)
+    fn.argtypes = [C.c_int, _i32p, _i32p, _f64p, C.c_int, C.c_int, _i32p, _i32p, _f64p, _i32p, C.c_int, _i32p, _i32p, _f64p]
+    e = fn(old_n, off, tgt, wv, 1 if has_w else 0, nd, pad(dsrc, np.int32), pad(ddst, np.int32), pad(dw, np.float64),
+           pad(dop, np.int32), new_n, new_off, new_tgt, new_w)
+    assert e >= 0
+    return new_off, new_tgt[:e].copy(), (new_w[:e].copy() if has_w else None)
+
+
+def csr_apply_delta(off, tgt, w, dsrc, ddst, dw, dop, new_n):
+    return _delta_call(_lib().orc_csr_apply_delta, off, tgt, w, dsrc, ddst, dw, dop, new_n)
+
+
+def ref_csr_apply_delta(off, tgt, w, dsrc, ddst, dw, dop, new_n):
+    """the reference's own csr_apply_delta (oracle/_ref/muninn.so, build container only)"""
+    return _delta_call(C.CDLL(REF_EXT_SO).ref_csr_apply_delta, off, tgt, w, dsrc, ddst, dw, dop, new_n)
+
+
+def delta_case(seed, n=300, e=2000, nd=900, weighted=False, new_nodes=40):
+    """A random CSR (multi-edges included) and a delta log: inserts, deletes of present / absent / repeated edges,
+    edges to and from nodes beyond the old node count, out-of-range rows."""
+    r = np.random.default_rng(seed)
+    src = np.sort(r.integers(0, n, e)).astype(np.int32)
+    tgt = r.integers(0, n, e).astype(np.int32)
+    off = np.zeros(n + 1, np.int32)
+    np.add.at(off, src + 1, 1)
+    off = np.cumsum(off).astype(np.int32)
+    w = r.random(e) if weighted else None
+    new_n = n + new_nodes
+    dsrc = r.integers(-2, new_n + 2, nd).astype(np.int32)
+    ddst = r.integers(-2, new_n + 2, nd).astype(np.int32)
+    dop = r.choice([1, 2, 2, 3], nd).astype(np.int32)
+    pick = r.integers(0, e, nd // 2)  # make half of the deletes hit existing edges
+    dsrc[: nd // 2][dop[: nd // 2] == 2] = src[pick][dop[: nd // 2] == 2]
+    ddst[: nd // 2][dop[: nd // 2] == 2] = tgt[pick][dop[: nd // 2] == 2]
+    dw = r.random(nd)
+    return off, tgt, w, dsrc, ddst, dw, dop, new_n

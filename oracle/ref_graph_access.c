@@ -41,3 +41,41 @@ double ref_leiden_edges(int n_ids, int n_edges, const int *src, const int *dst, 
     graph_data_destroy(&g);
     return Q;
 }
+
+
+/* the reference's own csr_apply_delta (src/graph_csr.c:175) on caller-supplied arrays; returns the new edge count */
+#include <stdlib.h>
+#include <string.h>
+#include "graph_csr.h"
+int ref_csr_apply_delta(int old_n, const int *off, const int *tgt, const double *w, int has_weights, int nd, const int *dsrc,
+                        const int *ddst, const double *dw, const int *dop, int new_n, int *new_off, int *new_tgt, double *new_w) {
+    CsrArray old, nw;
+    memset(&old, 0, sizeof(old));
+    old.node_count = old_n;
+    old.edge_count = old_n ? off[old_n] : 0;
+    old.offsets = (int32_t *)off;
+    old.targets = (int32_t *)tgt;
+    old.weights = (double *)w;
+    old.has_weights = has_weights;
+    CsrDelta *dl = (CsrDelta *)calloc((size_t)(nd ? nd : 1), sizeof(CsrDelta));
+    for (int d = 0; d < nd; d++) {
+        dl[d].src_idx = dsrc[d];
+        dl[d].dst_idx = ddst[d];
+        dl[d].weight = dw ? dw[d] : 0.0;
+        dl[d].op = dop[d];
+    }
+    if (csr_apply_delta(&old, dl, nd, new_n, &nw) != 0) {
+        free(dl);
+        return -1;
+    }
+    free(dl);
+    memcpy(new_off, nw.offsets, ((size_t)nw.node_count + 1) * sizeof(int));
+    if (nw.edge_count) {
+        memcpy(new_tgt, nw.targets, (size_t)nw.edge_count * sizeof(int));
+        if (has_weights && nw.weights && new_w)
+            memcpy(new_w, nw.weights, (size_t)nw.edge_count * sizeof(double));
+    }
+    int e = nw.edge_count;
+    csr_destroy(&nw);
+    return e;
+}

@@ -17,6 +17,8 @@
 // nothing changes and compresses: the same partition and sizes, component_id = smallest node index of the component.
 #include "../../include/muninn_hip.h"
 #include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
 #include <cstdarg>
@@ -351,3 +353,228 @@ extern "C" int mn_graph_components(int n, int64_t n_edges, const int *src, const
     }
     return 0;
 }
+
+// ───────────────────────── csr_apply_delta (src/graph_csr.c:175-325) ─────────────────────────
+// The reference turns the CSR into per-node lists, replays the delta log in order (INSERT appends, DELETE removes the
+// first occurrence by swapping the last element in) and rebuilds the CSR.  A node's final list depends only on ITS
+// deltas in log order, so the replay is parallel over nodes: the log is grouped by source with a STABLE radix sort
+// (log order kept inside a node), every node copies its old list into a scratch row sized old degree + its deltas,
+// replays them, and an exclusive scan of the final lengths gives the new offsets.
+__global__ void k_delta_keys(const mn_csr_delta *dl, int nd, int n_new, unsigned *keys, int *vals) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nd)
+        return;
+    const int s = dl[i].src_idx, d = dl[i].dst_idx;
+    const bool ok = s >= 0 && s < n_new && d >= 0 && d < n_new; // :221-222: others are skipped
+    keys[i] = ok ? (unsigned)s : 0xffffffffu;
+    vals[i] = i;
+}
+
+__global__ void k_delta_ranges(const unsigned *keys, int nd, const int *old_off, int n_old, int n_new, int *dstart, int *cap) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_new)
+        return;
+    int lo = 0, hi = nd; // first sorted delta with key >= v
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (keys[mid] < (unsigned)v)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    int e = lo;
+    while (e < nd && keys[e] == (unsigned)v)
+        e++;
+    dstart[v] = lo;
+    const int deg = v < n_old ? old_off[v + 1] - old_off[v] : 0;
+    cap[v] = deg + (e - lo);
+}
+
+__global__ void k_delta_apply(const mn_csr_delta *dl, const unsigned *keys, const int *order, int nd, const int *old_off,
+                              const int *old_tgt, const double *old_w, int n_old, int n_new, const int *dstart, const int *tmp_off,
+                              int *tmp_tgt, double *tmp_w, int *cnt) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_new)
+        return;
+    int *row = tmp_tgt + tmp_off[v];
+    double *wrow = tmp_w ? tmp_w + tmp_off[v] : nullptr;
+    int n = 0;
+    if (v < n_old) {
+        const int o = old_off[v];
+        n = old_off[v + 1] - o;
+        for (int j = 0; j < n; j++) {
+            row[j] = old_tgt[o + j];
+            if (wrow)
+                wrow[j] = old_w ? old_w[o + j] : 0.0;
+        }
+    }
+    for (int x = dstart[v]; x < nd && keys[x] == (unsigned)v; x++) { // this node's deltas in log order
+        const mn_csr_delta d = dl[order[x]];
+        if (d.op == 2) { // DELETE: first occurrence, swap with the last (:225-238)
+            for (int j = 0; j < n; j++)
+                if (row[j] == d.dst_idx) {
+                    n--;
+                    if (j < n) {
+                        row[j] = row[n];
+                        if (wrow)
+                            wrow[j] = wrow[n];
+                    }
+                    break;
+                }
+        } else if (d.op == 1) { // INSERT: append (:239-261)
+            row[n] = d.dst_idx;
+            if (wrow)
+                wrow[n] = d.weight;
+            n++;
+        }
+    }
+    cnt[v] = n;
+}
+
+__global__ void k_delta_compact(const int *tmp_off, const int *tmp_tgt, const double *tmp_w, const int *new_off, const int *cnt,
+                                int n_new, int *out_tgt, double *out_w) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_new)
+        return;
+    const int a = tmp_off[v], b = new_off[v], n = cnt[v];
+    for (int j = 0; j < n; j++) {
+        out_tgt[b + j] = tmp_tgt[a + j];
+        if (out_w)
+            out_w[b + j] = tmp_w[a + j];
+    }
+}
+
+extern "C" int mn_csr_apply_delta(int old_node_count, const int *old_offsets, const int *old_targets, const double *old_weights,
+                                  int has_weights, const mn_csr_delta *deltas, int delta_count, int new_node_count, int device,
+                                  int *new_offsets, int **new_targets, double **new_weights, int *new_edge_count) {
+    if (old_node_count < 0 || delta_count < 0 || !old_offsets || !new_offsets || !new_targets || !new_edge_count) {
+        aset_err("mn_csr_apply_delta: bad arguments");
+        return -1;
+    }
+    if (new_node_count < old_node_count) // :179-180
+        new_node_count = old_node_count;
+    *new_targets = nullptr;
+    if (new_weights)
+        *new_weights = nullptr;
+    *new_edge_count = 0;
+    const int n_old = old_node_count, n_new = new_node_count, nd = delta_count;
+    if (n_new == 0) {
+        new_offsets[0] = 0;
+        return 0;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        aset_err("mn_csr_apply_delta: HIP device %d not available (no CPU fallback)", device);
+        return -1;
+    }
+    ACHK(hipSetDevice(device));
+    const int E = n_old ? old_offsets[n_old] : 0;
+    Bufs b;
+    int *d_off = b.alloc<int>((size_t)n_old + 1), *d_tgt = b.alloc<int>(E), *d_vals = b.alloc<int>(nd), *d_vals_s = b.alloc<int>(nd),
+        *d_dstart = b.alloc<int>(n_new), *d_cap = b.alloc<int>(n_new), *d_tmpoff = b.alloc<int>((size_t)n_new + 1), *d_cnt = b.alloc<int>(n_new),
+        *d_newoff = b.alloc<int>((size_t)n_new + 1);
+    unsigned *d_keys = b.alloc<unsigned>(nd), *d_keys_s = b.alloc<unsigned>(nd);
+    double *d_w = has_weights ? b.alloc<double>(E) : nullptr;
+    mn_csr_delta *d_dl = b.alloc<mn_csr_delta>(nd);
+    if (!d_off || !d_tgt || !d_vals || !d_vals_s || !d_dstart || !d_cap || !d_tmpoff || !d_cnt || !d_newoff || !d_keys || !d_keys_s ||
+        !d_dl || (has_weights && !d_w)) {
+        aset_err("mn_csr_apply_delta: out of device memory");
+        return -1;
+    }
+    ACHK(hipMemcpy(d_off, old_offsets, ((size_t)n_old + 1) * sizeof(int), hipMemcpyHostToDevice));
+    if (n_old == 0)
+        ACHK(hipMemset(d_off, 0, sizeof(int)));
+    if (E)
+        ACHK(hipMemcpy(d_tgt, old_targets, (size_t)E * sizeof(int), hipMemcpyHostToDevice));
+    if (has_weights && E && old_weights)
+        ACHK(hipMemcpy(d_w, old_weights, (size_t)E * sizeof(double), hipMemcpyHostToDevice));
+    if (nd)
+        ACHK(hipMemcpy(d_dl, deltas, (size_t)nd * sizeof(mn_csr_delta), hipMemcpyHostToDevice));
+    const int nbd = (nd + 255) / 256, nbn = (n_new + 255) / 256;
+    const unsigned *keys_sorted = d_keys;
+    const int *order = d_vals;
+    void *tmp = nullptr;
+    if (nd) {
+        hipLaunchKernelGGL(k_delta_keys, dim3(nbd), dim3(256), 0, nullptr, d_dl, nd, n_new, d_keys, d_vals);
+        size_t bytes = 0;
+        if (rocprim::radix_sort_pairs(nullptr, bytes, d_keys, d_keys_s, d_vals, d_vals_s, (size_t)nd, 0, 32, nullptr) != hipSuccess) {
+            aset_err("rocprim::radix_sort_pairs (size query) failed");
+            return -1;
+        }
+        ACHK(hipMalloc(&tmp, bytes ? bytes : 16));
+        b.p.push_back(tmp);
+        if (rocprim::radix_sort_pairs(tmp, bytes, d_keys, d_keys_s, d_vals, d_vals_s, (size_t)nd, 0, 32, nullptr) != hipSuccess) { // stable
+            aset_err("rocprim::radix_sort_pairs failed");
+            return -1;
+        }
+        keys_sorted = d_keys_s;
+        order = d_vals_s;
+    }
+    hipLaunchKernelGGL(k_delta_ranges, dim3(nbn), dim3(256), 0, nullptr, keys_sorted, nd, d_off, n_old, n_new, d_dstart, d_cap);
+    auto scan = [&](int *in, int *out, int n) -> int { // exclusive scan; out[n] = total
+        size_t bytes = 0;
+        void *t2 = nullptr;
+        if (rocprim::exclusive_scan(nullptr, bytes, in, out, 0, (size_t)n, rocprim::plus<int>(), nullptr) != hipSuccess)
+            return -1;
+        if (hipMalloc(&t2, bytes ? bytes : 16) != hipSuccess)
+            return -1;
+        b.p.push_back(t2);
+        if (rocprim::exclusive_scan(t2, bytes, in, out, 0, (size_t)n, rocprim::plus<int>(), nullptr) != hipSuccess)
+            return -1;
+        int last_in = 0, last_out = 0;
+        if (hipMemcpy(&last_in, in + n - 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(&last_out, out + n - 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+            return -1;
+        const int total = last_in + last_out;
+        if (hipMemcpy(out + n, &total, sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+            return -1;
+        return total;
+    };
+    const int tmp_total = scan(d_cap, d_tmpoff, n_new);
+    if (tmp_total < 0) {
+        aset_err("mn_csr_apply_delta: scan failed");
+        return -1;
+    }
+    int *d_tmpt = b.alloc<int>(tmp_total);
+    double *d_tmpw = has_weights ? b.alloc<double>(tmp_total) : nullptr;
+    if (!d_tmpt || (has_weights && !d_tmpw)) {
+        aset_err("mn_csr_apply_delta: out of device memory");
+        return -1;
+    }
+    hipLaunchKernelGGL(k_delta_apply, dim3(nbn), dim3(256), 0, nullptr, d_dl, keys_sorted, order, nd, d_off, d_tgt, d_w, n_old, n_new,
+                       d_dstart, d_tmpoff, d_tmpt, d_tmpw, d_cnt);
+    const int total = scan(d_cnt, d_newoff, n_new);
+    if (total < 0) {
+        aset_err("mn_csr_apply_delta: scan failed");
+        return -1;
+    }
+    int *d_outt = b.alloc<int>(total);
+    double *d_outw = has_weights ? b.alloc<double>(total) : nullptr;
+    if (!d_outt || (has_weights && !d_outw)) {
+        aset_err("mn_csr_apply_delta: out of device memory");
+        return -1;
+    }
+    hipLaunchKernelGGL(k_delta_compact, dim3(nbn), dim3(256), 0, nullptr, d_tmpoff, d_tmpt, d_tmpw, d_newoff, d_cnt, n_new, d_outt, d_outw);
+    ACHK(hipGetLastError());
+    ACHK(hipMemcpy(new_offsets, d_newoff, ((size_t)n_new + 1) * sizeof(int), hipMemcpyDeviceToHost));
+    if (total) { // (the reference leaves targets / weights NULL for an empty graph, :282-291)
+        *new_targets = (int *)malloc((size_t)total * sizeof(int));
+        if (!*new_targets) {
+            aset_err("mn_csr_apply_delta: out of memory");
+            return -1;
+        }
+        ACHK(hipMemcpy(*new_targets, d_outt, (size_t)total * sizeof(int), hipMemcpyDeviceToHost));
+        if (has_weights && new_weights) {
+            *new_weights = (double *)malloc((size_t)total * sizeof(double));
+            if (!*new_weights) {
+                aset_err("mn_csr_apply_delta: out of memory");
+                return -1;
+            }
+            ACHK(hipMemcpy(*new_weights, d_outw, (size_t)total * sizeof(double), hipMemcpyDeviceToHost));
+        }
+    }
+    *new_edge_count = total;
+    return 0;
+}
+
+extern "C" void mn_host_free(void *p) { free(p); }

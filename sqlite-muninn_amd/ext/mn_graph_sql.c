@@ -637,10 +637,17 @@ static sqlite3_module leiden_module = {
     .xRowid = lei_rowid,
 };
 
+/* one registration per reference registration function, so that an integrated build can keep the reference's
+ * sqlite3_muninn_init (src/muninn.c:42-121) and point its calls here */
+int mn_register_node2vec(sqlite3 *db) { /* node2vec_register_functions, src/node2vec.c:594-597 */
+    return sqlite3_create_function(db, "node2vec_train", 13, SQLITE_UTF8 | SQLITE_DETERMINISTIC, 0, fn_node2vec_train, 0, 0);
+}
+int mn_register_leiden(sqlite3 *db) { /* community_register_tvfs, src/graph_community.c:668-670 */
+    return sqlite3_create_module(db, "graph_leiden", &leiden_module, 0);
+}
 int mn_register_graph_functions(sqlite3 *db) {
-    int rc = sqlite3_create_function(db, "node2vec_train", 13, SQLITE_UTF8 | SQLITE_DETERMINISTIC, 0, fn_node2vec_train, 0,
-                                     0); /* src/node2vec.c:594-597 */
+    int rc = mn_register_node2vec(db);
     if (rc == SQLITE_OK)
-        rc = sqlite3_create_module(db, "graph_leiden", &leiden_module, 0); /* src/graph_community.c:668-670 */
+        rc = mn_register_leiden(db);
     return rc;
 }

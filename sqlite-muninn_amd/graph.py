@@ -62,6 +62,9 @@ GRAPH_SYMBOLS = [
                                     np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"), C.POINTER(AlgoStats)]),
     ("mn_graph_components", C.c_int, [C.c_int, C.c_int64, _i32p, _i32p, C.c_int, C.c_int, _i32p, _i32p, C.POINTER(AlgoStats)]),
     ("mn_graph_algo_last_error", C.c_char_p, []),
+    ("mn_csr_apply_delta", C.c_int, [C.c_int, _i32p, _i32p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, _i32p,
+                                     C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
+    ("mn_host_free", None, [C.c_void_p]),
 ]
 
 
@@ -233,3 +236,34 @@ def components(n, src, dst, mode=COMPONENTS_EXACT, device=0):
     if L.mn_graph_components(n, ne, s, d, mode, device, cid, csz, C.byref(st)) != 0:
         raise MuninnHipError((L.mn_graph_algo_last_error() or b"").decode())
     return cid[:n], csz[:n], {"device_ms": st.device_ms, "rounds": st.iterations}
+
+
+class CsrDelta(C.Structure):  # CsrDelta, src/graph_csr.h:37-42
+    _fields_ = [("src_idx", C.c_int32), ("dst_idx", C.c_int32), ("weight", C.c_double), ("op", C.c_int)]
+
+
+def csr_apply_delta(off, tgt, w, dsrc, ddst, dw, dop, new_n, device=0):
+    """csr_apply_delta (src/graph_csr.c:175-325) on the device → (new_off, new_tgt, new_w or None)"""
+    L = _glib()
+    off = np.ascontiguousarray(off, np.int32)
+    old_n = len(off) - 1
+    tgt = np.ascontiguousarray(tgt if len(tgt) else np.zeros(1, np.int32), np.int32)
+    wv = None if w is None else np.ascontiguousarray(w if len(w) else np.zeros(1), np.float64)
+    nd = len(dsrc)
+    dl = (CsrDelta * max(nd, 1))()
+    for i in range(nd):
+        dl[i] = CsrDelta(int(dsrc[i]), int(ddst[i]), float(dw[i]), int(dop[i]))
+    new_off = np.zeros(max(new_n, old_n) + 1, np.int32)
+    pt, pw, ne = C.c_void_p(), C.c_void_p(), C.c_int(0)
+    rc = L.mn_csr_apply_delta(old_n, off, tgt, None if wv is None else wv.ctypes.data, 0 if wv is None else 1, dl, nd, new_n, device,
+                              new_off, C.byref(pt), C.byref(pw), C.byref(ne))
+    if rc != 0:
+        raise MuninnHipError((L.mn_graph_algo_last_error() or b"").decode())
+    e = ne.value
+    new_tgt = np.ctypeslib.as_array(C.cast(pt, C.POINTER(C.c_int32)), (e,)).copy() if e else np.zeros(0, np.int32)
+    new_w = None
+    if wv is not None:
+        new_w = np.ctypeslib.as_array(C.cast(pw, C.POINTER(C.c_double)), (e,)).copy() if e else np.zeros(0, np.float64)
+    L.mn_host_free(pt)
+    L.mn_host_free(pw)
+    return new_off, new_tgt, new_w

@@ -130,3 +130,45 @@ def test_sql_table_valued_functions_equal_the_reference(gpu, ext_conn):
         c.execute("SELECT * FROM graph_pagerank WHERE edge_table='e' AND src_col='s' AND dst_col='d' AND iterations = 3").fetchall()
     c.execute("CREATE TABLE empty_e(s TEXT, d TEXT)")
     assert c.execute("SELECT * FROM graph_pagerank WHERE edge_table='empty_e' AND src_col='s' AND dst_col='d'").fetchall() == []
+
+
+# ───────────── f-2: csr_apply_delta (the merge step of graph_adjacency's incremental rebuild) ─────────────
+
+def _same_csr(a, b):
+    return np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and ((a[2] is None and b[2] is None) or
+                                                                          np.array_equal(a[2].view(np.int64), b[2].view(np.int64)))
+
+
+@pytest.mark.parametrize("seed,weighted", [(1, False), (2, True), (3, False)])
+def test_csr_delta_oracle_vs_live_reference(seed, weighted):
+    if not og.have_ref_graph():
+        pytest.skip("oracle/_ref not built (reference sources absent)")
+    case = og.delta_case(seed, weighted=weighted)
+    assert _same_csr(og.csr_apply_delta(*case), og.ref_csr_apply_delta(*case))
+
+
+def test_csr_delta_reference_unit_cases_on_the_oracle():
+    """test/test_graph_csr.c:140-233 restated: insert A->C, delete A->B (swap with last), insert to a new node D."""
+    one = lambda *v: np.array(v, np.int32)  # noqa: E731
+    off, tgt, _ = og.csr_apply_delta(one(0, 1, 1, 1), one(1), None, one(0), one(2), np.ones(1), one(1), 3)
+    assert off.tolist() == [0, 2, 2, 2] and tgt.tolist() == [1, 2]
+    off, tgt, _ = og.csr_apply_delta(one(0, 2, 2, 2), one(1, 2), None, one(0), one(1), np.ones(1), one(2), 3)
+    assert off.tolist() == [0, 1, 1, 1] and tgt.tolist() == [2]
+    off, tgt, _ = og.csr_apply_delta(one(0, 1, 1), one(1), None, one(0), one(2), np.ones(1), one(1), 3)
+    assert off.tolist() == [0, 2, 2, 2] and tgt.tolist() == [1, 2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,weighted", [(1, False), (2, True), (3, False), (4, True)])
+def test_csr_delta_device_equals_oracle(gpu, seed, weighted):
+    case = og.delta_case(seed, n=3000, e=40_000, nd=9000, weighted=weighted)
+    assert _same_csr(gpu.graph.csr_apply_delta(*case), og.csr_apply_delta(*case))
+    # empty log, empty graph, everything deleted
+    off, tgt, w, dsrc, ddst, dw, dop, new_n = case
+    none = np.zeros(0, np.int32)
+    assert _same_csr(gpu.graph.csr_apply_delta(off, tgt, w, none, none, np.zeros(0), none, len(off) - 1),
+                     og.csr_apply_delta(off, tgt, w, none, none, np.zeros(0), none, len(off) - 1))
+    z = np.zeros(1, np.int32)
+    got = gpu.graph.csr_apply_delta(z, none, None, np.array([0, 1], np.int32), np.array([1, 0], np.int32), np.ones(2),
+                                    np.array([1, 1], np.int32), 2)
+    assert got[0].tolist() == [0, 1, 2] and got[1].tolist() == [1, 0]
