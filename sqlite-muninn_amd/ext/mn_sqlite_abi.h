@@ -5,7 +5,7 @@
  * SQLite's extension ABI is append-only and public (https://sqlite.org/loadext.html,
  * https://sqlite.org/vtab.html): an extension receives a pointer to `sqlite3_api_routines`, a
  * struct of function pointers whose member ORDER never changes.  Only the slot NUMBERS of the
- * routines used here are recorded (MN_SLOT_*); tests/test_sqlite_abi.py re-derives them — and the
+ * routines used here are recorded (MN_SLOT_*); tests/test_sqlite_ext.py (test_abi_header_matches_real_sqlite_header) re-derives them — and the
  * vtab struct layouts below — from a real sqlite3ext.h when one is available and fails on any
  * drift.  All routines used exist since SQLite 3.8.2 (estimatedRows) or earlier.
  */

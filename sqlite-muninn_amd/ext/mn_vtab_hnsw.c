@@ -58,26 +58,49 @@ typedef struct {
     float *vecbuf;
 } CurHnsw;
 
-/* live hnsw_index tables of this process, so that hnsw_search_batch can reach an index by name */
-static VtabHnsw *g_live[256];
+/* live hnsw_index tables of this process, so that hnsw_search_batch can reach an index by name.  Connections may live
+ * on different threads (SURVEY §8b "Threading": one host thread per connection, several connections per process), so the
+ * list is guarded; it grows as needed (a table beyond a fixed capacity would silently become unreachable). */
+#include <pthread.h>
+static pthread_mutex_t g_live_mu = PTHREAD_MUTEX_INITIALIZER;
+static VtabHnsw **g_live = 0;
+static int g_live_cap = 0;
 
 static void live_add(VtabHnsw *v) {
-    for (int i = 0; i < 256; i++)
-        if (!g_live[i]) {
-            g_live[i] = v;
-            return;
+    pthread_mutex_lock(&g_live_mu);
+    int slot = -1;
+    for (int i = 0; i < g_live_cap && slot < 0; i++)
+        if (!g_live[i])
+            slot = i;
+    if (slot < 0) {
+        const size_t nc = g_live_cap > 0 ? 2 * (size_t)g_live_cap : 64;
+        VtabHnsw **n = nc <= (1u << 20) ? (VtabHnsw **)realloc(g_live, nc * sizeof(*n)) : 0;
+        if (n) {
+            memset(n + g_live_cap, 0, (nc - (size_t)g_live_cap) * sizeof(*n));
+            slot = g_live_cap;
+            g_live = n;
+            g_live_cap = (int)nc;
         }
+    }
+    if (slot >= 0)
+        g_live[slot] = v;
+    pthread_mutex_unlock(&g_live_mu);
 }
 static void live_remove(VtabHnsw *v) {
-    for (int i = 0; i < 256; i++)
+    pthread_mutex_lock(&g_live_mu);
+    for (int i = 0; i < g_live_cap; i++)
         if (g_live[i] == v)
             g_live[i] = 0;
+    pthread_mutex_unlock(&g_live_mu);
 }
 static VtabHnsw *live_find(sqlite3 *db, const char *name) {
-    for (int i = 0; i < 256; i++)
+    VtabHnsw *hit = 0;
+    pthread_mutex_lock(&g_live_mu);
+    for (int i = 0; i < g_live_cap && !hit; i++)
         if (g_live[i] && g_live[i]->db == db && !strcmp(g_live[i]->name, name))
-            return g_live[i];
-    return 0;
+            hit = g_live[i];
+    pthread_mutex_unlock(&g_live_mu);
+    return hit;
 }
 
 enum { COL_VECTOR = 0, COL_DISTANCE = 1, COL_K = 2, COL_EF = 3 };
