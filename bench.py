@@ -55,15 +55,13 @@ def spawn_ranks_if_needed(gpus: int, script: str, argv: list) -> None:
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
-def gen_vectors(n, dim, seed, dataset, chunk=65536):
-    """Seeded synthetic vectors, generated in 64k-row chunks."""
+def gen_chunks(n, dim, seed, dataset, chunk=65536):
+    """Seeded synthetic vectors as a stream of 64k-row chunks — the same rows whatever is done with them."""
     rng = np.random.default_rng(seed)
-    out = np.empty((n, dim), np.float32)
     if dataset == "gaussian":
         for a in range(0, n, chunk):
-            b = min(n, a + chunk)
-            out[a:b] = rng.standard_normal((b - a, dim), dtype=np.float32)
-        return out
+            yield rng.standard_normal((min(n, a + chunk) - a, dim), dtype=np.float32)
+        return
     if dataset == "lowrank":
         # embedding-like data: intrinsic dimension 32 embedded in `dim` (x = zA + 0.02 eps), unit-normalised.
         # Isotropic Gaussian and the sigma=0.1 "clustered" set are both ~768-dimensional intrinsically (the
@@ -71,23 +69,59 @@ def gen_vectors(n, dim, seed, dataset, chunk=65536):
         arng = np.random.default_rng(777)
         A = arng.standard_normal((32, dim), dtype=np.float32) / np.float32(np.sqrt(32))
         for a in range(0, n, chunk):
-            b = min(n, a + chunk)
-            v = rng.standard_normal((b - a, 32), dtype=np.float32) @ A
-            v += np.float32(0.02) * rng.standard_normal((b - a, dim), dtype=np.float32)
+            m = min(n, a + chunk) - a
+            v = rng.standard_normal((m, 32), dtype=np.float32) @ A
+            v += np.float32(0.02) * rng.standard_normal((m, dim), dtype=np.float32)
             v /= np.linalg.norm(v, axis=1, keepdims=True)
-            out[a:b] = v
-        return out
+            yield v
+        return
     # "clustered": 64 Gaussian clusters, sigma 0.1, unit-normalised — mimics embeddings
     crng = np.random.default_rng(4242)  # centres shared by base vectors and queries
     centres = crng.standard_normal((64, dim), dtype=np.float32)
     centres /= np.linalg.norm(centres, axis=1, keepdims=True)
     for a in range(0, n, chunk):
-        b = min(n, a + chunk)
-        c = rng.integers(0, 64, b - a)
-        v = centres[c] + np.float32(0.1) * rng.standard_normal((b - a, dim), dtype=np.float32)
+        m = min(n, a + chunk) - a
+        c = rng.integers(0, 64, m)
+        v = centres[c] + np.float32(0.1) * rng.standard_normal((m, dim), dtype=np.float32)
         v /= np.linalg.norm(v, axis=1, keepdims=True)
-        out[a:b] = v
+        yield v
+
+
+def gen_vectors(n, dim, seed, dataset, chunk=65536):
+    out = np.empty((n, dim), np.float32)
+    a = 0
+    for v in gen_chunks(n, dim, seed, dataset, chunk):
+        out[a:a + len(v)] = v
+        a += len(v)
     return out
+
+
+def build_streamed(g, n, dim, seed, dataset, first_id=1, piece=1 << 20):
+    """Build without ever holding the whole matrix on the host (10M x 768 = 30.7 GB): the chunk stream is fed to
+    mn_hnsw_build a million rows at a time — the same vectors and ids as one call over the whole matrix; the batch schedule
+    differs only at the piece boundaries (the last batch of a piece is cut short)."""
+    buf, have, done, spent = [], 0, 0, 0.0
+    for v in gen_chunks(n, dim, seed, dataset):
+        buf.append(v)
+        have += len(v)
+        if have >= piece or done + have == n:
+            X = np.concatenate(buf)
+            ids = np.arange(first_id + done, first_id + done + have, dtype=np.int64)
+            t0 = time.perf_counter()
+            if g.build(ids, X, 16, 8192) != 0:
+                return -1, spent
+            g.sync()
+            spent += time.perf_counter() - t0  # (generating the rows is not part of the build)
+            done += have
+            buf, have = [], 0
+            progress(f"  built {done} / {n}")
+    return 0, spent
+
+
+def progress(msg):
+    """one line per stage on stderr (stdout carries only the JSON line): long runs must not look hung"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def recall_of(found, truth, k):
@@ -109,8 +143,15 @@ def graph_quality_leg(pkg, args, dev_ord, order, M, EFC, n, datasets, efs):
         truth = None
         for name, mode in (("exact", "sequential"), ("batched", "batched")):
             g = pkg.HnswIndex(D, args.metric, M, EFC, order=order, device=dev_ord)
+            progress(f"graph quality: {ds} {n}x{D}, {name} build")
             t0 = time.perf_counter()
-            rc = g.insert_batch(ids, X, pkg.BUILD_SEQUENTIAL) if mode == "sequential" else g.build(ids, X, 16, 8192)
+            if mode == "sequential":  # in pieces, so that a multi-minute exact build reports progress
+                rc, step = 0, 20_000
+                for a in range(0, n, step):
+                    rc = rc or g.insert_batch(ids[a:a + step], X[a:a + step], pkg.BUILD_SEQUENTIAL)
+                    progress(f"  exact inserts: {min(n, a + step)} / {n}")
+            else:
+                rc = g.build(ids, X, 16, 8192)
             if rc != 0:
                 raise SystemExit("build failed: " + pkg.hnsw._err())
             g.sync()
@@ -200,6 +241,8 @@ def main():
     ap.add_argument("--quality-n", type=int, default=50_000,
                     help="N=1: size of the exact-vs-batched graph comparison (two extra builds; 0 = skip)")
     ap.add_argument("--quality-datasets", default="lowrank", help="comma list of datasets for that comparison")
+    ap.add_argument("--stream-above", type=int, default=2_000_000,
+                    help="N above this is built from the chunk stream without holding the matrix on the host (single rank)")
     ap.add_argument("--exact-inserts", type=int, default=200,
                     help="N=1: vectors inserted one at a time (reference semantics) into the full-size index, by the GPU and by "
                          "the compiled reference on the same graph: build CPU baseline + full-size insert parity (0 = skip)")
@@ -252,7 +295,16 @@ def main():
 
     # ---- synthetic data (same seed on every rank → replicas are identical) ----
     sharded = args.mode == "sharded" and world > 1
-    if sharded:  # shard r holds the rowids ≡ r (mod world); every rank searches the SAME queries
+    streamed = N > args.stream_above  # e.g. 10M x 768: 30.7 GB fits HBM (288 GB) but is not held on the host
+    if streamed:
+        if world > 1 or not args.no_cpu_baseline or args.recall_target > 0 or args.quality_n > 0:
+            progress("large N: streamed build; CPU baselines, the recall-target leg and the graph-quality leg are skipped")
+        args.no_cpu_baseline, args.recall_target, args.quality_n = True, 0.0, 0
+        if world > 1:
+            raise SystemExit("bench.py: the streamed build is single-rank")
+        X, ids = None, None
+        Q = gen_vectors(NQ, D, 43 + rank, args.dataset)
+    elif sharded:  # shard r holds the rowids ≡ r (mod world); every rank searches the SAME queries
         X = gen_vectors(N, D, 42 + 1000 * rank, args.dataset)
         ids = np.arange(N, dtype=np.int64) * world + rank
         Q = gen_vectors(NQ, D, 43, args.dataset)
@@ -261,6 +313,7 @@ def main():
         ids = np.arange(1, N + 1, dtype=np.int64)
         Q = gen_vectors(NQ, D, 43 + rank, args.dataset)
 
+    progress(f"data generated; building {N}x{D} on device {args.device if args.device >= 0 else local_rank}")
     # ---- build on the device (reported, not the timed step) ----
     dev_ord = args.device if args.device >= 0 else local_rank
     g = pkg.HnswIndex(D, args.metric, M, EFC, order=order, device=dev_ord)
@@ -272,14 +325,19 @@ def main():
         comm = pkg.parallel.Comm(dev_ord)
         dist.barrier()
     t0 = time.perf_counter()
-    if shared_build:
+    streamed_build_s = None
+    if streamed:
+        rc, streamed_build_s = build_streamed(g, N, D, 42, args.dataset)
+        if rc != 0:
+            raise SystemExit("build failed: " + pkg.hnsw._err())
+    elif shared_build:
         # replicas of ONE graph: every batch's search half is split over the ranks, the selected lists are all-gathered
         # (RCCL), every replica links the whole batch → the graph of a one-GPU build, on every GPU (parallel.py)
         pkg.parallel.build_distributed(g, ids, X, 16, 8192, comm=comm)
     elif g.build(ids, X, 16, 8192) != 0:
         raise SystemExit("build failed: " + pkg.hnsw._err())
     g.sync()
-    build_s = time.perf_counter() - t0
+    build_s = streamed_build_s if streamed else time.perf_counter() - t0
     build_s_max = build_s
     bst = g.build_stats()
     if dist is not None:  # slowest rank's build: the N-GPU build rate is (vectors built by all ranks) / that
@@ -319,6 +377,7 @@ def main():
                     raise SystemExit("heap workspace overflow — results would be invalid")
         return kms, nd, ne
 
+    progress(f"built in {build_s:.1f}s; timing {args.steps} steps")
     run_steps(args.warmup, EF)
     barrier()
     t0 = time.perf_counter()
@@ -370,6 +429,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_queries > 0:  # N=1 only (contract)
         from oracle import orc
 
+        progress("cpu baseline: oracle, then the compiled reference, on the same graph")
         o = orc.Oracle(D, args.metric, M, EFC, order=orc.ORDER_SSE if args.order == "sse" else orc.ORDER_WAVE)
         o.load_from_device(g, vectors=X)
         nc = min(args.cpu_queries, NQ)
@@ -460,7 +520,8 @@ def main():
     if rank == 0 and world == 1 and args.recall_target > 0 and args.dataset == "gaussian":
         g.close()  # make room: the second index is the same size
         g = None
-        del X
+        X = None
+        progress("recall-target leg: lowrank data, ef ladder")
         at_target = recall_target_leg(pkg, args, dev_ord, order, M, EFC, args.recall_target)
     if rank == 0 and world == 1 and args.quality_n > 0:
         quality = graph_quality_leg(pkg, args, dev_ord, order, M, EFC, min(args.quality_n, N),

@@ -620,3 +620,20 @@ def test_wave_order_id_sets_against_the_reference_order_at_100k_x_768(gpu, orc):
     rel = np.abs(gd[same] - wd[same]) / np.maximum(np.abs(wd[same]), 1.0)
     assert rel.max() <= 1e-5
     g.close()
+
+
+def test_bench_streamed_build_path(gpu):
+    """bench.py's large-N path (the matrix is never held on the host: 10M x 768 is 30.7 GB) at a size that takes seconds."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--num-vectors", "150000", "--dim", "32", "--nq", "500",
+                        "--stream-above", "50000", "--steps", "2", "--warmup", "1", "--dataset", "lowrank"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["config"]["n"] == 150000 and j["recall_queries"] == 500 and j["recall_at_10"] > 0.8
+    assert j["build_roofline"]["batches"] > 10 and j["cpu_baseline"] is None
