@@ -66,6 +66,8 @@ struct MnSearchArgs {
     int res_gcap;
     unsigned long long *counters; // [0] n_dist [1] n_expanded [2] overflowed queries
     int use_tile;                 // SSE order: stage candidate rows through the LDS tile (coalesced loads)
+    int lds_bitmap;               // k_beam_coop, search: the layer-0 visited bitmap lives in LDS (small indexes: one query's
+                                  // bitmap fits, and the visited probe stops being a global-memory round trip per expansion)
     // build, speculative exact mode: per query the link rows its search read (mn_beam.hpp log_row_read)
     int *readlog; // [nq][readcap] or null
     int readcap;

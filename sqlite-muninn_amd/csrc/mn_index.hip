@@ -617,14 +617,19 @@ static int reserve_search_ws(mn_index *x, int64_t nq, int ef) {
     return 0;
 }
 
-static int prepare_search_ws(mn_index *x, int64_t nq, int ef, MnSearchArgs &a, bool zero_counters = true) {
+static int prepare_search_ws(mn_index *x, int64_t nq, int ef, MnSearchArgs &a, bool zero_counters = true,
+                             bool lds_bitmap_ok = false) {
     hipStream_t st = x->stream;
     a.bm0_words = ((int64_t)x->n_slots + 31) / 32;
     a.cand_gcap = 16 * ef + 1024;
     a.res_gcap = ef > MN_RES_LDS ? ef : 8;
     if (reserve_search_ws(x, nq, ef))
         return -1;
-    HIPCHK(hipMemsetAsync(x->ws_bm0.p, 0, (size_t)nq * a.bm0_words * sizeof(unsigned), st));
+    // few queries on a small index (the SQL surface: one query per xFilter): k_beam_coop keeps the visited bitmap in LDS
+    a.lds_bitmap = lds_bitmap_ok && nq <= 128 && a.bm0_words * (long long)sizeof(unsigned) <= 40 * 1024 &&
+                   !(getenv("MN_COOP") && atoi(getenv("MN_COOP")) == 0) && !(getenv("MN_LDS_BITMAP") && atoi(getenv("MN_LDS_BITMAP")) == 0);
+    if (!a.lds_bitmap)
+        HIPCHK(hipMemsetAsync(x->ws_bm0.p, 0, (size_t)nq * a.bm0_words * sizeof(unsigned), st));
     if (zero_counters)
         HIPCHK(hipMemsetAsync(x->ws_counters.p, 0, 4 * sizeof(unsigned long long), st));
     a.bitmap0 = x->ws_bm0.p;
@@ -694,7 +699,7 @@ extern "C" int mn_hnsw_search_batch_dev(mn_index *x, const float *d_queries, int
         const int64_t m = std::min<int64_t>(chunk, nq - q0);
         MnSearchArgs a;
         memset(&a, 0, sizeof(a));
-        if (prepare_search_ws(x, m, ef, a, q0 == 0)) { // (sized above: memsets only)
+        if (prepare_search_ws(x, m, ef, a, q0 == 0, true)) { // (sized above: memsets only)
             (void)hipEventRecord(x->ev1, st);
             return -1;
         }

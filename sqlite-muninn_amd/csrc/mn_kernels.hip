@@ -146,7 +146,7 @@ void mn_launch_dist_batch(int metric, int order, const float *d_query, const flo
 // one query, one (leading) wavefront; `coop` = the group's shared area when helpers stand by (k_beam_coop)
 template <int ORDER, int NCH, bool BUILD, bool WIDE>
 DEVI void beam_query(const MnDevIndex &ix, const MnSearchArgs &a, const long long qi, const int lane, unsigned char *smem,
-                     CoopCtx *coop) {
+                     CoopCtx *coop, unsigned *lds_bitmap = nullptr) {
     // LDS carve: cand heap | result heap | scratch | query
     uint2 *cand_l = reinterpret_cast<uint2 *>(smem);
     uint2 *res_l = cand_l + MN_CAND_LDS;
@@ -200,7 +200,7 @@ DEVI void beam_query(const MnDevIndex &ix, const MnSearchArgs &a, const long lon
     res.size = 0;
     res.ovf = 0;
 
-    unsigned *bm0 = a.bitmap0 + (size_t)qi * a.bm0_words;
+    unsigned *bm0 = lds_bitmap ? lds_bitmap : a.bitmap0 + (size_t)qi * a.bm0_words;
     int cur = a.entry_slot;
 
     if (!BUILD) {
@@ -286,8 +286,15 @@ __global__ void __launch_bounds__(MN_COOP_WAVES * 64) k_beam_coop(MnDevIndex ix,
     c.dist = reinterpret_cast<float *>(c.list + 64);
     c.nw = blockDim.x >> 6;
     c.wv = threadIdx.x >> 6;
+    unsigned *lbm = nullptr;
+    if (!BUILD && a.lds_bitmap) { // (uniform) one query's visited bitmap in LDS, cleared by the whole workgroup
+        lbm = reinterpret_cast<unsigned *>(smem + base_lds) + 4 + 64 + 64;
+        for (long long i = threadIdx.x; i < a.bm0_words; i += blockDim.x)
+            lbm[i] = 0u;
+        __syncthreads();
+    }
     if (c.wv == 0) {
-        beam_query<ORDER, NCH, BUILD, WIDE>(ix, a, blockIdx.x, lane, smem, &c);
+        beam_query<ORDER, NCH, BUILD, WIDE>(ix, a, blockIdx.x, lane, smem, &c, lbm);
         if (lane == 0)
             *c.n = -1;
         __syncthreads(); // releases the helpers
@@ -315,7 +322,7 @@ static void launch_beam(const MnDevIndex &ix, const MnSearchArgs &a, bool build,
     const char *co = getenv("MN_COOP"); // MN_COOP=0: always one wavefront per query
     if (a.nq <= 128 && !(co && atoi(co) == 0)) {
         const size_t base = (lds + 15) & ~(size_t)15;
-        const size_t tot = base + (4 + 64 + 64) * sizeof(int);
+        const size_t tot = base + (4 + 64 + 64) * sizeof(int) + (!build && a.lds_bitmap ? (size_t)a.bm0_words * sizeof(unsigned) : 0);
         dim3 cblock(MN_COOP_WAVES * 64);
         if (wide) {
             if (build)

@@ -114,3 +114,21 @@ def test_gpu_high_degree_nodes_use_global_scratch(gpu):
     comm, q, _ = g.leiden(1.0, "both", gpu.LEIDEN_BATCHED, 512)
     assert np.array_equal(comm, bc) and qbits(q) == qbits(bq)
     g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("weighted", [False, True])
+def test_gpu_batched_matches_oracle_schedule_at_100k_nodes(gpu, weighted):
+    """config 5's kernels at a size between the unit graphs and the bench: LFR-like, 100k nodes / ~1M edges, rounds of
+    4096 nodes; unweighted = the O(degree) hashed evaluation + device-side bookkeeping, weighted = list-order f64 sums +
+    host bookkeeping.  Communities, Q bits and the move count equal the CPU restatement of the same schedule."""
+    s, d, _ = gpu.lfr.lfr_like(100_000, 20, 100, 0.3, seed=5)
+    w = (np.random.default_rng(8).random(len(s)) * 2 + 0.5) if weighted else None
+    csr = og.Csr(s, d, w, "both", n_nodes=100_000, first_seen=False)
+    oc, oq, ost = og.leiden(csr, 1.0, 4096)
+    g = _dev_graph(gpu, csr)
+    comm, q, st = g.leiden(1.0, "both", gpu.LEIDEN_BATCHED, 4096)
+    assert np.array_equal(comm, oc) and qbits(q) == qbits(oq) and st["moves"] == ost["moves"]
+    comm2, q2, _ = g.leiden(1.0, "both", gpu.LEIDEN_BATCHED, 4096)  # the per-graph workspace is reused: same answer again
+    assert np.array_equal(comm2, oc) and qbits(q2) == qbits(oq)
+    g.close()

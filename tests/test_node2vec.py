@@ -143,3 +143,17 @@ def test_gpu_batched_acceptance_blocks(gpu):
     emb, st = gpu.node2vec_train(g.off, g.adj, 32, 1.0, 1.0, 4, 30, 4, 4, 0.025, 2, mode=gpu.N2V_BATCHED)
     w, b = _block_quality(g, emb)
     assert w - b > 0.4  # within-block similarity far above between-block (pytests/test_node2vec.py:194-273 in spirit)
+
+
+@pytest.mark.gpu
+def test_gpu_batched_bit_exact_vs_oracle_schedule_8k_nodes(gpu):
+    """config 4's kernels at a size between the unit graphs and the bench: ER graph, 8 000 nodes / 80 000 edge draws,
+    dim 32, batches of 1024 walks — embedding bits and pair count equal the CPU restatement of the same schedule."""
+    rng = np.random.default_rng(3)
+    s, d = rng.integers(0, 8000, 80_000), rng.integers(0, 8000, 80_000)
+    keep = s != d
+    g = og.N2vGraph(s[keep], d[keep])
+    prm = (32, 1.0, 1.0, 2, 20, 5, 5, 0.025, 1)
+    want, npairs = og.node2vec_train_batched(g, *prm, 1024)
+    got, st = gpu.node2vec_train(g.off, g.adj, 32, 1.0, 1.0, 2, 20, 5, 5, 0.025, 1, mode=gpu.N2V_BATCHED, batch_walks=1024)
+    assert st["pairs"] == npairs and np.array_equal(got.view(np.int32), want.view(np.int32))
