@@ -235,6 +235,18 @@ int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int mode, int 
                     double *modularity_out);
 int mn_graph_leiden_stats(mn_graph *g, mn_leiden_stats *out);
 
+/* brandes_compute (src/graph_centrality.c:393-505): node betweenness cb_out[n] and, when eb_out != NULL, the reference's dense
+ * edge matrix eb_out[n*n] (EB[v*n + w] = betweenness of v -> w; the reference allocates the same n x n doubles).  BFS for
+ * unweighted graphs, Dijkstra for weighted ones; direction 0 = "both" (halved), 1 = "forward", 2 = "reverse";
+ * auto_approx > 0 and n > auto_approx → ceil(sqrt(n)) evenly spaced sources, scaled (:420-429); normalized → / ((n-1)(n-2)[/2]).
+ * The graph must have been created with the lists the direction traverses (out for 1, in for 2, both for 0), as
+ * graph_data_load fills them (src/graph_load.c:144-250).  Bit-identical to the reference.  0 / -1. */
+int mn_graph_betweenness(mn_graph *g, int direction, int auto_approx, int normalized, double *cb_out, double *eb_out);
+double mn_graph_last_ms(mn_graph *g); /* device time of the last betweenness call */
+/* GraphData.out as CSR on the host (off[n+1], tgt[mn_graph_out_edge_count]) — the order graph_edge_betweenness emits rows in */
+long long mn_graph_out_edge_count(mn_graph *g);
+int mn_graph_out_lists(mn_graph *g, int *off, int *tgt);
+
 /* ---- node2vec.c replacements (a14-a17) ---- */
 typedef struct {
     int dim;            /* 1..1024 (src/node2vec.c:447) */

@@ -85,3 +85,27 @@ def tvf_cases():
     c["two_rows"] = ([("a", "b"), ("b", "a")], 0.85, 1)
     c["zero_iterations"] = ([("a", "b"), ("c", "a")], 0.85, 0)
     return c
+
+
+def betweenness_cases():
+    """name -> (rows (src, dst[, w]) as text ids, weighted, direction or None (= "forward"), normalized or None, auto_approx or None)
+    for graph_node_betweenness / graph_edge_betweenness: BFS and Dijkstra, the three directions, duplicate rows and self
+    loops, equal-length alternatives (sigma > 1), ties between weighted paths, the sqrt(N) source sample."""
+    r = np.random.default_rng(21)
+    c = {}
+    ks = [(str(a), str(b)) for a, b in KARATE]
+    c["karate_forward"] = (ks, False, None, None, None)
+    c["karate_both_norm"] = (ks, False, "both", 1, None)
+    c["karate_reverse"] = (ks, False, "reverse", None, None)
+    rows = [(f"n{a}", f"n{b}") for a, b in r.integers(0, 60, (260, 2))] + [("n1", "n1"), ("n2", "n3"), ("n2", "n3")]
+    c["er60_forward"] = (rows, False, "forward", None, None)
+    c["er60_both"] = (rows, False, "both", None, None)
+    c["er60_approx"] = (rows, False, "both", 1, 20)  # 60 nodes > 20 -> ceil(sqrt(60)) = 8 sources, scaled
+    wrows = [(f"n{a}", f"n{b}", float(w)) for (a, b), w in zip(r.integers(0, 50, (220, 2)), r.integers(1, 4, 220))]  # small integer weights: many ties
+    c["w50_forward"] = (wrows, True, "forward", None, None)
+    c["w50_both_norm"] = (wrows, True, "both", 1, None)
+    frows = [(f"n{a}", f"n{b}", float(w)) for (a, b), w in zip(r.integers(0, 40, (160, 2)), r.random(160) + 0.1)]
+    c["wfloat40_reverse"] = (frows, True, "reverse", None, None)
+    grid = [(f"g{i}_{j}", f"g{i + 1}_{j}") for i in range(5) for j in range(6)] + [(f"g{i}_{j}", f"g{i}_{j + 1}") for i in range(6) for j in range(5)]
+    c["grid6_both"] = (grid, False, "both", None, None)  # many equal-length shortest paths
+    return c

@@ -15,6 +15,7 @@ int mn_register_hnsw_module(sqlite3 *db);
 int mn_register_node2vec(sqlite3 *db);
 int mn_register_leiden(sqlite3 *db);
 int mn_register_graph_tvfs(sqlite3 *db);
+int mn_register_betweenness_tvfs(sqlite3 *db);
 
 int hnsw_register_module(sqlite3 *db) { /* src/hnsw_vtab.h */
     mn_sqlite_api = sqlite3_api;
@@ -24,6 +25,8 @@ int community_register_tvfs(sqlite3 *db) { /* src/graph_community.h; runs after 
     int rc = mn_register_leiden(db);
     if (rc == 0)
         rc = mn_register_graph_tvfs(db); /* graph_components / graph_pagerank: the device versions replace the reference's */
+    if (rc == 0)
+        rc = mn_register_betweenness_tvfs(db); /* likewise graph_node_betweenness / graph_edge_betweenness */
     return rc;
 }
 int node2vec_register_functions(sqlite3 *db) { /* src/node2vec.h */

@@ -946,3 +946,206 @@ int orc_csr_apply_delta(int old_n, const int *off, const int *tgt, const double 
     free(cap); free(cnt); free(start); free(lt); free(lw);
     return o;
 }
+
+
+/* ───────────────────────── f-4: Brandes betweenness (src/graph_centrality.c:150-505) ───────────────────────── */
+
+typedef struct {
+    int node;
+    double dist;
+} obr_ent;
+
+static int obr_double_eq(double a, double b) { /* :215-217 */
+    return fabs(a - b) < 1e-10 * fmax(1.0, fabs(b));
+}
+
+int orc_betweenness(const orc_graph *g, int direction, int auto_approx, int normalized, double *cb, double *eb) {
+    const int N = g->n;
+    if (N <= 0)
+        return 0;
+    const int use_out = direction != 2, use_in = direction == 2 || direction == 0;
+    const int weighted = g->w_out != NULL || g->w_in != NULL;
+    /* predecessor slots: one per traversed edge arriving at a node */
+    int *poff = (int *)calloc((size_t)N + 1, sizeof(int));
+    long etrav = 0;
+    if (use_out)
+        for (int e = 0; e < g->off_out[N]; e++, etrav++)
+            poff[g->tgt_out[e] + 1]++;
+    if (use_in)
+        for (int e = 0; e < g->off_in[N]; e++, etrav++)
+            poff[g->tgt_in[e] + 1]++;
+    for (int i = 0; i < N; i++)
+        poff[i + 1] += poff[i];
+    double *dist = (double *)malloc((size_t)N * sizeof(double)), *sigma = (double *)malloc((size_t)N * sizeof(double));
+    double *delta = (double *)malloc((size_t)N * sizeof(double));
+    int *stack = (int *)malloc((size_t)N * sizeof(int)), *queue = (int *)malloc((size_t)N * sizeof(int));
+    int *pcnt = (int *)malloc((size_t)N * sizeof(int)), *pit = (int *)malloc((size_t)(poff[N] ? poff[N] : 1) * sizeof(int));
+    int *settled = (int *)malloc((size_t)N * sizeof(int)), *sources = (int *)malloc((size_t)N * sizeof(int));
+    obr_ent *h = (obr_ent *)malloc((size_t)(etrav + 2) * sizeof(obr_ent));
+    if (!poff || !dist || !sigma || !delta || !stack || !queue || !pcnt || !pit || !settled || !sources || !h)
+        return -1;
+    for (int i = 0; i < N; i++)
+        cb[i] = 0.0;
+    int n_sources = N; /* :417-433 */
+    double scale = 1.0;
+    if (auto_approx > 0 && N > auto_approx) {
+        n_sources = (int)ceil(sqrt((double)N));
+        if (n_sources < 1)
+            n_sources = 1;
+        int step = N / n_sources;
+        if (step < 1)
+            step = 1;
+        n_sources = 0;
+        for (int i = 0; i < N && n_sources < (int)ceil(sqrt((double)N)); i += step)
+            sources[n_sources++] = i;
+        scale = (double)N / (double)n_sources;
+    } else {
+        for (int i = 0; i < N; i++)
+            sources[i] = i;
+    }
+    for (int si = 0; si < n_sources; si++) {
+        const int s = sources[si];
+        int ss = 0;
+        for (int i = 0; i < N; i++) {
+            dist[i] = -1.0;
+            sigma[i] = 0.0;
+            pcnt[i] = 0;
+            settled[i] = 0;
+        }
+        dist[s] = 0.0;
+        sigma[s] = 1.0;
+        if (!weighted) { /* sssp_bfs :263-315 */
+            int qh = 0, qt = 0;
+            queue[qt++] = s;
+            while (qh < qt) {
+                int v = queue[qh++];
+                stack[ss++] = v;
+                for (int pass = 0; pass < 2; pass++) {
+                    if (pass == 0 ? !use_out : !use_in)
+                        continue;
+                    const int *off = pass ? g->off_in : g->off_out, *tgt = pass ? g->tgt_in : g->tgt_out;
+                    for (int e = off[v]; e < off[v + 1]; e++) {
+                        int w = tgt[e];
+                        if (dist[w] < 0) {
+                            dist[w] = dist[v] + 1.0;
+                            queue[qt++] = w;
+                        }
+                        if (obr_double_eq(dist[w], dist[v] + 1.0)) {
+                            if (pcnt[w] == 0 || pit[poff[w] + pcnt[w] - 1] != v) {
+                                sigma[w] += sigma[v];
+                                pit[poff[w] + pcnt[w]++] = v;
+                            }
+                        }
+                    }
+                }
+            }
+        } else { /* sssp_dijkstra :321-378, dpq :158-212 */
+            int hs = 0;
+            h[hs].node = s;
+            h[hs].dist = 0.0;
+            hs++;
+            while (hs > 0) {
+                obr_ent top = h[0];
+                hs--;
+                if (hs > 0) {
+                    h[0] = h[hs];
+                    int i = 0;
+                    for (;;) {
+                        int left = 2 * i + 1, right = 2 * i + 2, smallest = i;
+                        if (left < hs && h[left].dist < h[smallest].dist)
+                            smallest = left;
+                        if (right < hs && h[right].dist < h[smallest].dist)
+                            smallest = right;
+                        if (smallest == i)
+                            break;
+                        obr_ent t = h[i];
+                        h[i] = h[smallest];
+                        h[smallest] = t;
+                        i = smallest;
+                    }
+                }
+                int v = top.node;
+                if (settled[v])
+                    continue;
+                settled[v] = 1;
+                stack[ss++] = v;
+                for (int pass = 0; pass < 2; pass++) {
+                    if (pass == 0 ? !use_out : !use_in)
+                        continue;
+                    const int *off = pass ? g->off_in : g->off_out, *tgt = pass ? g->tgt_in : g->tgt_out;
+                    const double *wt = pass ? g->w_in : g->w_out;
+                    for (int e = off[v]; e < off[v + 1]; e++) {
+                        int w = tgt[e];
+                        double nd = dist[v] + (wt ? wt[e] : 1.0);
+                        if (dist[w] < 0 || nd < dist[w] - 1e-10) {
+                            dist[w] = nd;
+                            sigma[w] = sigma[v];
+                            pit[poff[w]] = v;
+                            pcnt[w] = 1;
+                            int i = hs++;
+                            h[i].node = w;
+                            h[i].dist = nd;
+                            while (i > 0) {
+                                int parent = (i - 1) / 2;
+                                if (h[parent].dist <= h[i].dist)
+                                    break;
+                                obr_ent t = h[parent];
+                                h[parent] = h[i];
+                                h[i] = t;
+                                i = parent;
+                            }
+                        } else if (obr_double_eq(nd, dist[w])) {
+                            if (pcnt[w] == 0 || pit[poff[w] + pcnt[w] - 1] != v) {
+                                sigma[w] += sigma[v];
+                                pit[poff[w] + pcnt[w]++] = v;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        for (int i = 0; i < N; i++)
+            delta[i] = 0.0;
+        while (ss > 0) { /* :448-462 */
+            int w = stack[--ss];
+            for (int pi = 0; pi < pcnt[w]; pi++) {
+                int v = pit[poff[w] + pi];
+                if (sigma[w] > 0) {
+                    double flow = (sigma[v] / sigma[w]) * (1.0 + delta[w]);
+                    delta[v] += flow;
+                    if (eb)
+                        eb[(size_t)v * N + w] += flow;
+                }
+            }
+            if (w != s)
+                cb[w] += delta[w];
+        }
+    }
+    const long NN = (long)N * N;
+    if (scale != 1.0) { /* :466-474 */
+        for (int i = 0; i < N; i++)
+            cb[i] *= scale;
+        if (eb)
+            for (long i = 0; i < NN; i++)
+                eb[i] *= scale;
+    }
+    const int undirected = direction == 0;
+    if (undirected) {
+        for (int i = 0; i < N; i++)
+            cb[i] /= 2.0;
+        if (eb)
+            for (long i = 0; i < NN; i++)
+                eb[i] /= 2.0;
+    }
+    if (normalized && N > 2) {
+        double nf = undirected ? (double)(N - 1) * (double)(N - 2) / 2.0 : (double)(N - 1) * (double)(N - 2);
+        for (int i = 0; i < N; i++)
+            cb[i] /= nf;
+        if (eb)
+            for (long i = 0; i < NN; i++)
+                eb[i] /= nf;
+    }
+    free(poff); free(dist); free(sigma); free(delta); free(stack); free(queue); free(pcnt); free(pit); free(settled);
+    free(sources); free(h);
+    return 0;
+}

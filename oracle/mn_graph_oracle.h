@@ -56,6 +56,9 @@ int orc_biased_walk(const orc_n2v_graph *g, int start, double p, double q, int w
  * returns n; off must hold n_max+1 ints, adj 2*n_edges ints, index_of_id n_ids ints (or NULL). */
 int orc_n2v_build_graph(int n_edges, const int *src, const int *dst, int n_ids, int *off, int *adj, int *index_of_id);
 
+/* brandes_compute (src/graph_centrality.c:393-505) over orc_graph (out / in lists in adjacency order, weights or NULL):
+ * direction 0 "both", 1 "forward", 2 "reverse".  cb[n]; eb = NULL or n*n doubles (zeroed by the caller). */
+int orc_betweenness(const orc_graph *g, int direction, int auto_approx, int normalized, double *cb, double *eb);
 /* csr_apply_delta (src/graph_csr.c:175-325): per-node replay of the delta log.  delta arrays are parallel
  * (src, dst, weight, op: 1 INSERT, 2 DELETE).  new_off must hold max(new_n, old_n) + 1 ints, new_tgt / new_w room for
  * old edges + delta count.  Returns the new edge count, -1 on error. */

@@ -333,3 +333,43 @@ def delta_case(seed, n=300, e=2000, nd=900, weighted=False, new_nodes=40):
     ddst[: nd // 2][dop[: nd // 2] == 2] = tgt[pick][dop[: nd // 2] == 2]
     dw = r.random(nd)
     return off, tgt, w, dsrc, ddst, dw, dop, new_n
+
+
+# ───────────────────────── f-4: Brandes betweenness ─────────────────────────
+
+_DIR = {"both": 0, "forward": 1, "reverse": 2}
+
+
+def betweenness(csr: Csr, auto_approx=0, normalized=0, edges=False):
+    """orc_betweenness on a Csr built for the traversal direction → (cb[n], eb[n][n] or None)"""
+    L = _lib()
+    L.orc_betweenness.argtypes = [C.POINTER(_Graph), C.c_int, C.c_int, C.c_int, _f64p, C.c_void_p]
+    g = csr.c_struct()
+    cb = np.zeros(max(csr.n, 1), np.float64)
+    eb = np.zeros((csr.n, csr.n), np.float64) if edges else None
+    assert L.orc_betweenness(C.byref(g), _DIR[csr.direction], int(auto_approx), int(normalized), cb,
+                             eb.ctypes.data if edges else None) == 0
+    return cb[:csr.n], eb
+
+
+def ref_betweenness_sql(rows, weighted=False, direction=None, normalized=None, auto_approx=None):
+    """The reference's graph_node_betweenness / graph_edge_betweenness through its SQL surface (build container only).
+    rows: (src, dst[, weight]).  Returns ([(node, centrality)], [(src, dst, centrality)])."""
+    import sqlite3
+
+    c = sqlite3.connect(":memory:")
+    c.enable_load_extension(True)
+    c.load_extension(REF_EXT_SO[:-3])
+    c.execute("CREATE TABLE e(s TEXT, d TEXT, w REAL)")
+    c.executemany("INSERT INTO e VALUES (?, ?, ?)", [(r[0], r[1], r[2] if len(r) > 2 else None) for r in rows])
+    extra, args = "", []
+    for col, val in (("weight_col", "w" if weighted else None), ("direction", direction), ("normalized", normalized),
+                     ("auto_approx_threshold", auto_approx)):
+        if val is not None:
+            extra += f" AND {col} = ?"
+            args.append(val)
+    where = "edge_table='e' AND src_col='s' AND dst_col='d'" + extra
+    nodes = c.execute("SELECT node, centrality FROM graph_node_betweenness WHERE " + where, args).fetchall()
+    edges = c.execute("SELECT src, dst, centrality FROM graph_edge_betweenness WHERE " + where, args).fetchall()
+    c.close()
+    return nodes, edges

@@ -1401,3 +1401,362 @@ extern "C" int mn_graph_leiden_stats(mn_graph *g, mn_leiden_stats *out) {
     *out = g->stats;
     return 0;
 }
+
+// ───────────────────────── Brandes betweenness (src/graph_centrality.c:260-505) ─────────────────────────
+// The reference runs one single-source shortest-path pass per source — BFS for unweighted graphs, Dijkstra with a lazy binary
+// heap for weighted ones, predecessor lists in discovery order — then the dependency accumulation in reverse stack order,
+// and adds every source's result to CB / EB in source order (f64: the order of those additions is part of the result).
+// Sources are independent, so the device runs them side by side: ONE LANE PER SOURCE replays the reference's pass verbatim
+// on that source's own scratch rows (queue, stack, predecessor lists, heap — the same control flow, hence the same
+// stack order, predecessor order and f64 operations), and k_brandes_accumulate then folds the sources of the chunk into
+// CB[w] / EB[v][w] in source order, one lane per target w (a cell is only ever written by w's lane).  The dependency of w
+// at the moment the reference pops it is its final value, so the flow (sigma[v] / sigma[w]) * (1 + delta[w]) is recomputed
+// there from the stored sigma / delta with the same operands.  Divergent by construction (64 different traversals per
+// wavefront): this trades SIMD efficiency for bit-exact reference semantics; throughput comes from thousands of sources
+// in flight.
+struct BrDpq {
+    int node;
+    double dist;
+};
+struct BrArgs {
+    DevGraph g;
+    int use_out, use_in, weighted;
+    int n_src;           // sources in this chunk
+    const int *sources;  // [n_src]
+    const int *poff;     // [N+1] predecessor-list slots per node (static: one per incident traversed edge)
+    long long P;         // poff[N]
+    long long heap_cap;  // Dijkstra: entries per source
+    double *dist, *sigma, *delta; // [n_src][N]
+    int *stack, *queue, *pcnt;    // [n_src][N]   (queue doubles as Dijkstra's settled flags)
+    int *pitems;                  // [n_src][P]
+    BrDpq *heap;                  // [n_src][heap_cap]
+    int *overflow;
+};
+
+DEVI bool br_double_eq(double a, double b) { return fabs(a - b) < 1e-10 * fmax(1.0, fabs(b)); } // :215-217
+
+__global__ void __launch_bounds__(64) k_brandes_sources(BrArgs a) {
+    const int si = blockIdx.x * blockDim.x + threadIdx.x;
+    if (si >= a.n_src)
+        return;
+    const int N = a.g.n, src = a.sources[si];
+    double *dist = a.dist + (size_t)si * N, *sigma = a.sigma + (size_t)si * N, *delta = a.delta + (size_t)si * N;
+    int *stack = a.stack + (size_t)si * N, *queue = a.queue + (size_t)si * N, *pcnt = a.pcnt + (size_t)si * N;
+    int *pitems = a.pitems + (size_t)si * a.P;
+    for (int i = 0; i < N; i++) {
+        dist[i] = -1.0;
+        sigma[i] = 0.0;
+        pcnt[i] = 0;
+        queue[i] = 0;
+    }
+    dist[src] = 0.0;
+    sigma[src] = 1.0;
+    int ss = 0;
+    if (!a.weighted) { // sssp_bfs, :263-315
+        int qh = 0, qt = 0;
+        queue[qt++] = src;
+        while (qh < qt) {
+            const int v = queue[qh++];
+            stack[ss++] = v;
+            for (int pass = 0; pass < 2; pass++) {
+                if (pass == 0 ? !a.use_out : !a.use_in)
+                    continue;
+                const int *off = pass ? a.g.off_in : a.g.off_out, *tgt = pass ? a.g.tgt_in : a.g.tgt_out;
+                for (int e = off[v]; e < off[v + 1]; e++) {
+                    const int w = tgt[e];
+                    if (dist[w] < 0) {
+                        dist[w] = dist[v] + 1.0;
+                        queue[qt++] = w;
+                    }
+                    if (br_double_eq(dist[w], dist[v] + 1.0)) {
+                        const int pc = pcnt[w];
+                        if (pc == 0 || pitems[a.poff[w] + pc - 1] != v) {
+                            sigma[w] += sigma[v];
+                            pitems[a.poff[w] + pc] = v;
+                            pcnt[w] = pc + 1;
+                        }
+                    }
+                }
+            }
+        }
+    } else { // sssp_dijkstra, :321-378, with dpq_push / dpq_pop (:158-212) verbatim
+        BrDpq *h = a.heap + (size_t)si * a.heap_cap;
+        int hs = 0;
+        int *settled = queue;
+        h[hs].node = src;
+        h[hs].dist = 0.0;
+        hs++;
+        while (hs > 0) {
+            const BrDpq top = h[0];
+            hs--;
+            if (hs > 0) {
+                h[0] = h[hs];
+                int i = 0;
+                for (;;) {
+                    const int left = 2 * i + 1, right = 2 * i + 2;
+                    int smallest = i;
+                    if (left < hs && h[left].dist < h[smallest].dist)
+                        smallest = left;
+                    if (right < hs && h[right].dist < h[smallest].dist)
+                        smallest = right;
+                    if (smallest == i)
+                        break;
+                    const BrDpq t = h[i];
+                    h[i] = h[smallest];
+                    h[smallest] = t;
+                    i = smallest;
+                }
+            }
+            const int v = top.node;
+            if (settled[v])
+                continue;
+            settled[v] = 1;
+            stack[ss++] = v;
+            for (int pass = 0; pass < 2; pass++) {
+                if (pass == 0 ? !a.use_out : !a.use_in)
+                    continue;
+                const int *off = pass ? a.g.off_in : a.g.off_out, *tgt = pass ? a.g.tgt_in : a.g.tgt_out;
+                const double *wt = pass ? a.g.w_in : a.g.w_out;
+                for (int e = off[v]; e < off[v + 1]; e++) {
+                    const int w = tgt[e];
+                    const double nd = dist[v] + (wt ? wt[e] : 1.0);
+                    if (dist[w] < 0 || nd < dist[w] - 1e-10) {
+                        dist[w] = nd;
+                        sigma[w] = sigma[v];
+                        pitems[a.poff[w]] = v;
+                        pcnt[w] = 1;
+                        if (hs >= a.heap_cap) {
+                            *a.overflow = 1;
+                            return;
+                        }
+                        int i = hs++;
+                        h[i].node = w;
+                        h[i].dist = nd;
+                        while (i > 0) {
+                            const int parent = (i - 1) / 2;
+                            if (h[parent].dist <= h[i].dist)
+                                break;
+                            const BrDpq t = h[parent];
+                            h[parent] = h[i];
+                            h[i] = t;
+                            i = parent;
+                        }
+                    } else if (br_double_eq(nd, dist[w])) {
+                        const int pc = pcnt[w];
+                        if (pc == 0 || pitems[a.poff[w] + pc - 1] != v) {
+                            if (pc >= a.poff[w + 1] - a.poff[w]) { // (cannot happen: one slot per incident edge)
+                                *a.overflow = 1;
+                                return;
+                            }
+                            sigma[w] += sigma[v];
+                            pitems[a.poff[w] + pc] = v;
+                            pcnt[w] = pc + 1;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // dependency accumulation in reverse stack order (:448-462)
+    for (int i = 0; i < N; i++)
+        delta[i] = 0.0;
+    while (ss > 0) {
+        const int w = stack[--ss];
+        const int pc = pcnt[w];
+        for (int pi = 0; pi < pc; pi++) {
+            const int v = pitems[a.poff[w] + pi];
+            if (sigma[w] > 0) {
+                const double flow = (sigma[v] / sigma[w]) * (1.0 + delta[w]);
+                delta[v] += flow;
+            }
+        }
+    }
+}
+
+// CB[w] += delta_s[w] (w != s) and EB[v*N + w] += flow, sources of the chunk in order; one lane per target w
+__global__ void k_brandes_accumulate(BrArgs a, double *CB, double *EB) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = a.g.n;
+    if (w >= N)
+        return;
+    double cb = CB[w];
+    for (int si = 0; si < a.n_src; si++) {
+        const double *sigma = a.sigma + (size_t)si * N, *delta = a.delta + (size_t)si * N;
+        const double dw = delta[w];
+        if (EB) {
+            const int pc = a.pcnt[(size_t)si * N + w];
+            const int *items = a.pitems + (size_t)si * a.P + a.poff[w];
+            const double sw = sigma[w];
+            for (int pi = 0; pi < pc; pi++) {
+                const int v = items[pi];
+                if (sw > 0)
+                    EB[(size_t)v * N + w] += (sigma[v] / sw) * (1.0 + dw);
+            }
+        }
+        if (w != a.sources[si])
+            cb += dw;
+    }
+    CB[w] = cb;
+}
+
+__global__ void k_scale_d(double *x, long long n, double mul, double div1, double div2) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    double v = x[i];
+    if (mul != 1.0)
+        v *= mul;
+    if (div1 != 1.0)
+        v /= div1;
+    if (div2 != 1.0)
+        v /= div2;
+    x[i] = v;
+}
+
+extern "C" int mn_graph_betweenness(mn_graph *g, int direction, int auto_approx, int normalized, double *cb_out, double *eb_out) {
+    GCHK(hipSetDevice(g->device));
+    const int N = g->n;
+    if (N == 0)
+        return 0;
+    if (direction < 0 || direction > 2) {
+        gset_err("mn_graph_betweenness: direction must be 0 (both), 1 (forward) or 2 (reverse)");
+        return -1;
+    }
+    const int use_out = direction != 2, use_in = direction == 2 || direction == 0; // :281-282
+    hipStream_t st = g->stream;
+    // source set (:417-433)
+    std::vector<int> sources;
+    double scale = 1.0;
+    if (auto_approx > 0 && N > auto_approx) {
+        const int want = (int)ceil(sqrt((double)N));
+        int n_sources = want < 1 ? 1 : want;
+        int step = N / n_sources;
+        if (step < 1)
+            step = 1;
+        for (int i = 0; i < N && (int)sources.size() < want; i += step)
+            sources.push_back(i);
+        scale = (double)N / (double)sources.size();
+    } else {
+        for (int i = 0; i < N; i++)
+            sources.push_back(i);
+    }
+    // predecessor slots: one per traversed edge arriving at the node
+    std::vector<int> tgt_o((size_t)g->e_out), tgt_i((size_t)g->e_in), poff((size_t)N + 1, 0);
+    if (g->e_out)
+        GCHK(hipMemcpy(tgt_o.data(), g->tgt_out, (size_t)g->e_out * sizeof(int), hipMemcpyDeviceToHost));
+    if (g->e_in)
+        GCHK(hipMemcpy(tgt_i.data(), g->tgt_in, (size_t)g->e_in * sizeof(int), hipMemcpyDeviceToHost));
+    long long e_trav = 0;
+    if (use_out)
+        for (int x : tgt_o) {
+            poff[(size_t)x + 1]++;
+            e_trav++;
+        }
+    if (use_in)
+        for (int x : tgt_i) {
+            poff[(size_t)x + 1]++;
+            e_trav++;
+        }
+    for (int i = 0; i < N; i++)
+        poff[(size_t)i + 1] += poff[(size_t)i];
+    const long long P = poff[(size_t)N] > 0 ? poff[(size_t)N] : 1;
+    const long long heap_cap = g->weighted ? e_trav + 2 : 1;
+    // chunk of sources that fits the scratch budget
+    const size_t per_src = (size_t)N * (3 * sizeof(double) + 3 * sizeof(int)) + (size_t)P * sizeof(int) + (size_t)heap_cap * sizeof(BrDpq);
+    size_t budget = (size_t)8 << 30;
+    if (const char *e = getenv("MN_BRANDES_SCRATCH_MB"))
+        budget = (size_t)atoll(e) << 20;
+    int chunk = (int)std::max<size_t>(1, std::min<size_t>(sources.size(), budget / per_src));
+    struct Scr {
+        std::vector<void *> p;
+        ~Scr() {
+            for (void *q : p)
+                (void)hipFree(q);
+        }
+        void *get(size_t bytes) {
+            void *q = nullptr;
+            if (hipMalloc(&q, bytes ? bytes : 16) != hipSuccess)
+                return nullptr;
+            p.push_back(q);
+            return q;
+        }
+    } scr;
+    BrArgs a;
+    memset(&a, 0, sizeof(a));
+    a.g = {N, g->off_out, g->tgt_out, g->w_out, g->off_in, g->tgt_in, g->w_in};
+    a.use_out = use_out;
+    a.use_in = use_in;
+    a.weighted = g->weighted ? 1 : 0;
+    a.P = P;
+    a.heap_cap = heap_cap;
+    int *d_sources = (int *)scr.get((size_t)chunk * sizeof(int)), *d_poff = (int *)scr.get(((size_t)N + 1) * sizeof(int));
+    a.dist = (double *)scr.get((size_t)chunk * N * sizeof(double));
+    a.sigma = (double *)scr.get((size_t)chunk * N * sizeof(double));
+    a.delta = (double *)scr.get((size_t)chunk * N * sizeof(double));
+    a.stack = (int *)scr.get((size_t)chunk * N * sizeof(int));
+    a.queue = (int *)scr.get((size_t)chunk * N * sizeof(int));
+    a.pcnt = (int *)scr.get((size_t)chunk * N * sizeof(int));
+    a.pitems = (int *)scr.get((size_t)chunk * P * sizeof(int));
+    a.heap = (BrDpq *)scr.get((size_t)chunk * heap_cap * sizeof(BrDpq));
+    a.overflow = (int *)scr.get(sizeof(int));
+    double *d_cb = (double *)scr.get((size_t)N * sizeof(double));
+    double *d_eb = eb_out ? (double *)scr.get((size_t)N * N * sizeof(double)) : nullptr;
+    if (!d_sources || !d_poff || !a.dist || !a.sigma || !a.delta || !a.stack || !a.queue || !a.pcnt || !a.pitems || !a.heap ||
+        !a.overflow || !d_cb || (eb_out && !d_eb)) {
+        gset_err("mn_graph_betweenness: out of device memory (N = %d%s)", N, eb_out ? ", dense N x N edge matrix as in the reference" : "");
+        return -1;
+    }
+    a.sources = d_sources;
+    a.poff = d_poff;
+    GCHK(hipMemcpyAsync(d_poff, poff.data(), ((size_t)N + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    GCHK(hipMemsetAsync(d_cb, 0, (size_t)N * sizeof(double), st));
+    GCHK(hipMemsetAsync(a.overflow, 0, sizeof(int), st));
+    if (d_eb)
+        GCHK(hipMemsetAsync(d_eb, 0, (size_t)N * N * sizeof(double), st));
+    GCHK(hipEventRecord(g->ev0, st));
+    for (size_t s0 = 0; s0 < sources.size(); s0 += (size_t)chunk) {
+        a.n_src = (int)std::min<size_t>((size_t)chunk, sources.size() - s0);
+        GCHK(hipMemcpyAsync(d_sources, sources.data() + s0, (size_t)a.n_src * sizeof(int), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_brandes_sources, dim3((a.n_src + 63) / 64), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(k_brandes_accumulate, dim3((N + 255) / 256), dim3(256), 0, st, a, d_cb, d_eb);
+        GCHK(hipStreamSynchronize(st)); // (the host vector `sources` chunk must outlive the copy; also bounds the queue)
+    }
+    // approximation scale, undirected halving, normalisation — in the reference's order (:466-498)
+    const int undirected = direction == 0;
+    const double half = undirected ? 2.0 : 1.0;
+    double norm = 1.0;
+    if (normalized && N > 2)
+        norm = undirected ? (double)(N - 1) * (double)(N - 2) / 2.0 : (double)(N - 1) * (double)(N - 2);
+    hipLaunchKernelGGL(k_scale_d, dim3((N + 255) / 256), dim3(256), 0, st, d_cb, (long long)N, scale, half, norm);
+    if (d_eb)
+        hipLaunchKernelGGL(k_scale_d, dim3((unsigned)(((long long)N * N + 255) / 256)), dim3(256), 0, st, d_eb, (long long)N * N, scale,
+                           half, norm);
+    GCHK(hipEventRecord(g->ev1, st));
+    GCHK(hipGetLastError());
+    int ovf = 0;
+    GCHK(hipMemcpyAsync(&ovf, a.overflow, sizeof(int), hipMemcpyDeviceToHost, st));
+    GCHK(hipMemcpyAsync(cb_out, d_cb, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (d_eb)
+        GCHK(hipMemcpyAsync(eb_out, d_eb, (size_t)N * N * sizeof(double), hipMemcpyDeviceToHost, st));
+    GCHK(hipStreamSynchronize(st));
+    if (ovf) {
+        gset_err("mn_graph_betweenness: scratch overflow");
+        return -1;
+    }
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, g->ev0, g->ev1) == hipSuccess)
+        g->last_ms = ms;
+    return 0;
+}
+
+extern "C" double mn_graph_last_ms(mn_graph *g) { return g->last_ms; }
+
+// GraphData.out as the host sees it (graph_edge_betweenness emits its rows in this order, src/graph_centrality.c:1172-1182)
+extern "C" long long mn_graph_out_edge_count(mn_graph *g) { return g->e_out; }
+extern "C" int mn_graph_out_lists(mn_graph *g, int *off, int *tgt) {
+    GCHK(hipSetDevice(g->device));
+    memcpy(off, g->h_off_out.data(), ((size_t)g->n + 1) * sizeof(int));
+    if (g->e_out)
+        GCHK(hipMemcpy(tgt, g->tgt_out, (size_t)g->e_out * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}

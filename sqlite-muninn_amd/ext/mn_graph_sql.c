@@ -442,76 +442,58 @@ static int lei_run(LeiCursor *c, LeiVtab *vt, mn_graph *g, int n, char **ids, co
     return SQLITE_OK;
 }
 
-/* src/graph_community.c:516-610 + graph_data_load (src/graph_load.c:144-250) */
-static int lei_filter(sqlite3_vtab_cursor *cur, int idxNum, const char *idxStr, int argc, sqlite3_value **argv) {
-    (void)idxStr;
-    LeiCursor *c = (LeiCursor *)cur;
-    LeiVtab *vt = (LeiVtab *)cur->pVtab;
-    lei_clear(c);
-    c->pos = 0;
-    c->eof = 1;
-    if (argc < 3)
-        return SQLITE_OK;
-    const char *edge_table = 0, *src_col = 0, *dst_col = 0, *weight_col = 0, *direction = 0, *ts_col = 0;
-    sqlite3_value *t0 = 0, *t1 = 0;
-    double resolution = 1.0;
-    int pos = 0;
-    for (int bit = 0; bit < 9 && pos < argc; bit++) {
-        if (!(idxNum & (1 << bit)))
-            continue;
-        switch (bit + LC_EDGE_TABLE) {
-        case LC_EDGE_TABLE: edge_table = safe_text(argv[pos]); break;
-        case LC_SRC: src_col = safe_text(argv[pos]); break;
-        case LC_DST: dst_col = safe_text(argv[pos]); break;
-        case LC_WEIGHT: weight_col = safe_text(argv[pos]); break;
-        case LC_RES: resolution = sqlite3_value_double(argv[pos]); break;
-        case LC_DIR: direction = safe_text(argv[pos]); break;
-        case LC_TS: ts_col = safe_text(argv[pos]); break;
-        case LC_T0: t0 = argv[pos]; break;
-        case LC_T1: t1 = argv[pos]; break;
-        }
-        pos++;
-    }
-    if (!direction)
-        direction = "both";
+/* graph_data_load (src/graph_load.c:144-250) — or, when edge_table names a graph_adjacency table, graph_data_load_from_adjacency
+ * (src/graph_adjacency.c:1532-1573) — straight to a device graph: text ids → first-seen indices, out / in lists in row order
+ * for the directions loaded, weights when a weight column is given.  SQLITE_OK with *g_out = NULL for an empty graph; on error
+ * *err is set (sqlite3_mprintf).  The ids (malloc'ed strings) and the graph belong to the caller.  Shared by graph_leiden and
+ * the centrality TVFs (mn_graph_tvf.c). */
+int mn_sql_load_graph(sqlite3 *db, const char *who, const char *edge_table, const char *src_col, const char *dst_col,
+                      const char *weight_col, const char *direction, const char *ts_col, sqlite3_value *t0, sqlite3_value *t1,
+                      mn_graph **g_out, char ***ids_out, int *n_out, char **err) {
+    *g_out = 0;
+    *ids_out = 0;
+    *n_out = 0;
     if (!ident_ok(edge_table) || !ident_ok(src_col) || !ident_ok(dst_col)) {
-        vt->base.zErrMsg = sqlite3_mprintf("invalid table/column identifier");
+        *err = sqlite3_mprintf("invalid table/column identifier");
         return SQLITE_ERROR;
     }
     if (weight_col && !ident_ok(weight_col)) {
-        vt->base.zErrMsg = sqlite3_mprintf("invalid weight column identifier");
+        *err = sqlite3_mprintf("invalid weight column identifier");
         return SQLITE_ERROR;
     }
     if (ts_col && !ident_ok(ts_col)) {
-        vt->base.zErrMsg = sqlite3_mprintf("invalid timestamp column identifier");
+        *err = sqlite3_mprintf("invalid timestamp column identifier");
         return SQLITE_ERROR;
     }
     const char *load_dir = direction;
-    char *a_table = adj_cfg(vt->db, edge_table, "edge_table"), *a_src = 0, *a_dst = 0, *a_w = 0;
+    char *a_table = adj_cfg(db, edge_table, "edge_table"), *a_src = 0, *a_dst = 0, *a_w = 0;
     if (a_table) { /* edge_table names a graph_adjacency table */
-        if (adj_delta_count(vt->db, edge_table) == 0) {
+        if (adj_delta_count(db, edge_table) == 0) {
             sqlite3_free(a_table);
-            char **ids = 0, *err = 0;
+            char **ids = 0, *e2 = 0;
             int n = 0;
-            mn_graph *g = adj_load_fresh(vt->db, edge_table, &ids, &n, &err);
+            mn_graph *g = adj_load_fresh(db, edge_table, &ids, &n, &e2);
             if (!g) {
                 for (int i = 0; i < n; i++)
                     free(ids[i]);
                 free(ids);
-                if (err) {
-                    vt->base.zErrMsg = err;
+                if (e2) {
+                    *err = e2;
                     return SQLITE_ERROR;
                 }
                 return SQLITE_OK; /* empty graph */
             }
-            return lei_run(c, vt, g, n, ids, direction, resolution);
+            *g_out = g;
+            *ids_out = ids;
+            *n_out = n;
+            return SQLITE_OK;
         }
         /* stale: the original edge table, both directions, no time window (src/graph_adjacency.c:1536-1569) */
-        a_src = adj_cfg(vt->db, edge_table, "src_col");
-        a_dst = adj_cfg(vt->db, edge_table, "dst_col");
-        a_w = adj_cfg(vt->db, edge_table, "weight_col");
+        a_src = adj_cfg(db, edge_table, "src_col");
+        a_dst = adj_cfg(db, edge_table, "dst_col");
+        a_w = adj_cfg(db, edge_table, "weight_col");
         if (!a_src || !a_dst) {
-            vt->base.zErrMsg = sqlite3_mprintf("graph_adjacency '%s': missing config", edge_table);
+            *err = sqlite3_mprintf("graph_adjacency '%s': missing config", edge_table);
             sqlite3_free(a_table); sqlite3_free(a_src); sqlite3_free(a_dst); sqlite3_free(a_w);
             return SQLITE_ERROR;
         }
@@ -534,12 +516,12 @@ static int lei_filter(sqlite3_vtab_cursor *cur, int idxNum, const char *idxStr, 
     else
         sql = sqlite3_mprintf("SELECT \"%w\", \"%w\" FROM \"%w\"", src_col, dst_col, edge_table);
     sqlite3_stmt *st = 0;
-    int rc = sqlite3_prepare_v2(vt->db, sql, -1, &st, 0);
+    int rc = sqlite3_prepare_v2(db, sql, -1, &st, 0);
     sqlite3_free(sql);
     const int with_w = weight_col != 0;
     sqlite3_free(a_table); sqlite3_free(a_src); sqlite3_free(a_dst); sqlite3_free(a_w); /* names are in the statement now */
     if (rc != SQLITE_OK) {
-        vt->base.zErrMsg = sqlite3_mprintf("failed to prepare: %s", sqlite3_errmsg(vt->db));
+        *err = sqlite3_mprintf("failed to prepare: %s", sqlite3_errmsg(db));
         return SQLITE_ERROR;
     }
     if (ts_col) {
@@ -591,12 +573,60 @@ static int lei_filter(sqlite3_vtab_cursor *cur, int idxNum, const char *idxStr, 
     mn_graph *g = mn_graph_create(n, oo, ot, ow, io, it, iw, 0);
     free(oo); free(ot); free(ow); free(io); free(it); free(iw);
     if (!g) {
-        vt->base.zErrMsg = sqlite3_mprintf("graph_leiden: %s", mn_graph_last_error());
+        *err = sqlite3_mprintf("%s: %s", who, mn_graph_last_error());
         nm_free(&nm);
         return SQLITE_ERROR;
     }
     free(nm.slots);
-    return lei_run(c, vt, g, n, nm.ids, direction, resolution); /* ownership of the ids moves to the cursor */
+    *g_out = g;
+    *ids_out = nm.ids; /* ownership of the ids moves to the caller */
+    *n_out = n;
+    return SQLITE_OK;
+}
+
+/* src/graph_community.c:516-610 + graph_data_load (src/graph_load.c:144-250) */
+static int lei_filter(sqlite3_vtab_cursor *cur, int idxNum, const char *idxStr, int argc, sqlite3_value **argv) {
+    (void)idxStr;
+    LeiCursor *c = (LeiCursor *)cur;
+    LeiVtab *vt = (LeiVtab *)cur->pVtab;
+    lei_clear(c);
+    c->pos = 0;
+    c->eof = 1;
+    if (argc < 3)
+        return SQLITE_OK;
+    const char *edge_table = 0, *src_col = 0, *dst_col = 0, *weight_col = 0, *direction = 0, *ts_col = 0;
+    sqlite3_value *t0 = 0, *t1 = 0;
+    double resolution = 1.0;
+    int pos = 0;
+    for (int bit = 0; bit < 9 && pos < argc; bit++) {
+        if (!(idxNum & (1 << bit)))
+            continue;
+        switch (bit + LC_EDGE_TABLE) {
+        case LC_EDGE_TABLE: edge_table = safe_text(argv[pos]); break;
+        case LC_SRC: src_col = safe_text(argv[pos]); break;
+        case LC_DST: dst_col = safe_text(argv[pos]); break;
+        case LC_WEIGHT: weight_col = safe_text(argv[pos]); break;
+        case LC_RES: resolution = sqlite3_value_double(argv[pos]); break;
+        case LC_DIR: direction = safe_text(argv[pos]); break;
+        case LC_TS: ts_col = safe_text(argv[pos]); break;
+        case LC_T0: t0 = argv[pos]; break;
+        case LC_T1: t1 = argv[pos]; break;
+        }
+        pos++;
+    }
+    if (!direction)
+        direction = "both";
+    mn_graph *g = 0;
+    char **ids = 0, *err = 0;
+    int n = 0;
+    if (mn_sql_load_graph(vt->db, "graph_leiden", edge_table, src_col, dst_col, weight_col, direction, ts_col, t0, t1, &g, &ids, &n,
+                          &err) != SQLITE_OK) {
+        vt->base.zErrMsg = err;
+        return SQLITE_ERROR;
+    }
+    if (!g)
+        return SQLITE_OK; /* empty graph */
+    return lei_run(c, vt, g, n, ids, direction, resolution); /* ownership of the ids moves to the cursor */
 }
 
 static int lei_next(sqlite3_vtab_cursor *cur) {

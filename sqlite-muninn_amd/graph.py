@@ -58,6 +58,11 @@ GRAPH_SYMBOLS = [
     ("mn_graph_last_error", C.c_char_p, []),
     ("mn_graph_leiden", C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, _i32p, C.POINTER(C.c_double)]),
     ("mn_graph_leiden_stats", C.c_int, [C.c_void_p, C.POINTER(LeidenStats)]),
+    ("mn_graph_betweenness", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"),
+                                       C.c_void_p]),
+    ("mn_graph_last_ms", C.c_double, [C.c_void_p]),
+    ("mn_graph_out_edge_count", C.c_longlong, [C.c_void_p]),
+    ("mn_graph_out_lists", C.c_int, [C.c_void_p, _i32p, _i32p]),
     ("mn_graph_pagerank", C.c_int, [C.c_int, C.c_int64, _i32p, _i32p, C.c_double, C.c_int, C.c_int,
                                     np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"), C.POINTER(AlgoStats)]),
     ("mn_graph_components", C.c_int, [C.c_int, C.c_int64, _i32p, _i32p, C.c_int, C.c_int, _i32p, _i32p, C.POINTER(AlgoStats)]),
@@ -137,6 +142,15 @@ class Graph:
             self.h = None
 
     __del__ = close
+
+    def betweenness(self, direction="forward", auto_approx=0, normalized=0, edges=False):
+        """brandes_compute (src/graph_centrality.c:393-505) → (cb[n], eb[n][n] or None, device ms)"""
+        cb = np.zeros(max(self.n, 1), np.float64)
+        eb = np.zeros((self.n, self.n), np.float64) if edges else None
+        d = {"both": 0, "forward": 1, "reverse": 2}[direction]
+        if self.L.mn_graph_betweenness(self.h, d, int(auto_approx), int(normalized), cb, eb.ctypes.data if edges else None) != 0:
+            raise MuninnHipError(_gerr())
+        return cb[:self.n], eb, self.L.mn_graph_last_ms(self.h)
 
     def leiden(self, resolution=1.0, direction="both", mode=LEIDEN_SEQUENTIAL, batch=0):
         """run_leiden → (community[n] int32, Q, stats dict)"""

@@ -172,3 +172,110 @@ def test_csr_delta_device_equals_oracle(gpu, seed, weighted):
     got = gpu.graph.csr_apply_delta(z, none, None, np.array([0, 1], np.int32), np.array([1, 0], np.int32), np.ones(2),
                                     np.array([1, 1], np.int32), 2)
     assert got[0].tolist() == [0, 1, 2] and got[1].tolist() == [1, 0]
+
+
+# ───────────── f-4: Brandes betweenness (src/graph_centrality.c:393-505) ─────────────
+
+from oracle.graph_cases import betweenness_cases  # noqa: E402
+
+BCASES = betweenness_cases()
+
+
+def _bgolden():
+    with gzip.open(os.path.join(G, "betweenness.json.gz"), "rt") as f:
+        return json.load(f)
+
+
+def _bcase_csr(name):
+    rows, weighted, direction, normalized, approx = BCASES[name]
+    ids = {}
+    s, d, w = [], [], []
+    for r in rows:
+        for x in r[:2]:
+            ids.setdefault(x, len(ids))
+        s.append(ids[r[0]])
+        d.append(ids[r[1]])
+        w.append(r[2] if len(r) > 2 else 1.0)
+    csr = og.Csr(np.array(s), np.array(d), np.array(w) if weighted else None, direction or "forward", n_nodes=len(ids),
+                 first_seen=False)
+    return csr, list(ids), normalized or 0, approx
+
+
+def _edge_rows(csr, names, eb):
+    rows, bits = [], []
+    for i in range(csr.n):  # GraphData.out in list order, positive values only (src/graph_centrality.c:1172-1182)
+        for e in range(csr.off_out[i], csr.off_out[i + 1]):
+            t = csr.tgt_out[e]
+            if eb[i, t] > 0:
+                rows.append([names[i], names[t]])
+                bits.append(int(eb[i, t].view(np.int64)))
+    return rows, bits
+
+
+@pytest.mark.parametrize("name", sorted(BCASES))
+def test_betweenness_oracle_matches_reference_golden(name):
+    z = _bgolden()[name]
+    csr, names, normalized, approx = _bcase_csr(name)
+    cb, _ = og.betweenness(csr, 50000 if approx is None else approx, normalized)  # node TVF default threshold (:838)
+    assert names == z["nodes"] and cb.view(np.int64).tolist() == z["cb_bits"]
+    _, eb = og.betweenness(csr, 0 if approx is None else approx, normalized, edges=True)  # edge TVF default (:1082)
+    rows, bits = _edge_rows(csr, names, eb)
+    assert rows == z["edges"] and bits == z["eb_bits"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(BCASES))
+def test_betweenness_device_matches_reference_golden(gpu, name):
+    z = _bgolden()[name]
+    csr, names, normalized, approx = _bcase_csr(name)
+    g = gpu.Graph(csr.n, csr.off_out, csr.tgt_out, csr.w_out if csr.weighted else None, csr.off_in, csr.tgt_in,
+                  csr.w_in if csr.weighted else None)
+    cb, _, _ = g.betweenness(csr.direction, 50000 if approx is None else approx, normalized)
+    assert cb.view(np.int64).tolist() == z["cb_bits"], name
+    _, eb, _ = g.betweenness(csr.direction, 0 if approx is None else approx, normalized, edges=True)
+    rows, bits = _edge_rows(csr, names, eb)
+    assert rows == z["edges"] and bits == z["eb_bits"], name
+    g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("weighted", [False, True])
+def test_betweenness_device_vs_oracle_larger(gpu, weighted):
+    """3 000 nodes / 15 000 edges, all sources, in several chunks of the scratch budget: node values bit-identical."""
+    rng = np.random.default_rng(12)
+    n, m = 3000, 15000
+    s, d = rng.integers(0, n, m), rng.integers(0, n, m)
+    w = rng.integers(1, 5, m).astype(np.float64) if weighted else None
+    csr = og.Csr(s, d, w, "both", n_nodes=n, first_seen=False)
+    want, _ = og.betweenness(csr, 0, 1)
+    g = gpu.Graph(csr.n, csr.off_out, csr.tgt_out, csr.w_out if weighted else None, csr.off_in, csr.tgt_in, csr.w_in if weighted else None)
+    os.environ["MN_BRANDES_SCRATCH_MB"] = "256"  # several chunks of sources: the source-order accumulation crosses chunks
+    try:
+        got, _, ms = g.betweenness("both", 0, 1)
+    finally:
+        os.environ.pop("MN_BRANDES_SCRATCH_MB")
+    assert np.array_equal(got.view(np.int64), want.view(np.int64))
+    g.close()
+
+
+@pytest.mark.gpu
+def test_betweenness_sql_equals_the_reference(gpu, ext_conn):
+    c = ext_conn
+    z = _bgolden()
+    for name, (rows, weighted, direction, normalized, approx) in sorted(BCASES.items()):
+        c.execute("DROP TABLE IF EXISTS e")
+        c.execute("CREATE TABLE e(s TEXT, d TEXT, w REAL)")
+        c.executemany("INSERT INTO e VALUES (?, ?, ?)", [(r[0], r[1], r[2] if len(r) > 2 else None) for r in rows])
+        extra, args = "", []
+        for col, val in (("weight_col", "w" if weighted else None), ("direction", direction), ("normalized", normalized),
+                         ("auto_approx_threshold", approx)):
+            if val is not None:
+                extra += f" AND {col} = ?"
+                args.append(val)
+        where = "edge_table='e' AND src_col='s' AND dst_col='d'" + extra
+        nodes = c.execute("SELECT node, centrality FROM graph_node_betweenness WHERE " + where, args).fetchall()
+        assert [r[0] for r in nodes] == z[name]["nodes"], name
+        assert np.array([r[1] for r in nodes], np.float64).view(np.int64).tolist() == z[name]["cb_bits"], name
+        edges = c.execute("SELECT src, dst, centrality FROM graph_edge_betweenness WHERE " + where, args).fetchall()
+        assert [[r[0], r[1]] for r in edges] == z[name]["edges"], name
+        assert np.array([r[2] for r in edges], np.float64).view(np.int64).tolist() == z[name]["eb_bits"], name
