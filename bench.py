@@ -403,6 +403,8 @@ def main():
     g.dev_download(out_ids, d_ids)
     nrec = min(args.recall_queries, NQ)
     recall = None
+    if sharded:
+        nrec = 0  # (ground truth lives on the union of the shards; the per-shard brute force is not it)
     if nrec > 0:
         tb0 = time.perf_counter()
         truth = g.bruteforce_topk(dq, nrec, K)
