@@ -626,7 +626,8 @@ static int prepare_search_ws(mn_index *x, int64_t nq, int ef, MnSearchArgs &a, b
     if (reserve_search_ws(x, nq, ef))
         return -1;
     // few queries on a small index (the SQL surface: one query per xFilter): k_beam_coop keeps the visited bitmap in LDS
-    a.lds_bitmap = lds_bitmap_ok && nq <= 128 && a.bm0_words * (long long)sizeof(unsigned) <= 40 * 1024 &&
+    a.lds_bitmap = lds_bitmap_ok && nq <= 128 &&
+                   (long long)mn_search_lds_bytes(x->ld, true) + 1024 + a.bm0_words * (long long)sizeof(unsigned) <= 64 * 1024 &&
                    !(getenv("MN_COOP") && atoi(getenv("MN_COOP")) == 0) && !(getenv("MN_LDS_BITMAP") && atoi(getenv("MN_LDS_BITMAP")) == 0);
     if (!a.lds_bitmap)
         HIPCHK(hipMemsetAsync(x->ws_bm0.p, 0, (size_t)nq * a.bm0_words * sizeof(unsigned), st));

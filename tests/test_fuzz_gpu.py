@@ -22,8 +22,9 @@ def _run(script, seconds, seed):
 
 @pytest.mark.gpu
 def test_hnsw_random_configurations_match_oracle(gpu):
-    last = _run("fuzz_parity.py", 35, 11)
-    assert int(last.split()[1]) >= 20, last  # it did get through a meaningful number of cases
+    last = _run("fuzz_parity.py", 45, 11)
+    assert int(last.split()[1]) >= 6, last  # it did get through a meaningful number of cases (heavy-delete cases are slow)
+    assert " 0 delete refusals" in last, last
 
 
 @pytest.mark.gpu
