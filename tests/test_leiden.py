@@ -132,3 +132,36 @@ def test_gpu_batched_matches_oracle_schedule_at_100k_nodes(gpu, weighted):
     comm2, q2, _ = g.leiden(1.0, "both", gpu.LEIDEN_BATCHED, 4096)  # the per-graph workspace is reused: same answer again
     assert np.array_equal(comm2, oc) and qbits(q2) == qbits(oq)
     g.close()
+
+
+@pytest.mark.gpu
+def test_config5_full_size_properties(gpu):
+    """BASELINE config 5 at full size (LFR-like, 500k nodes / ~9.3M edges, 1 GPU): size-independent properties of run_leiden's
+    output — contiguous ids in first-seen order, Q = compute_modularity of the returned partition recomputed on the host in
+    f64 (1e-9), the planted communities recovered (NMI > 0.99), and the same bits when run again on the reused workspace."""
+    n = 500_000
+    s, d, truth = gpu.lfr.lfr_like(n, 40, 200, 0.3)
+    g = gpu.graph.graph_from_edges(n, s, d)
+    comm, q, st = g.leiden(1.0, "both", gpu.LEIDEN_BATCHED)
+    comm2, q2, _ = g.leiden(1.0, "both", gpu.LEIDEN_BATCHED)
+    g.close()
+    assert np.array_equal(comm, comm2) and qbits(q) == qbits(q2)
+    K = int(comm.max()) + 1
+    first = np.full(K, n, np.int64)
+    np.minimum.at(first, comm, np.arange(n))
+    assert (np.diff(first) > 0).all()  # renumbered in first-seen order (src/graph_community.c:317-331)
+    # modularity of the partition, both directions (every undirected edge appears in out[] of one end and in[] of the other)
+    m = float(len(s))
+    deg = np.bincount(s, minlength=n) + np.bincount(d, minlength=n)
+    tot = np.bincount(comm, weights=deg, minlength=K)
+    inside = np.bincount(comm[s][comm[s] == comm[d]], minlength=K) * 2.0
+    q_host = float(np.sum(inside / (2 * m) - (tot / (2 * m)) ** 2))
+    assert abs(q - q_host) < 1e-9 and q > 0.6
+    a = np.unique(truth, return_inverse=True)[1]
+    cont = np.zeros((a.max() + 1, K))
+    np.add.at(cont, (a, comm), 1)
+    pa, pb, pab = cont.sum(1) / n, cont.sum(0) / n, cont / n
+    nz = pab > 0
+    mi = (pab[nz] * np.log(pab[nz] / (pa[:, None] * pb[None, :])[nz])).sum()
+    nmi = 2 * mi / (-(pa[pa > 0] * np.log(pa[pa > 0])).sum() - (pb[pb > 0] * np.log(pb[pb > 0])).sum())
+    assert nmi > 0.99 and st["move_sweeps"] > 0

@@ -157,3 +157,28 @@ def test_gpu_batched_bit_exact_vs_oracle_schedule_8k_nodes(gpu):
     want, npairs = og.node2vec_train_batched(g, *prm, 1024)
     got, st = gpu.node2vec_train(g.off, g.adj, 32, 1.0, 1.0, 2, 20, 5, 5, 0.025, 1, mode=gpu.N2V_BATCHED, batch_walks=1024)
     assert st["pairs"] == npairs and np.array_equal(got.view(np.int32), want.view(np.int32))
+
+
+@pytest.mark.gpu
+def test_config4_shape_properties_200k_nodes(gpu):
+    """BASELINE config 4's parameters (p = q = 1, dim 128, window 5, neg 5, 80-step walks) on a 200k-node / 4M-edge-draw ER
+    graph: every embedding is unit length (the reference normalises before its INSERTs), the pair count is the closed
+    form for walks that never dead-end, neighbours are closer than strangers, and a second run gives the same bits."""
+    rng = np.random.default_rng(42)
+    n, m = 200_000, 4_000_000
+    s, d = rng.integers(0, n, m), rng.integers(0, n, m)
+    keep = s != d
+    off, adj = gpu.graph.n2v_csr_from_edges(n, s[keep], d[keep])
+    prm = dict(p=1.0, q=1.0, num_walks=2, walk_length=80, window=5, neg_samples=5, learning_rate=0.025, epochs=1)
+    emb, st = gpu.node2vec_train(off, adj, 128, mode=gpu.N2V_BATCHED, **prm)
+    emb2, st2 = gpu.node2vec_train(off, adj, 128, mode=gpu.N2V_BATCHED, **prm)
+    assert np.array_equal(emb.view(np.int32), emb2.view(np.int32)) and st["pairs"] == st2["pairs"]
+    nn = len(off) - 1
+    assert np.abs(np.linalg.norm(emb, axis=1) - 1.0).max() < 1e-5
+    L, W = 80, 5  # pairs of one full-length walk: sum over positions of the clipped window (src/node2vec.c:519-531)
+    per_walk = sum(min(L - 1, i + W) - max(0, i - W) for i in range(L))
+    assert st["pairs"] == nn * 2 * per_walk  # (mean degree 40: no isolated nodes, no dead ends on an undirected graph)
+    a = rng.integers(0, nn, 2000)
+    nb = adj[off[a]]  # first neighbour of each sampled node
+    stranger = rng.integers(0, nn, 2000)
+    assert float((emb[a] * emb[nb]).sum(1).mean()) > float((emb[a] * emb[stranger]).sum(1).mean()) + 0.05
