@@ -231,7 +231,7 @@ DEVI int greedy_layer(const MnDevIndex &ix, WaveCtx &w, int entry, int level, in
             }
             const int pos = c0 + lane;
             int nb = (pos < W) ? ld_link<COH>(row + pos) : -1;
-            bool valid = pos >= i0 && nb >= 0 && !ix.deleted[nb >= 0 ? nb : 0];
+            bool valid = pos >= i0 && nb >= 0 && !(ix.has_deleted && ix.deleted[nb >= 0 ? nb : 0]);
             unsigned long long m = __ballot(valid);
             int n = __popcll(m);
             if (n == 0) {
@@ -284,7 +284,7 @@ DEVI void beam_layer(const MnDevIndex &ix, WaveCtx &w, WHeap &cand, WHeap &res, 
                      int ef, int lane) {
     cand.size = 0;
     res.size = 0;
-    if (!ix.deleted[entry]) { // :360-366
+    if (!(ix.has_deleted && ix.deleted[entry])) { // :360-366
         float d = ctx_distance<ORDER, NCH>(ix, w, entry, 1, lane);
         d = __shfl(d, 0);
         w.n_dist += 1;
@@ -326,7 +326,7 @@ DEVI void beam_layer(const MnDevIndex &ix, WaveCtx &w, WHeap &cand, WHeap &res, 
             int vi = level == 0 ? nb : ix.up_off[nb];
             unsigned bit = 1u << (vi & 31);
             unsigned old = atomicOr(&bitmap[vi >> 5], bit);
-            todo = !(old & bit) && !ix.deleted[nb];
+            todo = !(old & bit) && !(ix.has_deleted && ix.deleted[nb]);
         }
         unsigned long long m = __ballot(todo);
         int n = __popcll(m);

@@ -35,6 +35,7 @@ struct MnDevIndex {
     int WX;     // max(W0, WU): stride of per-row scratch that serves both kinds of row
     int n_slots;
     int n_pool_rows;
+    int has_deleted; // 0: no soft-deleted node exists — the per-candidate deleted[] gather of the searches is skipped
 };
 
 // One launch of the beam-search kernel (search or build flavour).

@@ -82,6 +82,7 @@ struct mn_index {
     int max_level = -1;
     unsigned rng_state = 42;
     int node_count = 0;
+    int n_deleted = 0; // soft-deleted nodes among the slots
     // host metadata, slot-indexed
     std::vector<int64_t> ids;
     std::vector<signed char> levels;
@@ -293,6 +294,7 @@ static MnDevIndex dev_view(mn_index *x) {
     v.WX = std::max(x->W0, x->WU);
     v.n_slots = x->n_slots;
     v.n_pool_rows = x->n_pool_rows;
+    v.has_deleted = x->n_deleted > 0;
     return v;
 }
 
@@ -1498,6 +1500,7 @@ extern "C" int mn_hnsw_delete(mn_index *x, int64_t id) { // src/hnsw_algo.c:717-
     }
     x->deleted[s] = 1; // :722-723
     x->node_count--;
+    x->n_deleted++;
     if (x->entry_id == id) { // :790-802 scan in hash-table order, strict >
         x->entry_id = -1;
         x->max_level = -1;
@@ -1582,6 +1585,8 @@ extern "C" int mn_hnsw_load_node(mn_index *x, int64_t id, const float *vector, i
     }
     if (!deleted)
         x->node_count++;
+    else
+        x->n_deleted++;
     // host only: the vector waits for one bulk upload (sync_meta) instead of a copy + two synchronisations per row
     if (x->load_vecs.empty())
         x->load_first = s;
