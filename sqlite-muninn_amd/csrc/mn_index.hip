@@ -1292,17 +1292,23 @@ extern "C" int mn_hnsw_build_shared(mn_index *x, mn_comm *c, const int64_t *ids,
         HIPCHK(hipMemsetAsync(x->sh_sel.p, 0xFF, (size_t)rows * row_sel * sizeof(int), st));
         HIPCHK(hipMemsetAsync(x->sh_nsel.p, 0, (size_t)rows * nlev * sizeof(int), st));
         const int lo = split ? std::min(m, rank * per) : 0, hi = split ? std::min(m, rank * per + per) : m;
-        if (mn_hnsw_batch_search(x, lo, hi, x->sh_sel.p, x->sh_nsel.p)) // this rank's slice of the batch's searches
+        // from here on the batch's nodes are in the host tables but not linked: a failure must not leave a half-built index in use
+        if (mn_hnsw_batch_search(x, lo, hi, x->sh_sel.p, x->sh_nsel.p)) { // this rank's slice of the batch's searches
+            x->broken = true;
             return -1;
+        }
         if (split) { // in place: rank r's rows already sit at r * per
             if (mn_comm_allgather_dev(c, x->sh_sel.p + (size_t)rank * per * row_sel, x->sh_sel.p, (size_t)per * row_sel * sizeof(int), st) ||
                 mn_comm_allgather_dev(c, x->sh_nsel.p + (size_t)rank * per * nlev, x->sh_nsel.p, (size_t)per * nlev * sizeof(int), st)) {
                 set_err("mn_hnsw_build_shared: %s", mn_comm_last_error_str());
+                x->broken = true;
                 return -1;
             }
         }
-        if (mn_hnsw_batch_link(x, x->sh_sel.p, x->sh_nsel.p)) // every replica links the whole batch
+        if (mn_hnsw_batch_link(x, x->sh_sel.p, x->sh_nsel.p)) { // every replica links the whole batch
+            x->broken = true;
             return -1;
+        }
     }
     return 0;
 }
