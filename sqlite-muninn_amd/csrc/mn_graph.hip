@@ -41,7 +41,10 @@
 
 #define DEVI __device__ __forceinline__
 #define LEI_CAP 1024 // edges of one node staged in LDS; larger nodes use the global scratch path
-#define LEI_SG_CAP 64 // sub-group evaluation: edges staged per node (more → the node takes a whole wavefront)
+#ifndef LEI_SG_CAP
+#define LEI_SG_CAP 64 // sub-group evaluation: edges staged per node (more → the node takes a whole wavefront); power of two
+#endif
+#define LEI_SG_LOG2H (LEI_SG_CAP == 32 ? 6 : LEI_SG_CAP == 64 ? 7 : LEI_SG_CAP == 128 ? 8 : 9) // table of 2 * LEI_SG_CAP entries
 
 struct DevGraph {
     int n;
@@ -463,7 +466,7 @@ template <int SG, bool HASH> __global__ void __launch_bounds__(64) k_leiden_eval
         if (HASH) {
             int *tk = reinterpret_cast<int *>(lei_smem) + grp * 3 * (2 * LEI_SG_CAP);
             best = best_move_hash<SG>(a.g, v, a.label, a.sum_tot, a.kdeg, a.m, a.resolution, a.use_both, a.elig_part, tk,
-                                      tk + 2 * LEI_SG_CAP, tk + 4 * LEI_SG_CAP, 7, lane, sl, &dk); // H = 128 = 2 * LEI_SG_CAP
+                                      tk + 2 * LEI_SG_CAP, tk + 4 * LEI_SG_CAP, LEI_SG_LOG2H, lane, sl, &dk); // H = 2 * LEI_SG_CAP
         } else {
             double *lds_w = reinterpret_cast<double *>(lei_smem);
             int *lds_c = reinterpret_cast<int *>(lds_w + NG * LEI_SG_CAP);
