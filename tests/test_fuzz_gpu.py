@@ -22,12 +22,12 @@ def _run(script, seconds, seed):
 
 @pytest.mark.gpu
 def test_hnsw_random_configurations_match_oracle(gpu):
-    last = _run("fuzz_parity.py", 45, 11)
-    assert int(last.split()[1]) >= 6, last  # it did get through a meaningful number of cases (heavy-delete cases are slow)
+    last = _run("fuzz_parity.py", 30, 11)
+    assert int(last.split()[1]) >= 4, last  # it did get through a meaningful number of cases (heavy-delete cases are slow)
     assert " 0 delete refusals" in last, last
 
 
 @pytest.mark.gpu
 def test_graph_random_configurations_match_oracle(gpu):
-    last = _run("fuzz_graph.py", 25, 11)
-    assert int(last.split()[1]) >= 50, last
+    last = _run("fuzz_graph.py", 18, 11)
+    assert int(last.split()[1]) >= 30, last
