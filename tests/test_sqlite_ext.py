@@ -556,3 +556,28 @@ def test_integrated_build_keeps_the_rest_of_the_reference_surface_loadable():
     c.execute("CREATE VIRTUAL TABLE g USING graph_adjacency(edge_table='e', src_col='s', dst_col='d')")
     assert c.execute("SELECT count(*) FROM g").fetchone()[0] == 4  # the reference's graph_adjacency vtab, unchanged
     c.close()
+
+
+@pytest.mark.gpu
+def test_session_with_lists_longer_than_m_max_equals_the_reference(ext_built, gpu, monkeypatch):
+    """tests/golden/vtab_overgrown.npz: one SQL session recorded from the REFERENCE's extension in which 800 of 1 000 rows of
+    an m = 2 index are deleted (its reconnection step grows neighbour lists past M_max), searched, extended by 60 rows
+    (which prune the long lists they touch) and searched again.  Same statements through this extension: same answers
+    (ids and distances) on both states and identical shadow tables."""
+    from oracle import gen_golden as gg
+
+    monkeypatch.setenv("MUNINN_HNSW_MODE", "exact")
+    z = np.load(os.path.join(ROOT, "tests", "golden", "vtab_overgrown.npz"))
+    c = sqlite3.connect(":memory:")
+    c.enable_load_extension(True)
+    c.load_extension(ext_built)
+    res1, res2, nodes, edges, cfg = gg.vtab_overgrown_ops(c)
+    c.close()
+    for res, ki, kd in ((res1, "res1_ids", "res1_dist"), (res2, "res2_ids", "res2_dist")):
+        for q, rr in enumerate(res):
+            assert [r[0] for r in rr] == [int(x) for x in z[ki][q] if x >= 0], (ki, q)
+            assert [r[1] for r in rr] == z[kd][q][:len(rr)].tolist(), (kd, q)
+    assert [f"{k}={v}" for k, v in cfg] == z["config"].tolist()
+    assert np.array_equal(np.array(nodes, np.int64), z["nodes"])
+    assert np.array_equal(np.array([e[:3] for e in edges], np.int64), z["edges_int"])
+    assert np.array_equal(np.array([e[3] for e in edges], np.float64), z["edges_dist"])
