@@ -25,6 +25,9 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: cannot build libmuninn_hip.so")
 
 
+OBJ = os.path.join(HERE, "csrc", "_obj")
+
+
 def stale() -> bool:
     if not os.path.exists(LIB):
         return True
@@ -34,9 +37,29 @@ def stale() -> bool:
 
 
 def build(force: bool = False) -> str:
-    if force or stale():
-        cmd = [_hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-        subprocess.run(cmd, check=True, cwd=CSRC)
+    """One object per translation unit, compiled side by side (the kernels instantiate many templates: ~3 minutes serially,
+    under a minute on 8 cores), then one link.  No device code crosses a translation unit, so plain -c objects suffice."""
+    if not (force or stale()):
+        return LIB
+    from concurrent.futures import ThreadPoolExecutor
+
+    os.makedirs(OBJ, exist_ok=True)
+    cc = _hipcc()
+    cflags = [f for f in FLAGS if f not in ("-shared", "-ldl")]
+    hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS + [os.path.basename(__file__)] if os.path.exists(os.path.join(CSRC, h)))
+    hdr_t = max(hdr_t, os.path.getmtime(os.path.abspath(__file__)))
+
+    def one(src):
+        obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+        sp = os.path.join(CSRC, src)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(sp), hdr_t):
+            return obj
+        subprocess.run([cc] + cflags + ["-c", "-o", obj, sp], check=True, cwd=CSRC)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(one, SOURCES))
+    subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"], check=True, cwd=CSRC)
     return LIB
 
 
