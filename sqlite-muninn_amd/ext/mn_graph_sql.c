@@ -175,7 +175,7 @@ static void fn_node2vec_train(sqlite3_context *ctx, int argc, sqlite3_value **ar
     /* pairs ≈ n · walks · length · 2·window · epochs; the serial stream handles ~0.4 M pairs/s */
     long long work = (long long)n * prm.num_walks * prm.walk_length * 2 * prm.window * prm.epochs;
     int mode = graph_mode_fast(work, 4000000LL) && n >= 512 ? MN_N2V_BATCHED : MN_N2V_SEQUENTIAL;
-    int got = emb ? mn_node2vec_train(n, off, tgt, &prm, mode, 0, emb, 0) : -1;
+    int got = emb ? mn_node2vec_train(n, off, tgt, &prm, mode, mn_env_device(), emb, 0) : -1;
     free(off);
     free(tgt);
     nm_free(&nm);
@@ -414,7 +414,7 @@ static mn_graph *adj_load_fresh(sqlite3 *db, const char *t, char ***ids_out, int
         *err = sqlite3_mprintf("failed to load forward CSR");
     else if (adj_read_blocks(db, t, "_csr_rev", &rev, &nr) != SQLITE_OK)
         *err = sqlite3_mprintf("failed to load reverse CSR");
-    else if (!(g = mn_graph_create_blocked(n, fwd, nf, rev, nr, 0)))
+    else if (!(g = mn_graph_create_blocked(n, fwd, nf, rev, nr, mn_env_device())))
         *err = sqlite3_mprintf("graph_leiden: %s", mn_graph_last_error());
     adj_free_blocks(fwd, nf);
     adj_free_blocks(rev, nr);
@@ -570,7 +570,7 @@ int mn_sql_load_graph(sqlite3 *db, const char *who, const char *edge_table, cons
     double *ow, *iw;
     lists_to_csr(outl, n, with_w, &oo, &ot, &ow);
     lists_to_csr(inl, n, with_w, &io, &it, &iw);
-    mn_graph *g = mn_graph_create(n, oo, ot, ow, io, it, iw, 0);
+    mn_graph *g = mn_graph_create(n, oo, ot, ow, io, it, iw, mn_env_device());
     free(oo); free(ot); free(ow); free(io); free(it); free(iw);
     if (!g) {
         *err = sqlite3_mprintf("%s: %s", who, mn_graph_last_error());

@@ -199,7 +199,7 @@ static int gc_filter(sqlite3_vtab_cursor *cur, int idxNum, const char *idxStr, i
     if (n > 0) {
         c->comp_id = (int *)malloc((size_t)n * sizeof(int));
         c->comp_size = (int *)malloc((size_t)n * sizeof(int));
-        if (mn_graph_components(n, ne, src, dst, components_mode(ne), 0, c->comp_id, c->comp_size, 0) != 0) {
+        if (mn_graph_components(n, ne, src, dst, components_mode(ne), mn_env_device(), c->comp_id, c->comp_size, 0) != 0) {
             cur->pVtab->zErrMsg = sqlite3_mprintf("graph_components: %s", mn_graph_algo_last_error());
             free(src);
             free(dst);
@@ -271,7 +271,7 @@ static int gpr_filter(sqlite3_vtab_cursor *cur, int idxNum, const char *idxStr, 
     const int n = c->nodes.n;
     if (n > 0) {
         c->rank = (double *)malloc((size_t)n * sizeof(double));
-        if (mn_graph_pagerank(n, ne, src, dst, damping, iterations, 0, c->rank, 0) != 0) {
+        if (mn_graph_pagerank(n, ne, src, dst, damping, iterations, mn_env_device(), c->rank, 0) != 0) {
             cur->pVtab->zErrMsg = sqlite3_mprintf("graph_pagerank: %s", mn_graph_algo_last_error());
             free(src);
             free(dst);

@@ -6,6 +6,15 @@
 #include <string.h>
 #define MN_UNUSED __attribute__((unused))
 
+/* MUNINN_DEVICE=<HIP ordinal> pins this process's extension to one GPU of the node (default 0): with one process per GPU a
+ * host serves independent connections from all of them; the jointly built / sharded multi-GPU modes are the C-ABI's
+ * mn_comm entry points (include/muninn_hip.h "multi-GPU"). */
+MN_UNUSED static int mn_env_device(void) {
+    const char *e = getenv("MUNINN_DEVICE");
+    int d = e ? atoi(e) : 0;
+    return d < 0 ? 0 : d;
+}
+
 /* ───────────────────────── shared: identifiers, string→index map ───────────────────────── */
 
 MN_UNUSED static int ident_ok(const char *s) { /* id_validate, src/id_validate.c:17-28 */

@@ -25,6 +25,7 @@
  */
 #include "../../include/muninn_hip.h"
 #include "mn_sqlite_abi.h"
+#include "mn_nodemap.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -535,7 +536,7 @@ static int x_create(sqlite3 *db, void *aux, int argc, const char *const *argv, s
         *err = sqlite3_mprintf("hnsw_index: failed to create shadow tables");
         return rc;
     }
-    mn_index *ix = mn_hnsw_create(p.dimensions, p.metric, p.m, p.efc);
+    mn_index *ix = mn_hnsw_create_on(p.dimensions, p.metric, p.m, p.efc, mn_env_device());
     if (!ix) {
         *err = sqlite3_mprintf("hnsw_index: failed to allocate index (%s)", mn_last_error());
         return SQLITE_NOMEM;
@@ -568,7 +569,7 @@ static int x_connect(sqlite3 *db, void *aux, int argc, const char *const *argv, 
     rc = sqlite3_declare_vtab(db, SCHEMA);
     if (rc != SQLITE_OK)
         return rc;
-    mn_index *ix = mn_hnsw_create(p.dimensions, p.metric, p.m, p.efc);
+    mn_index *ix = mn_hnsw_create_on(p.dimensions, p.metric, p.m, p.efc, mn_env_device());
     if (!ix) {
         *err = sqlite3_mprintf("hnsw_index: failed to allocate index (%s)", mn_last_error());
         return SQLITE_NOMEM;
