@@ -11,6 +11,7 @@
 #include "mn_graph_oracle.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -138,6 +139,8 @@ static unsigned long long fx_up(double k) {
  * round has movers but no safe winner, the STRICT rule is used instead: v wins iff it is the smallest
  * index among the movers touching old or c (and has no smaller moving neighbour).  Winners are applied
  * in node order.  Returns the number of moves. */
+#define ORC_LEI_GROW 4
+#define ORC_LEI_GROW_DIV 256
 typedef struct {
     int *dec;
     double *dk;
@@ -231,17 +234,33 @@ static int batched_phase(const orc_graph *g, int *label, double *sum_tot, const 
                          int use_both, const int *elig_part, int batch, int max_sweeps, int *scratch, int64_t *n_sweeps) {
     int N = g->n, total = 0, improved = 1, sweeps = 0;
     round_ws ws;
-    ws_init(&ws, N, batch);
+    /* tail rule of the schedule: rounds ORC_LEI_GROW times larger once the sweep before the previous one committed fewer
+     * than N / ORC_LEI_GROW_DIV moves (the device queues a sweep before the previous sweep's count has reached the host) */
+    const int batch0 = batch;
+    int G_ = ORC_LEI_GROW, T_ = ORC_LEI_GROW_DIV;
+    if (getenv("ORC_LEI_GROW")) sscanf(getenv("ORC_LEI_GROW"), "%d,%d", &G_, &T_);
+    long long big = (long long)batch0 * G_;
+    if (big > (N > batch0 ? N : batch0))
+        big = N > batch0 ? N : batch0;
+    int moves_prev = -1, moves_prev2 = -1;
+    ws_init(&ws, N, (int)big);
     while (improved && sweeps < max_sweeps) {
         improved = 0;
         sweeps++;
+        batch = (moves_prev2 >= 0 && moves_prev2 < N / T_) ? (int)big : batch0;
+        int tr_rounds = 0, tr_moves = 0;
         for (int b = 0; b < N; b += batch) {
             int mv = batch_round(g, b, b + batch < N ? b + batch : N, label, sum_tot, k, m, resolution, use_both, elig_part,
                                  scratch, &ws);
             if (mv)
-                improved = 1;
+                improved = 1, tr_rounds++;
             total += mv;
+            tr_moves += mv;
         }
+        if (getenv("ORC_LEIDEN_TRACE"))
+            fprintf(stderr, "sweep %d%s: rounds of %d: %d moves in %d rounds\n", sweeps, elig_part ? " (refine)" : "", batch, tr_moves, tr_rounds);
+        moves_prev2 = moves_prev;
+        moves_prev = tr_moves;
     }
     ws_free(&ws);
     if (n_sweeps)

@@ -275,18 +275,36 @@ DEVI int best_move_sg(const DevGraph &g, int v, const int *label, const double *
 DEVI unsigned lei_hash(int c, int log2h) { return ((unsigned)c * 2654435761u) >> (32 - log2h); }
 
 // SG lanes (lane = absolute lane, sl = lane % SG) evaluate node v; tk/tc/tp: the group's table of H = 1 << log2h entries
+// everything about node v whose address depends on v alone: requested together, one round trip
+struct LeiHead {
+    int o0, d_out, i0, d_in, old, mypart;
+    double k_v;
+};
+DEVI LeiHead lei_head(const DevGraph &g, int v, const int *label, const double *kdeg, int use_both, const int *elig_part) {
+    LeiHead h;
+    const int o0 = g.off_out[v], o1 = g.off_out[v + 1];
+    const int i0 = g.off_in[use_both ? v : 0], i1 = g.off_in[use_both ? v + 1 : 0]; // (unconditional loads)
+    h.old = label[v];
+    h.mypart = (elig_part ? elig_part : label)[v];
+    h.k_v = kdeg[v];
+    h.o0 = o0;
+    h.d_out = o1 - o0;
+    h.i0 = use_both ? i0 : 0;
+    h.d_in = use_both ? i1 - i0 : 0;
+    return h;
+}
+
 template <int SG>
-DEVI int best_move_hash(const DevGraph &g, int v, const int *label, const double *sum_tot, const double *kdeg, double m,
-                        double resolution, int use_both, const int *elig_part, int *tk, int *tc, int *tp, int log2h, int lane,
+DEVI int best_move_hash(const DevGraph &g, const LeiHead &hd, const int *label, const double *sum_tot, double m,
+                        double resolution, const int *elig_part, int *tk, int *tc, int *tp, int log2h, int lane,
                         int sl, double *dk_out) {
     const int H = 1 << log2h;
-    const int o0 = g.off_out[v], d_out = g.off_out[v + 1] - o0;
-    const int i0 = use_both ? g.off_in[v] : 0, d_in = use_both ? g.off_in[v + 1] - i0 : 0;
+    const int o0 = hd.o0, d_out = hd.d_out, i0 = hd.i0, d_in = hd.d_in;
     const int d = d_out + d_in;
-    const int old = label[v];
-    const int mypart = elig_part ? elig_part[v] : 0;
-    // issued now, consumed after the table is built: these round trips overlap the offsets → targets → labels chain
-    const double k_v = kdeg[v];
+    const int old = hd.old;
+    const int mypart = elig_part ? hd.mypart : 0;
+    // issued now, consumed after the table is built: this round trip overlaps the targets → labels chain
+    const double k_v = hd.k_v;
     const double st_old = sum_tot[old];
     for (int j = sl; j < H; j += SG) {
         tk[j] = LEI_EMPTY;
@@ -294,20 +312,46 @@ DEVI int best_move_hash(const DevGraph &g, int v, const int *label, const double
         tp[j] = 0x7fffffff;
     }
     __builtin_amdgcn_wave_barrier();
-    for (int e = sl; e < d; e += SG) {
-        const int t = e < d_out ? g.tgt_out[o0 + e] : g.tgt_in[i0 + (e - d_out)];
-        const int c = label[t];
-        const bool ok = !elig_part || elig_part[t] == mypart;
-        unsigned h = lei_hash(c, log2h);
-        for (;;) {
-            const int prev = atomicCAS(&tk[h], LEI_EMPTY, c);
-            if (prev == LEI_EMPTY || prev == c)
-                break;
-            h = (h + 1) & (H - 1);
+    // Four edges per lane at a time, every load unconditional (index clamped to the last edge): the four targets go out
+    // back to back, then their four labels (and partitions) — two round trips per 4·SG edges instead of two per SG edges.
+    for (int e0 = 0; e0 < d; e0 += 4 * SG) {
+        int t[4], c[4], part[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int ec = min(e0 + j * SG + sl, d - 1);
+            const int *pt = ec < d_out ? g.tgt_out + o0 + ec : g.tgt_in + i0 + (ec - d_out);
+            t[j] = *pt;
         }
-        atomicAdd(&tc[h], 1);
-        if (ok)
-            atomicMin(&tp[h], e);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            c[j] = label[t[j]];
+        if (elig_part) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                part[j] = elig_part[t[j]];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                part[j] = mypart;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int e = e0 + j * SG + sl;
+            if (e >= d)
+                continue;
+            unsigned h = lei_hash(c[j], log2h);
+            for (;;) {
+                int prev = tk[h]; // (a plain read first: most edges find their community already inserted)
+                if (prev == LEI_EMPTY)
+                    prev = atomicCAS(&tk[h], LEI_EMPTY, c[j]);
+                if (prev == LEI_EMPTY || prev == c[j])
+                    break;
+                h = (h + 1) & (H - 1);
+            }
+            atomicAdd(&tc[h], 1);
+            if (part[j] == mypart)
+                atomicMin(&tp[h], e);
+        }
     }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
@@ -327,21 +371,38 @@ DEVI int best_move_hash(const DevGraph &g, int v, const int *label, const double
     }
     double bg = -1.0, bdk = 0.0;
     int bpos = 0x7fffffff, bc = old;
-    for (int j = sl; j < H; j += SG) {
-        const int c = tk[j];
-        const int pos = tp[j];
-        if (c == LEI_EMPTY || c == old || pos == 0x7fffffff)
-            continue;
-        const double sacc = (double)tc[j];
-        const double st_c = sum_tot[c];
-        double gain = (sacc - k_v_to_old) / m + resolution * k_v * (st_old - k_v - st_c) / (2.0 * m * m); // :209-210
-        if (!(gain > 0.0))
-            continue;
-        if (gain > bg || (gain == bg && pos < bpos)) {
-            bg = gain;
-            bpos = pos;
-            bc = c;
-            bdk = sacc - k_v_to_old;
+    // candidates = occupied entries: four per lane at a time, their sum_tot gathers issued together (an entry that is
+    // not a candidate re-reads sum_tot[old])
+    for (int j0 = 0; j0 < H; j0 += 4 * SG) {
+        int c[4], pos[4], cnt[4];
+        double st_c[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int idx = j0 + j * SG + sl;
+            const bool in = idx < H;
+            c[j] = in ? tk[in ? idx : 0] : LEI_EMPTY;
+            pos[j] = in ? tp[in ? idx : 0] : 0x7fffffff;
+            cnt[j] = in ? tc[in ? idx : 0] : 0;
+            if (c[j] == LEI_EMPTY || c[j] == old || pos[j] == 0x7fffffff)
+                c[j] = LEI_EMPTY;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            st_c[j] = sum_tot[c[j] == LEI_EMPTY ? old : c[j]];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (c[j] == LEI_EMPTY)
+                continue;
+            const double sacc = (double)cnt[j];
+            double gain = (sacc - k_v_to_old) / m + resolution * k_v * (st_old - k_v - st_c[j]) / (2.0 * m * m); // :209-210
+            if (!(gain > 0.0))
+                continue;
+            if (gain > bg || (gain == bg && pos[j] < bpos)) {
+                bg = gain;
+                bpos = pos[j];
+                bc = c[j];
+                bdk = sacc - k_v_to_old;
+            }
         }
     }
 #pragma unroll
@@ -379,6 +440,7 @@ struct LeiArgs {
     int b0, b1;
     int *dec, *cmin;
     unsigned char *win;
+    unsigned char *mv;           // [round slot] 1 = the node wants to move (k_leiden_win scans these instead of dec + label)
     double *dk;
     unsigned long long *Jq, *Lq; // fixed-point (2^20) tallies of the movers' degrees per community
     int apply_on_device;         // 0: weighted graph → the host applies winners in node order
@@ -390,6 +452,9 @@ struct LeiArgs {
 };
 
 #define LEI_FX 1048576.0
+#define LEI_GROW 4       // tail rule of the batched schedule: round size factor ...
+#define LEI_GROW_DIV 256 // ... once a sweep commits fewer than N / 256 moves
+#define LEI_GROW_MAX 64  // (upper bound of the MN_LEIDEN_GROW tuning knob; sizes the round buffers)
 DEVI unsigned long long fx_up(double k) { return (unsigned long long)ceil(k * LEI_FX); }
 
 DEVI int node_degree(const LeiArgs &a, int v) {
@@ -439,6 +504,7 @@ __global__ void __launch_bounds__(64) k_leiden_seq(LeiArgs a) {
 DEVI void lei_tally(const LeiArgs &a, int v, int old, int best, double dk) {
     a.dec[v - a.b0] = best;
     a.dk[v - a.b0] = dk;
+    a.mv[v - a.b0] = best != old;
     if (best == old)
         return;
     atomicMin(a.cmin + old, v);
@@ -459,15 +525,22 @@ template <int SG, bool HASH> __global__ void __launch_bounds__(64) k_leiden_eval
     if ((int)blockIdx.x < nsmall) {
         const int grp = lane / SG, sl = lane % SG;
         const int v = a.b0 + blockIdx.x * NG + grp;
-        if (v >= a.b1 || node_degree(a, v) > LEI_SG_CAP)
+        if (v >= a.b1)
             return;
         double dk = 0.0;
-        int best;
+        int best, old;
         if (HASH) {
+            const LeiHead hd = lei_head(a.g, v, a.label, a.kdeg, a.use_both, a.elig_part);
+            if (hd.d_out + hd.d_in > LEI_SG_CAP)
+                return;
+            old = hd.old;
             int *tk = reinterpret_cast<int *>(lei_smem) + grp * 3 * (2 * LEI_SG_CAP);
-            best = best_move_hash<SG>(a.g, v, a.label, a.sum_tot, a.kdeg, a.m, a.resolution, a.use_both, a.elig_part, tk,
-                                      tk + 2 * LEI_SG_CAP, tk + 4 * LEI_SG_CAP, LEI_SG_LOG2H, lane, sl, &dk); // H = 2 * LEI_SG_CAP
+            best = best_move_hash<SG>(a.g, hd, a.label, a.sum_tot, a.m, a.resolution, a.elig_part, tk, tk + 2 * LEI_SG_CAP,
+                                      tk + 4 * LEI_SG_CAP, LEI_SG_LOG2H, lane, sl, &dk); // H = 2 * LEI_SG_CAP
         } else {
+            if (node_degree(a, v) > LEI_SG_CAP)
+                return;
+            old = a.label[v];
             double *lds_w = reinterpret_cast<double *>(lei_smem);
             int *lds_c = reinterpret_cast<int *>(lds_w + NG * LEI_SG_CAP);
             unsigned char *lds_e = reinterpret_cast<unsigned char *>(lds_c + NG * LEI_SG_CAP);
@@ -475,7 +548,7 @@ template <int SG, bool HASH> __global__ void __launch_bounds__(64) k_leiden_eval
                                     lds_c + grp * LEI_SG_CAP, lds_w + grp * LEI_SG_CAP, lds_e + grp * LEI_SG_CAP, lane, sl, &dk);
         }
         if (sl == 0)
-            lei_tally(a, v, a.label[v], best, dk);
+            lei_tally(a, v, old, best, dk);
         return;
     }
     const int bi = blockIdx.x - nsmall;
@@ -488,8 +561,12 @@ template <int SG, bool HASH> __global__ void __launch_bounds__(64) k_leiden_eval
     if (HASH && deg <= a.lds_cap) {
         int *tk = reinterpret_cast<int *>(lei_smem);
         const int H = 1 << a.big_log2h;
-        best = best_move_hash<64>(a.g, v, a.label, a.sum_tot, a.kdeg, a.m, a.resolution, a.use_both, a.elig_part, tk, tk + H,
-                                  tk + 2 * H, a.big_log2h, lane, lane, &dk);
+        const LeiHead hd = lei_head(a.g, v, a.label, a.kdeg, a.use_both, a.elig_part);
+        int lg = 8; // the table is sized to this node (≥ 2 · degree), not to the widest one: less to clear and to scan
+        while ((1 << lg) < 2 * deg)
+            lg++;
+        best = best_move_hash<64>(a.g, hd, a.label, a.sum_tot, a.m, a.resolution, a.elig_part, tk, tk + H, tk + 2 * H, lg, lane,
+                                  lane, &dk);
     } else if (deg <= a.lds_cap) {
         double *lds_w = reinterpret_cast<double *>(lei_smem);
         int *lds_c = reinterpret_cast<int *>(lds_w + a.lds_cap);
@@ -531,15 +608,23 @@ __global__ void __launch_bounds__(256) k_leiden_win(LeiArgs a) {
         const double st_o = a.sum_tot[old], st_b = a.sum_tot[best];
         const int cm_o = a.cmin[old], cm_b = a.cmin[best];
         int blocked = 0;
-        for (int x = xo0 + sl; x < xo1; x += 8) {
-            const int w = a.g.tgt_out[x];
-            if (w >= a.b0 && w < v && a.dec[w - a.b0] != a.label[w])
-                blocked = 1;
-        }
-        for (int x = xi0 + sl; x < xi1; x += 8) {
-            const int w = a.g.tgt_in[x];
-            if (w >= a.b0 && w < v && a.dec[w - a.b0] != a.label[w])
-                blocked = 1;
+        // four targets per lane in flight, then their four mover flags: every load is unconditional (clamped index), so the
+        // compiler issues them back to back instead of one guarded load + wait per edge
+        for (int pass = 0; pass < (a.use_both ? 2 : 1); pass++) {
+            const int *tgt = pass ? a.g.tgt_in : a.g.tgt_out;
+            const int x1 = pass ? xi1 : xo1;
+            for (int x = (pass ? xi0 : xo0) + sl; x < x1; x += 32) {
+                int w[4], f[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    w[j] = tgt[min(x + 8 * j, x1 - 1)]; // (a repeated last edge changes nothing)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const bool inr = w[j] >= a.b0 && w[j] < v;
+                    f[j] = a.mv[inr ? w[j] - a.b0 : 0] & (inr ? 1 : 0);
+                }
+                blocked |= f[0] | f[1] | f[2] | f[3];
+            }
         }
         blocked |= __shfl_xor(blocked, 1);
         blocked |= __shfl_xor(blocked, 2);
@@ -550,38 +635,53 @@ __global__ void __launch_bounds__(256) k_leiden_win(LeiArgs a) {
             const double gain2 = dkv / a.m + a.resolution * k_v * (st_o - Lo - k_v - st_b - Jc) / (2.0 * a.m * a.m);
             const int strict = cm_o == v && cm_b == v;
             win = (unsigned char)((gain2 > 0.0 ? 1 : 0) | (strict ? 2 : 0));
-            if (gain2 > 0.0)
-                atomicAdd(a.out + 1 + a.parity, 1); // safe winners in this round
         }
     }
     if (sl == 0)
         a.win[v - a.b0] = win;
+    // "this round has a safe winner" is a flag, not a count: a plain store (thousands of atomics on one address cost a
+    // mover-heavy round ≈ 10 ns each, even one per wavefront)
+    if (win & 1)
+        a.out[1 + a.parity] = 1;
 }
 
-__global__ void k_leiden_apply(LeiArgs a) {
+// resets the round's tallies and applies its winners
+__global__ void __launch_bounds__(256) k_leiden_apply(LeiArgs a) {
+    __shared__ int blk_moves;
     const int v = a.b0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (threadIdx.x == 0)
+        blk_moves = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0)
-        a.out[1 + (a.parity ^ 1)] = 0; // the next round's counter (this round reads the other one)
-    if (v >= a.b1)
-        return;
-    const int old = a.label[v], best = a.dec[v - a.b0];
-    const unsigned char wbits = a.win[v - a.b0];
-    const int safe = a.out[1 + a.parity];
-    const double k_v = a.kdeg[v];
-    if (best == old)
-        return;
-    a.cmin[old] = 0x7fffffff;
-    a.cmin[best] = 0x7fffffff;
-    a.Lq[old] = 0;
-    a.Jq[best] = 0;
-    const int use_bit = safe > 0 ? 1 : 2;
-    if (a.apply_on_device && (wbits & use_bit)) {
-        // unweighted graph: degrees are integers, f64 atomic adds are exact → order-free
-        atomicAdd(a.sum_tot + old, -k_v);
-        atomicAdd(a.sum_tot + best, k_v);
-        a.label[v] = best;
-        atomicAdd(a.out, 1);
+        a.out[1 + (a.parity ^ 1)] = 0; // the next round's flag (this round reads the other one)
+    __syncthreads();
+    int applied = 0;
+    if (v < a.b1) {
+        const int old = a.label[v], best = a.dec[v - a.b0];
+        const unsigned char wbits = a.win[v - a.b0];
+        const int safe = a.out[1 + a.parity];
+        const double k_v = a.kdeg[v];
+        if (best != old) {
+            a.cmin[old] = 0x7fffffff;
+            a.cmin[best] = 0x7fffffff;
+            a.Lq[old] = 0;
+            a.Jq[best] = 0;
+            const int use_bit = safe > 0 ? 1 : 2;
+            if (a.apply_on_device && (wbits & use_bit)) {
+                // unweighted graph: degrees are integers, f64 atomic adds are exact → order-free
+                atomicAdd(a.sum_tot + old, -k_v);
+                atomicAdd(a.sum_tot + best, k_v);
+                a.label[v] = best;
+                applied = 1;
+            }
+        }
     }
+    // the sweep's move count: one atomic per workgroup
+    const unsigned long long ba = __ballot(applied);
+    if (ba && (threadIdx.x & 63) == __ffsll((long long)ba) - 1)
+        atomicAdd(&blk_moves, __popcll(ba));
+    __syncthreads();
+    if (threadIdx.x == 0 && blk_moves)
+        atomicAdd(a.out, blk_moves);
 }
 
 // host-ordered application for weighted graphs: scatter the changed entries back
@@ -829,7 +929,7 @@ struct LeiWork {
     int n = 0, batch_cap = 0, scratch_slots = 0, scratch_deg = 0, big_mode = -1;
     int *label = nullptr, *refined = nullptr, *out = nullptr, *dec = nullptr, *cmin = nullptr, *sc = nullptr, *sidx = nullptr,
         *sival = nullptr, *first = nullptr, *flag = nullptr, *rank = nullptr, *biglist = nullptr, *counts = nullptr;
-    unsigned char *win = nullptr, *se = nullptr;
+    unsigned char *win = nullptr, *mv = nullptr, *se = nullptr;
     double *sum_tot = nullptr, *kdeg = nullptr, *tmp = nullptr, *sw = nullptr, *dk = nullptr, *sdval = nullptr, *scal = nullptr,
            *s_in = nullptr;
     unsigned long long *Jq = nullptr, *Lq = nullptr;
@@ -839,7 +939,7 @@ struct LeiWork {
     hipEvent_t ev_rd[2] = {nullptr, nullptr};
     std::vector<int> h_big; // nodes with more than LEI_SG_CAP edges (for big_mode = use_both)
     void release() {
-        void *ps[] = {label, refined, out, dec, cmin, sc, sidx, sival, first, flag, rank, biglist, counts, win, se, sum_tot, kdeg,
+        void *ps[] = {label, refined, out, dec, cmin, sc, sidx, sival, first, flag, rank, biglist, counts, win, mv, se, sum_tot, kdeg,
                       tmp, sw, dk, sdval, scal, s_in, Jq, Lq, scan_tmp};
         for (void *q : ps)
             (void)hipFree(q);
@@ -914,7 +1014,7 @@ static int lei_prepare(mn_graph *g, int mode, int batch, int use_both, int max_d
     hipStream_t st = g->stream;
     if (w.n != N) {
         if (wmalloc(&w.label, (size_t)N) || wmalloc(&w.refined, (size_t)N) || wmalloc(&w.sum_tot, (size_t)N) ||
-            wmalloc(&w.kdeg, (size_t)N) || wmalloc(&w.tmp, (size_t)N) || wmalloc(&w.out, 8) || wmalloc(&w.cmin, (size_t)N) ||
+            wmalloc(&w.kdeg, (size_t)N) || wmalloc(&w.tmp, (size_t)N) || wmalloc(&w.out, 16) || wmalloc(&w.cmin, (size_t)N) ||
             wmalloc(&w.Jq, (size_t)N) || wmalloc(&w.Lq, (size_t)N) || wmalloc(&w.first, (size_t)N) || wmalloc(&w.flag, (size_t)N) ||
             wmalloc(&w.rank, (size_t)N) || wmalloc(&w.counts, 8) || wmalloc(&w.scal, 8) || wmalloc(&w.s_in, (size_t)N))
             return -1;
@@ -949,7 +1049,7 @@ static int lei_prepare(mn_graph *g, int mode, int batch, int use_both, int max_d
         w.big_mode = use_both;
     }
     if (mode == MN_LEIDEN_BATCHED && batch > w.batch_cap) {
-        if (wmalloc(&w.dec, (size_t)batch) || wmalloc(&w.dk, (size_t)batch) || wmalloc(&w.win, (size_t)batch) ||
+        if (wmalloc(&w.dec, (size_t)batch) || wmalloc(&w.dk, (size_t)batch) || wmalloc(&w.win, (size_t)batch) || wmalloc(&w.mv, (size_t)batch) ||
             wmalloc(&w.sidx, (size_t)2 * batch + 2) || wmalloc(&w.sival, (size_t)2 * batch + 2) ||
             wmalloc(&w.sdval, (size_t)2 * batch + 2))
             return -1;
@@ -1070,21 +1170,36 @@ static long long run_phase(mn_graph *g, LeiArgs a, int mode, int batch, int64_t 
     const std::vector<int> &big = g->work->h_big;
     long long total = 0;
     int improved = 1, sweeps = 0, parity = 0;
-    std::vector<int> h_dec((size_t)batch), ch_idx, ch_ival, touched;
-    std::vector<unsigned char> h_win((size_t)batch);
+    const size_t round_cap = (size_t)std::min<long long>((long long)batch * LEI_GROW_MAX, std::max(batch, g->n));
+    std::vector<int> h_dec(round_cap), ch_idx, ch_ival, touched;
+    std::vector<unsigned char> h_win(round_cap);
     std::vector<double> ch_dval;
     const bool hashed = !g->weighted; // every weight 1.0 → counts (best_move_hash)
     int sg = (double)(a.use_both ? g->e_out + g->e_in : g->e_out) / std::max(1, g->n) > 48.0 ? 32 : 16;
     if (const char *e = getenv("MN_LEIDEN_SG")) // tuning knob: 16 or 32 lanes per node
         sg = atoi(e) == 16 ? 16 : 32;
-    int *const out_base = a.out; // two counter blocks of 4 ints: sweep s uses block s & 1
+    int *const out_base = a.out; // two counter blocks of 8 ints ([0] moves, [1..2] "has a safe winner" by round parity): sweep s uses block s & 1
     int pending = -1;            // sweep whose move count is still on its way to the host (device-applied moves only)
+    // Tail rule (part of the schedule, restated in oracle/mn_graph_oracle.c batched_phase): once the sweep before the
+    // previous one committed fewer than N / LEI_GROW_DIV moves, rounds are LEI_GROW times larger — few movers, few
+    // conflicts, and a round's cost is mostly its three launches.  "Before the previous one" because the previous sweep's
+    // count is still on its way to the host when this sweep is queued.
+    int grow = LEI_GROW, grow_div = LEI_GROW_DIV;
+    if (const char *e = getenv("MN_LEIDEN_GROW")) // tuning knob "factor,divisor" (results then differ from the oracle's)
+        sscanf(e, "%d,%d", &grow, &grow_div);
+    grow = std::min(std::max(grow, 1), LEI_GROW_MAX);
+    grow_div = std::max(grow_div, 1);
+    const int batch0 = batch;
+    long long moves_prev = -1, moves_prev2 = -1; // sweeps s-1 and s-2 (as far as the host has seen them)
     while (improved && sweeps < a.max_sweeps) {
         improved = 0;
         sweeps++;
+        batch = batch0;
+        if (moves_prev2 >= 0 && moves_prev2 < g->n / grow_div)
+            batch = (int)std::min<long long>((long long)batch0 * grow, std::max(batch0, g->n));
         const int blk = sweeps & 1;
-        a.out = out_base + 4 * blk;
-        GCHK(hipMemsetAsync(a.out, 0, 3 * sizeof(int), st));
+        a.out = out_base + 8 * blk;
+        GCHK(hipMemsetAsync(a.out, 0, 8 * sizeof(int), st));
         parity = 0;
         long long sweep_moves = 0;
         size_t bigpos = 0;
@@ -1164,6 +1279,8 @@ static long long run_phase(mn_graph *g, LeiArgs a, int mode, int batch, int64_t 
                 improved = 1;
                 total += sweep_moves;
             }
+            moves_prev2 = moves_prev;
+            moves_prev = sweep_moves;
             continue;
         }
         // Moves applied on the device: the count of this sweep travels to pinned memory behind the sweep, and the NEXT sweep
@@ -1184,6 +1301,7 @@ static long long run_phase(mn_graph *g, LeiArgs a, int mode, int batch, int64_t 
                 break;
             }
             total += mv;
+            moves_prev2 = mv; // `pending` is the sweep before the one just queued
         }
         pending = sweeps;
     }
@@ -1218,7 +1336,9 @@ extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int
     hipStream_t st = g->stream;
     DevGraph dg = {N, g->off_out, g->tgt_out, g->w_out, g->off_in, g->tgt_in, g->w_in};
     const int max_deg = ((use_both ? g->max_deg_both : g->max_deg_out) + 7) & ~3; // int4-aligned scratch stride
-    if (lei_prepare(g, mode, batch, use_both, max_deg))
+    // buffers hold the largest round of the schedule (run_phase's tail rule)
+    const int round_cap = (int)std::min<long long>((long long)batch * LEI_GROW_MAX, std::max(batch, N));
+    if (lei_prepare(g, mode, mode == MN_LEIDEN_BATCHED ? round_cap : batch, use_both, max_deg))
         return -1;
     LeiWork &d = *g->work;
     const int nbN = (N + 255) / 256;
@@ -1276,6 +1396,7 @@ extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int
     a.dec = d.dec;
     a.cmin = d.cmin;
     a.win = d.win;
+    a.mv = d.mv;
     a.dk = d.dk;
     a.Jq = d.Jq;
     a.Lq = d.Lq;
