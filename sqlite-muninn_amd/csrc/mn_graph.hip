@@ -44,6 +44,8 @@
 #ifndef LEI_SG_CAP
 #define LEI_SG_CAP 64 // sub-group evaluation: edges staged per node (more → the node takes a whole wavefront); power of two
 #endif
+// ints per sub-group: table of 2 * LEI_SG_CAP entries (key, count, first position) + counter (4 ints) + 16-bit slot list
+#define LEI_SG_AREA (6 * LEI_SG_CAP + 4 + LEI_SG_CAP / 2)
 #define LEI_SG_LOG2H (LEI_SG_CAP == 32 ? 6 : LEI_SG_CAP == 64 ? 7 : LEI_SG_CAP == 128 ? 8 : 9) // table of 2 * LEI_SG_CAP entries
 
 struct DevGraph {
@@ -296,7 +298,7 @@ DEVI LeiHead lei_head(const DevGraph &g, int v, const int *label, const double *
 
 template <int SG>
 DEVI int best_move_hash(const DevGraph &g, const LeiHead &hd, const int *label, const double *sum_tot, double m,
-                        double resolution, const int *elig_part, int *tk, int *tc, int *tp, int log2h, int lane,
+                        double resolution, const int *elig_part, int *tk, int *tc, int *tp, int *cl, int log2h, int lane,
                         int sl, double *dk_out) {
     const int H = 1 << log2h;
     const int o0 = hd.o0, d_out = hd.d_out, i0 = hd.i0, d_in = hd.d_in;
@@ -311,6 +313,11 @@ DEVI int best_move_hash(const DevGraph &g, const LeiHead &hd, const int *label, 
         tc[j] = 0;
         tp[j] = 0x7fffffff;
     }
+    // cl[0]: number of occupied entries; then their slots (16-bit), appended by whoever inserts a key — the candidate
+    // scan below visits the occupied entries only (a handful once communities have formed), not the whole table
+    unsigned short *clist = reinterpret_cast<unsigned short *>(cl + 4);
+    if (sl == 0)
+        cl[0] = 0;
     __builtin_amdgcn_wave_barrier();
     // Four edges per lane at a time, every load unconditional (index clamped to the last edge): the four targets go out
     // back to back, then their four labels (and partitions) — two round trips per 4·SG edges instead of two per SG edges.
@@ -342,8 +349,11 @@ DEVI int best_move_hash(const DevGraph &g, const LeiHead &hd, const int *label, 
             unsigned h = lei_hash(c[j], log2h);
             for (;;) {
                 int prev = tk[h]; // (a plain read first: most edges find their community already inserted)
-                if (prev == LEI_EMPTY)
+                if (prev == LEI_EMPTY) {
                     prev = atomicCAS(&tk[h], LEI_EMPTY, c[j]);
+                    if (prev == LEI_EMPTY)
+                        clist[atomicAdd(&cl[0], 1)] = (unsigned short)h;
+                }
                 if (prev == LEI_EMPTY || prev == c[j])
                     break;
                 h = (h + 1) & (H - 1);
@@ -371,38 +381,23 @@ DEVI int best_move_hash(const DevGraph &g, const LeiHead &hd, const int *label, 
     }
     double bg = -1.0, bdk = 0.0;
     int bpos = 0x7fffffff, bc = old;
-    // candidates = occupied entries: four per lane at a time, their sum_tot gathers issued together (an entry that is
-    // not a candidate re-reads sum_tot[old])
-    for (int j0 = 0; j0 < H; j0 += 4 * SG) {
-        int c[4], pos[4], cnt[4];
-        double st_c[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int idx = j0 + j * SG + sl;
-            const bool in = idx < H;
-            c[j] = in ? tk[in ? idx : 0] : LEI_EMPTY;
-            pos[j] = in ? tp[in ? idx : 0] : 0x7fffffff;
-            cnt[j] = in ? tc[in ? idx : 0] : 0;
-            if (c[j] == LEI_EMPTY || c[j] == old || pos[j] == 0x7fffffff)
-                c[j] = LEI_EMPTY;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            st_c[j] = sum_tot[c[j] == LEI_EMPTY ? old : c[j]];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (c[j] == LEI_EMPTY)
-                continue;
-            const double sacc = (double)cnt[j];
-            double gain = (sacc - k_v_to_old) / m + resolution * k_v * (st_old - k_v - st_c[j]) / (2.0 * m * m); // :209-210
-            if (!(gain > 0.0))
-                continue;
-            if (gain > bg || (gain == bg && pos[j] < bpos)) {
-                bg = gain;
-                bpos = pos[j];
-                bc = c[j];
-                bdk = sacc - k_v_to_old;
-            }
+    // candidates = the occupied entries, one per lane per pass (max gain, ties to the lowest first position: any order)
+    const int ncand = cl[0];
+    for (int i = sl; i < ncand; i += SG) {
+        const int slot = clist[i];
+        const int c = tk[slot], pos = tp[slot];
+        if (c == old || pos == 0x7fffffff)
+            continue;
+        const double sacc = (double)tc[slot];
+        const double st_c = sum_tot[c];
+        double gain = (sacc - k_v_to_old) / m + resolution * k_v * (st_old - k_v - st_c) / (2.0 * m * m); // :209-210
+        if (!(gain > 0.0))
+            continue;
+        if (gain > bg || (gain == bg && pos < bpos)) {
+            bg = gain;
+            bpos = pos;
+            bc = c;
+            bdk = sacc - k_v_to_old;
         }
     }
 #pragma unroll
@@ -534,9 +529,9 @@ template <int SG, bool HASH> __global__ void __launch_bounds__(64) k_leiden_eval
             if (hd.d_out + hd.d_in > LEI_SG_CAP)
                 return;
             old = hd.old;
-            int *tk = reinterpret_cast<int *>(lei_smem) + grp * 3 * (2 * LEI_SG_CAP);
+            int *tk = reinterpret_cast<int *>(lei_smem) + grp * LEI_SG_AREA; // H = 2 * LEI_SG_CAP entries
             best = best_move_hash<SG>(a.g, hd, a.label, a.sum_tot, a.m, a.resolution, a.elig_part, tk, tk + 2 * LEI_SG_CAP,
-                                      tk + 4 * LEI_SG_CAP, LEI_SG_LOG2H, lane, sl, &dk); // H = 2 * LEI_SG_CAP
+                                      tk + 4 * LEI_SG_CAP, tk + 6 * LEI_SG_CAP, LEI_SG_LOG2H, lane, sl, &dk);
         } else {
             if (node_degree(a, v) > LEI_SG_CAP)
                 return;
@@ -565,8 +560,8 @@ template <int SG, bool HASH> __global__ void __launch_bounds__(64) k_leiden_eval
         int lg = 8; // the table is sized to this node (≥ 2 · degree), not to the widest one: less to clear and to scan
         while ((1 << lg) < 2 * deg)
             lg++;
-        best = best_move_hash<64>(a.g, hd, a.label, a.sum_tot, a.m, a.resolution, a.elig_part, tk, tk + H, tk + 2 * H, lg, lane,
-                                  lane, &dk);
+        best = best_move_hash<64>(a.g, hd, a.label, a.sum_tot, a.m, a.resolution, a.elig_part, tk, tk + H, tk + 2 * H, tk + 3 * H,
+                                  lg, lane, lane, &dk);
     } else if (deg <= a.lds_cap) {
         double *lds_w = reinterpret_cast<double *>(lei_smem);
         int *lds_c = reinterpret_cast<int *>(lds_w + a.lds_cap);
@@ -585,8 +580,10 @@ template <int SG, bool HASH> __global__ void __launch_bounds__(64) k_leiden_eval
 // LDS bytes of one k_leiden_eval workgroup
 static size_t lei_eval_lds(int sg, bool hash, int lds_cap, int big_log2h) {
     const int ng = 64 / sg;
-    const size_t small = hash ? (size_t)ng * 3 * (2 * LEI_SG_CAP) * sizeof(int) : (size_t)ng * LEI_SG_CAP * 13;
-    const size_t big = hash ? (size_t)3 * ((size_t)1 << big_log2h) * sizeof(int) : (size_t)lds_cap * 13;
+    const size_t small = hash ? (size_t)ng * LEI_SG_AREA * sizeof(int) : (size_t)ng * LEI_SG_CAP * 13;
+    // table (3 ints per entry) + occupied-entry list: a counter (16 B) and one 16-bit slot per edge
+    const size_t big = hash ? (size_t)3 * ((size_t)1 << big_log2h) * sizeof(int) + 16 + (((size_t)lds_cap * 2 + 15) & ~(size_t)15)
+                            : (size_t)lds_cap * 13;
     return small > big ? small : big;
 }
 
