@@ -46,6 +46,7 @@
 #endif
 // ints per sub-group: table of 2 * LEI_SG_CAP entries (key, count, first position) + counter (4 ints) + 16-bit slot list
 #define LEI_SG_AREA (6 * LEI_SG_CAP + 4 + LEI_SG_CAP / 2)
+#define LEI_WPB 4 // wavefronts per k_leiden_eval workgroup (at most; power of two)
 #define LEI_SG_LOG2H (LEI_SG_CAP == 32 ? 6 : LEI_SG_CAP == 64 ? 7 : LEI_SG_CAP == 128 ? 8 : 9) // table of 2 * LEI_SG_CAP entries
 
 struct DevGraph {
@@ -513,13 +514,17 @@ DEVI void lei_tally(const LeiArgs &a, int v, int old, int best, double dk) {
 // than LEI_SG_CAP edges are skipped there), blocks [nsmall, nsmall + big1 - big0) take one such wide node each
 // (biglist).  HASH = unweighted graph → best_move_hash; otherwise the list-order f64 sums of best_move(_sg).
 // Dynamic LDS: max(sub-group area, wide-node area) — sized by the host (lei_eval_lds).
-template <int SG, bool HASH> __global__ void __launch_bounds__(64) k_leiden_eval(LeiArgs a, int nsmall) {
-    extern __shared__ __align__(16) unsigned char lei_smem[];
+template <int SG, bool HASH>
+__global__ void __launch_bounds__(64 * LEI_WPB) k_leiden_eval(LeiArgs a, int nsmall, unsigned wave_lds) {
+    // LEI_WPB independent wavefronts per workgroup (no workgroup barrier anywhere): a quarter of the workgroups to dispatch
+    extern __shared__ __align__(16) unsigned char lei_smem_all[];
+    unsigned char *lei_smem = lei_smem_all + (threadIdx.x >> 6) * wave_lds;
+    const int vblock = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); // the wavefront's index in the launch
     constexpr int NG = 64 / SG;
-    const int lane = threadIdx.x;
-    if ((int)blockIdx.x < nsmall) {
+    const int lane = threadIdx.x & 63;
+    if (vblock < nsmall) {
         const int grp = lane / SG, sl = lane % SG;
-        const int v = a.b0 + blockIdx.x * NG + grp;
+        const int v = a.b0 + vblock * NG + grp;
         if (v >= a.b1)
             return;
         double dk = 0.0;
@@ -546,7 +551,7 @@ template <int SG, bool HASH> __global__ void __launch_bounds__(64) k_leiden_eval
             lei_tally(a, v, old, best, dk);
         return;
     }
-    const int bi = blockIdx.x - nsmall;
+    const int bi = vblock - nsmall;
     if (bi >= a.big1 - a.big0)
         return;
     const int v = a.biglist[a.big0 + bi];
@@ -1211,16 +1216,20 @@ static long long run_phase(mn_graph *g, LeiArgs a, int mode, int batch, int64_t 
             a.big1 = (int)bigpos;
             {
                 const int nsmall = (nb + (64 / sg) - 1) / (64 / sg);
-                const dim3 grid((unsigned)(nsmall + a.big1 - a.big0));
-                const size_t lds = lei_eval_lds(sg, hashed, a.lds_cap, a.big_log2h);
+                const unsigned wlds = (unsigned)((lei_eval_lds(sg, hashed, a.lds_cap, a.big_log2h) + 15) & ~(size_t)15);
+                int wpb = LEI_WPB; // (wide nodes with large tables: fewer wavefronts per workgroup, 64 KB of dynamic LDS at most)
+                while (wpb > 1 && (size_t)wlds * wpb > 60 * 1024)
+                    wpb >>= 1;
+                const dim3 grid((unsigned)((nsmall + a.big1 - a.big0 + wpb - 1) / wpb)), blk(64 * wpb);
+                const size_t lds = (size_t)wlds * wpb;
                 if (sg == 32 && hashed)
-                    hipLaunchKernelGGL((k_leiden_eval<32, true>), grid, dim3(64), lds, st, a, nsmall);
+                    hipLaunchKernelGGL((k_leiden_eval<32, true>), grid, blk, lds, st, a, nsmall, wlds);
                 else if (sg == 32)
-                    hipLaunchKernelGGL((k_leiden_eval<32, false>), grid, dim3(64), lds, st, a, nsmall);
+                    hipLaunchKernelGGL((k_leiden_eval<32, false>), grid, blk, lds, st, a, nsmall, wlds);
                 else if (hashed)
-                    hipLaunchKernelGGL((k_leiden_eval<16, true>), grid, dim3(64), lds, st, a, nsmall);
+                    hipLaunchKernelGGL((k_leiden_eval<16, true>), grid, blk, lds, st, a, nsmall, wlds);
                 else
-                    hipLaunchKernelGGL((k_leiden_eval<16, false>), grid, dim3(64), lds, st, a, nsmall);
+                    hipLaunchKernelGGL((k_leiden_eval<16, false>), grid, blk, lds, st, a, nsmall, wlds);
             }
             hipLaunchKernelGGL(k_leiden_win, dim3((nb * 8 + 255) / 256), dim3(256), 0, st, a);
             ch_idx.clear();
