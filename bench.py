@@ -379,7 +379,23 @@ def main():
     if dist is not None:
         # the exchange itself runs below the C-ABI (mn_comm: RCCL all-gather on the library's stream, or the host transport
         # of the gloo rehearsal); torch.distributed only hands rank 0's RCCL id to the others and provides barriers
-        comm = pkg.parallel.Comm(dev_ord)
+        comm_err = ""
+        try:
+            comm = pkg.parallel.Comm(dev_ord)
+        except Exception as e:  # e.g. librccl cannot be loaded next to torch's: every rank must take the same branch
+            comm, comm_err = None, repr(e)[:200]
+        import torch
+
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            progress(f"mn_comm unavailable on some rank ({comm_err or 'another rank'}): every rank builds its replica alone "
+                     f"(same seed, same graph); the timed search step has no exchange either way")
+            if comm is not None:
+                comm.close()
+            comm, shared_build = None, False
+            if sharded:
+                raise SystemExit("bench.py --mode sharded needs the exchange: " + comm_err)
         dist.barrier()
     t0 = time.perf_counter()
     streamed_build_s = None

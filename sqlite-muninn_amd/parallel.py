@@ -38,10 +38,11 @@ class Comm:
             box = [None]
             if self.rank == 0:
                 buf = C.create_string_buffer(128)
-                if self.L.mn_comm_unique_id(buf) != 0:
-                    raise MuninnHipError((self.L.mn_comm_last_error() or b"").decode())
-                box = [buf.raw]
+                # (a failure is broadcast too: the other ranks are already waiting in the rendezvous below)
+                box = [buf.raw if self.L.mn_comm_unique_id(buf) == 0 else (self.L.mn_comm_last_error() or b"?").decode()]
             dist.broadcast_object_list(box, src=0, group=group)  # rendezvous only: 128 bytes
+            if not isinstance(box[0], bytes):
+                raise MuninnHipError(f"mn_comm_unique_id failed on rank 0: {box[0]}")
             self._id = C.create_string_buffer(box[0], 128)
             self.h = self.L.mn_comm_init_rccl(self.world, self.rank, self._id, device)
             self._cb = None
