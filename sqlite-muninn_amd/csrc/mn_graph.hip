@@ -442,6 +442,7 @@ struct LeiArgs {
     int apply_on_device;         // 0: weighted graph → the host applies winners in node order
     int lds_cap;                 // k_leiden_eval_big: edges staged in LDS per node (multiple of 16, ≤ LEI_CAP)
     const int *biglist;          // nodes with more than LEI_SG_CAP edges, ascending
+    const long long *bigoff;     // [biglist index] offset of the node's region in scratch_c/w/e (nodes with more than LEI_CAP edges)
     int big0, big1;              // the slice of biglist inside [b0, b1)
     int parity;                  // round parity: out[1 + parity] counts this round's safe winners
     int big_log2h;               // hash table size of a wide node (unweighted): 2^big_log2h >= 2 * lds_cap
@@ -574,7 +575,7 @@ __global__ void __launch_bounds__(64 * LEI_WPB) k_leiden_eval(LeiArgs a, int nsm
         best = best_move<false>(a.g, v, a.label, a.sum_tot, a.kdeg, a.m, a.resolution, a.use_both, a.elig_part, lds_c, lds_w,
                                 lds_e, lane, &dk);
     } else { // more edges than fit in LDS: global scratch, list-order sums
-        const size_t o = (size_t)bi * a.max_deg;
+        const size_t o = (size_t)a.bigoff[a.big0 + bi]; // this node's own region (only nodes past LEI_CAP have one)
         best = best_move<false>(a.g, v, a.label, a.sum_tot, a.kdeg, a.m, a.resolution, a.use_both, a.elig_part, a.scratch_c + o,
                                 a.scratch_w + o, a.scratch_e + o, lane, &dk);
     }
@@ -928,13 +929,15 @@ extern "C" mn_graph *mn_graph_create_blocked(int n_nodes, const mn_csr_block *fw
 // ───────────────────────── run_leiden workspace (one per graph, reused) ─────────────────────────
 
 struct LeiWork {
-    int n = 0, batch_cap = 0, scratch_slots = 0, scratch_deg = 0, big_mode = -1;
+    int n = 0, batch_cap = 0, big_mode = -1;
     int *label = nullptr, *refined = nullptr, *out = nullptr, *dec = nullptr, *cmin = nullptr, *sc = nullptr, *sidx = nullptr,
         *sival = nullptr, *first = nullptr, *flag = nullptr, *rank = nullptr, *biglist = nullptr, *counts = nullptr;
     unsigned char *win = nullptr, *mv = nullptr, *se = nullptr;
     double *sum_tot = nullptr, *kdeg = nullptr, *tmp = nullptr, *sw = nullptr, *dk = nullptr, *sdval = nullptr, *scal = nullptr,
            *s_in = nullptr;
     unsigned long long *Jq = nullptr, *Lq = nullptr;
+    long long *bigoff = nullptr;
+    size_t scratch_need = 0, scratch_have = 0; // entries: one region per node with more than LEI_CAP edges
     void *scan_tmp = nullptr;
     size_t scan_bytes = 0;
     int *h_out = nullptr;          // pinned: per-sweep move counts read back without stalling the launch queue
@@ -942,7 +945,7 @@ struct LeiWork {
     std::vector<int> h_big; // nodes with more than LEI_SG_CAP edges (for big_mode = use_both)
     void release() {
         void *ps[] = {label, refined, out, dec, cmin, sc, sidx, sival, first, flag, rank, biglist, counts, win, mv, se, sum_tot, kdeg,
-                      tmp, sw, dk, sdval, scal, s_in, Jq, Lq, scan_tmp};
+                      tmp, sw, dk, sdval, scal, s_in, Jq, Lq, scan_tmp, bigoff};
         for (void *q : ps)
             (void)hipFree(q);
         if (h_out)
@@ -1039,15 +1042,25 @@ static int lei_prepare(mn_graph *g, int mode, int batch, int use_both, int max_d
     GCHK(hipMemsetAsync(w.Lq, 0, (size_t)N * sizeof(unsigned long long), st));
     if (w.big_mode != use_both) { // nodes the sub-group kernel leaves to the one-wavefront-per-node kernel
         w.h_big.clear();
+        std::vector<long long> h_off;
+        size_t need = 0; // scratch entries: Σ degree (int4-aligned) over the nodes that do not fit in LDS — at most 2E + 4N
         for (int v = 0; v < N; v++) {
             const int d = g->h_off_out[v + 1] - g->h_off_out[v] + (use_both ? g->h_off_in[v + 1] - g->h_off_in[v] : 0);
-            if (d > LEI_SG_CAP)
+            if (d > LEI_SG_CAP) {
                 w.h_big.push_back(v);
+                h_off.push_back((long long)need);
+                if (d > LEI_CAP)
+                    need += ((size_t)d + 7) & ~(size_t)3;
+            }
         }
-        if (wmalloc(&w.biglist, w.h_big.size()))
+        w.scratch_need = need;
+        if (wmalloc(&w.biglist, w.h_big.size()) || wmalloc(&w.bigoff, w.h_big.size()))
             return -1;
-        if (!w.h_big.empty())
+        if (!w.h_big.empty()) {
             GCHK(hipMemcpyAsync(w.biglist, w.h_big.data(), w.h_big.size() * sizeof(int), hipMemcpyHostToDevice, st));
+            GCHK(hipMemcpyAsync(w.bigoff, h_off.data(), h_off.size() * sizeof(long long), hipMemcpyHostToDevice, st));
+            GCHK(hipStreamSynchronize(st)); // (h_off is a local)
+        }
         w.big_mode = use_both;
     }
     if (mode == MN_LEIDEN_BATCHED && batch > w.batch_cap) {
@@ -1057,13 +1070,13 @@ static int lei_prepare(mn_graph *g, int mode, int batch, int use_both, int max_d
             return -1;
         w.batch_cap = batch;
     }
-    const int nslots = mode == MN_LEIDEN_SEQUENTIAL ? 1 : batch;
-    if (max_deg > LEI_CAP && (nslots > w.scratch_slots || max_deg > w.scratch_deg)) {
-        if (wmalloc(&w.sc, (size_t)nslots * max_deg) || wmalloc(&w.sw, (size_t)nslots * max_deg) ||
-            wmalloc(&w.se, (size_t)nslots * max_deg))
+    // global scratch for nodes whose edges do not fit in LDS: the sequential kernel reuses one region of max_deg entries,
+    // the batched rounds give every such node its own (bigoff) — sized by those nodes' degrees, not by the round
+    const size_t want = std::max<size_t>(w.scratch_need, (size_t)max_deg);
+    if (max_deg > LEI_CAP && want > w.scratch_have) {
+        if (wmalloc(&w.sc, want) || wmalloc(&w.sw, want) || wmalloc(&w.se, want))
             return -1;
-        w.scratch_slots = nslots;
-        w.scratch_deg = max_deg;
+        w.scratch_have = want;
     }
     return 0;
 }
@@ -1412,6 +1425,7 @@ extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int
     while ((1 << a.big_log2h) < 2 * a.lds_cap)
         a.big_log2h++;
     a.biglist = d.biglist;
+    a.bigoff = d.bigoff;
     HostState hs = {&community, &sum_tot, &k, d.sidx, d.sival, d.sdval};
 
     for (int iter = 0; iter < 100; iter++) { // :368-417

@@ -104,7 +104,11 @@ def test_gpu_high_degree_nodes_use_global_scratch(gpu):
     hub_s = np.zeros(n - 1, np.int32)
     hub_d = np.arange(1, n, dtype=np.int32)
     s2, d2, _ = er(n, 6000, 9)
-    s, d = np.concatenate([hub_s, s2]), np.concatenate([hub_d, d2])
+    # two more hubs, one in the first hub's round and one in a later round: each has its own scratch region
+    h1_d = np.arange(2, 1502, dtype=np.int32)
+    h2_d = np.arange(100, 1300, dtype=np.int32)
+    s = np.concatenate([hub_s, s2, np.full(len(h1_d), 1, np.int32), np.full(len(h2_d), 2500, np.int32)])
+    d = np.concatenate([hub_d, d2, h1_d, h2_d])
     csr = og.Csr(s, d, None, "both")
     oc, oq, _ = og.leiden(csr, 1.0, 1)
     g = _dev_graph(gpu, csr)
