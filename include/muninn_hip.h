@@ -375,6 +375,30 @@ int mn_hnsw_search_sharded(mn_index *idx, mn_comm *c, const float *queries, int6
 int mn_node2vec_train_shared(mn_comm *c, int n_nodes, const int *off, const int *adj, const mn_n2v_params *prm, int device,
                              float *out, mn_n2v_stats *stats);
 
+/* ---- the same sharded index (BASELINE config 3) inside ONE process: a C host that owns several GPUs ----
+ * rowid mod n -> shard; every shard is an ordinary mn_index on its own GPU (mn_shards_index gives access for persistence:
+ * mn_hnsw_take_dirty etc.).  A search uploads the queries to every shard's GPU, searches all shards at once (one stream
+ * per GPU, queued by the calling thread), copies the per-shard top-k to the first shard's GPU (hipMemcpyPeerAsync) and
+ * merges there with the kernel mn_hnsw_search_sharded uses — the same result, bit for bit, as one rank per GPU over RCCL.
+ * devices may repeat an ordinal (several shards on one GPU).  What a loadable extension would bind for
+ * MUNINN_DEVICE=0,1,...: hnsw_vtab.c's hnsw_insert / hnsw_search / hnsw_delete call sites (src/hnsw_vtab.c:748, :604,
+ * :698) take these instead of the single-index calls.  Errors: mn_shards_last_error(). */
+typedef struct mn_shards mn_shards;
+mn_shards *mn_shards_create(int dim, int metric, int M, int ef_construction, const int *devices, int n);
+void mn_shards_destroy(mn_shards *s);
+int mn_shards_count(const mn_shards *s);
+mn_index *mn_shards_index(mn_shards *s, int i);
+int mn_shards_of(const mn_shards *s, int64_t id); /* ((id mod n) + n) mod n */
+int mn_shards_set_order(mn_shards *s, int order);
+int mn_shards_insert(mn_shards *s, int64_t id, const float *vector);   /* hnsw_insert on the id's shard */
+int mn_shards_delete(mn_shards *s, int64_t id);                         /* hnsw_delete on the id's shard */
+/* mn_hnsw_build per shard (input order kept inside every shard), the shards built side by side: one host thread per GPU */
+int mn_shards_build(mn_shards *s, const int64_t *ids, const float *vectors, int64_t n, int grow_div, int max_batch);
+int mn_shards_search(mn_shards *s, const float *query, int k, int ef_search, mn_search_result *results);
+int mn_shards_search_batch(mn_shards *s, const float *queries, int64_t nq, int k, int ef_search, int64_t *out_ids,
+                           float *out_dists, int *out_counts);
+const char *mn_shards_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,7 +8,7 @@ The directory name contains a hyphen (it is the project name); import it through
 ``muninn_amd.py`` at the repository root, which registers it as ``sqlite_muninn_amd``.
 """
 from .build import LIB, build  # noqa: F401
-from .hnsw import (BUILD_BATCHED, BUILD_SEQUENTIAL, METRIC, ORDER_SSE, ORDER_WAVE, HnswIndex, MuninnHipError,  # noqa: F401
+from .hnsw import (BUILD_BATCHED, BUILD_SEQUENTIAL, METRIC, ORDER_SSE, ORDER_WAVE, HnswIndex, MuninnHipError, ShardedIndex,  # noqa: F401
                    device_count, lib, vec_dist_batch, vec_parse_metric)
 from . import graph  # noqa: E402,F401
 from .graph import LEIDEN_BATCHED, LEIDEN_SEQUENTIAL, N2V_BATCHED, N2V_SEQUENTIAL, Graph, node2vec_train  # noqa: E402,F401

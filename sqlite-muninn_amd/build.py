@@ -9,7 +9,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmuninn_hip.so")
-SOURCES = ["mn_kernels.hip", "mn_build.hip", "mn_seq.hip", "mn_spec.hip", "mn_index.hip", "mn_brute.hip", "mn_graph.hip", "mn_n2v.hip", "mn_comm.hip", "mn_graph_algo.hip"]
+SOURCES = ["mn_kernels.hip", "mn_build.hip", "mn_seq.hip", "mn_spec.hip", "mn_index.hip", "mn_brute.hip", "mn_graph.hip", "mn_n2v.hip", "mn_comm.hip", "mn_shards.hip", "mn_graph_algo.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join("..", "..", "include", "muninn_hip.h")]
 # -ffp-contract=off: the reference's distance loops use separate mul/add (src/vec_math.c:85,106);
 # the wave-order kernels call fmaf explicitly where fusion is intended.

@@ -102,6 +102,19 @@ SYMBOLS = [
     ("mn_hnsw_search_sharded_dev", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p,
                                              C.c_void_p, C.c_void_p]),
     ("mn_hnsw_search_sharded", C.c_int, [C.c_void_p, C.c_void_p, _f32p, C.c_int64, C.c_int, C.c_int, _i64p, _f32p, _i32p]),
+    # the sharded index inside one process
+    ("mn_shards_create", C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_int, _i32p, C.c_int]),
+    ("mn_shards_destroy", None, [C.c_void_p]),
+    ("mn_shards_count", C.c_int, [C.c_void_p]),
+    ("mn_shards_index", C.c_void_p, [C.c_void_p, C.c_int]),
+    ("mn_shards_of", C.c_int, [C.c_void_p, C.c_int64]),
+    ("mn_shards_set_order", C.c_int, [C.c_void_p, C.c_int]),
+    ("mn_shards_insert", C.c_int, [C.c_void_p, C.c_int64, _f32p]),
+    ("mn_shards_delete", C.c_int, [C.c_void_p, C.c_int64]),
+    ("mn_shards_build", C.c_int, [C.c_void_p, _i64p, _f32p, C.c_int64, C.c_int, C.c_int]),
+    ("mn_shards_search", C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_void_p]),
+    ("mn_shards_search_batch", C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, C.c_int, _i64p, _f32p, _i32p]),
+    ("mn_shards_last_error", C.c_char_p, []),
 ]
 
 _lib = None
@@ -146,6 +159,59 @@ def vec_dist_batch(metric: str, query, rows, order: int = ORDER_SSE) -> np.ndarr
     if lib().mn_vec_dist_batch(METRIC[metric], order, q, r, r.shape[0], q.shape[0], out) != 0:
         raise MuninnHipError(_err())
     return out
+
+
+class ShardedIndex:
+    """BASELINE config 3 inside one process (mn_shards_*): rowid mod n -> one HNSW graph per entry of `devices`."""
+
+    def __init__(self, dim, metric="cosine", M=16, ef_construction=200, devices=(0,), order=ORDER_SSE):
+        self.L = lib()
+        self.dim = dim
+        dv = np.ascontiguousarray(devices, np.int32)
+        self.h = self.L.mn_shards_create(dim, METRIC[metric] if isinstance(metric, str) else metric, M, ef_construction, dv,
+                                         len(dv))
+        if not self.h:
+            raise MuninnHipError("mn_shards_create failed: " + self._err())
+        if order != ORDER_SSE and self.L.mn_shards_set_order(self.h, order) != 0:
+            raise MuninnHipError(self._err())
+
+    def _err(self):
+        return (self.L.mn_shards_last_error() or b"").decode()
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mn_shards_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def insert(self, id, vec) -> int:
+        return self.L.mn_shards_insert(self.h, int(id), np.ascontiguousarray(vec, np.float32))
+
+    def delete(self, id) -> int:
+        return self.L.mn_shards_delete(self.h, int(id))
+
+    def build(self, ids, vectors, grow_div=16, max_batch=8192) -> int:
+        ids = np.ascontiguousarray(ids, np.int64)
+        vectors = np.ascontiguousarray(vectors, np.float32).reshape(len(ids), self.dim)
+        return self.L.mn_shards_build(self.h, ids, vectors, len(ids), grow_div, max_batch)
+
+    def search(self, q, k, ef):
+        r = (_Result * max(k, 1))()
+        n = self.L.mn_shards_search(self.h, np.ascontiguousarray(q, np.float32), k, ef, r)
+        if n < 0:
+            raise MuninnHipError(self._err())
+        return (np.array([r[i].id for i in range(n)], np.int64), np.array([r[i].distance for i in range(n)], np.float32))
+
+    def search_batch(self, Q, k, ef):
+        Q = np.ascontiguousarray(Q, np.float32).reshape(-1, self.dim)
+        nq = len(Q)
+        ids = np.full((nq, k), -1, np.int64)
+        ds = np.zeros((nq, k), np.float32)
+        cnt = np.zeros(nq, np.int32)
+        if self.L.mn_shards_search_batch(self.h, Q, nq, k, ef, ids, ds, cnt) != 0:
+            raise MuninnHipError(self._err())
+        return ids, ds, cnt
 
 
 class HnswIndex:

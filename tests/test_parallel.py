@@ -347,3 +347,92 @@ def test_rccl_transport_single_rank(gpu):
     a.close()
     b.close()
     L.mn_comm_destroy(c)
+
+
+def _oracle_sharded(orc, shards, Q, k, ef):
+    """the reference per shard + the merge in the total order (distance, shard, position)"""
+    world = len(shards)
+    per = [o.search_many(Q, k, ef) for o in shards]
+    wi = np.full((len(Q), k), -1, np.int64)
+    wd = np.zeros((len(Q), k), np.float32)
+    wc = np.zeros(len(Q), np.int32)
+    for qi in range(len(Q)):
+        cand = [(per[r][1][qi][p], r, p, per[r][0][qi][p]) for r in range(world) for p in range(per[r][2][qi])]
+        cand.sort(key=lambda t: (t[0], t[1], t[2]))
+        for p, c in enumerate(cand[:k]):
+            wi[qi, p], wd[qi, p] = c[3], c[0]
+        wc[qi] = min(k, len(cand))
+    return wi, wd, wc
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nshards", [1, 2, 3])
+def test_config3_in_one_process_equals_the_reference_built_per_shard(gpu, orc, nshards):
+    """mn_shards_*: the sharded index of config 3 driven by ONE host process (what a C host owning several GPUs binds).
+    One box has one GPU, so the shards share ordinal 0 — streams, peer copies and the merge kernel are the ones N GPUs
+    use.  Expected = the oracle (= the reference, pinned) built once per shard by exact inserts + the merge; ids and
+    distance bits, before and after deletes and further inserts; negative rowids land on ((id mod n) + n) mod n."""
+    n, d, k = 1500, 16, 10
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((n, d), dtype=np.float32)
+    X[7] = X[6]
+    ids = np.arange(n, dtype=np.int64) - 200  # negative rowids too
+    Q = rng.standard_normal((48, d), dtype=np.float32)
+    Q[0] = X[6]
+    sh = gpu.ShardedIndex(d, "l2", 8, 60, devices=[0] * nshards)
+    oracles = [orc.Oracle(d, "l2", 8, 60) for _ in range(nshards)]
+    for i in range(n):  # exact inserts: hnsw_insert on the id's shard
+        r = int(((ids[i] % nshards) + nshards) % nshards)
+        assert gpu.lib().mn_shards_of(sh.h, int(ids[i])) == r
+        assert sh.insert(ids[i], X[i]) == 0
+        assert oracles[r].insert(int(ids[i]), X[i]) == 0
+    for ef in (10, 80):
+        gi, gd, gc = sh.search_batch(Q, k, ef)
+        wi, wd, wc = _oracle_sharded(orc, oracles, Q, k, ef)
+        assert np.array_equal(gi, wi) and np.array_equal(gd.view(np.int32), wd.view(np.int32)) and np.array_equal(gc, wc), ef
+    for i in rng.choice(n, 300, replace=False):
+        r = int(((ids[i] % nshards) + nshards) % nshards)
+        assert sh.delete(ids[i]) == 0 and oracles[r].delete(int(ids[i])) == 0
+    assert sh.delete(10**9) == -1  # absent
+    X2 = rng.standard_normal((200, d), dtype=np.float32)
+    for j in range(200):
+        nid = int(n + 1000 + j)
+        assert sh.insert(nid, X2[j]) == 0 and oracles[nid % nshards].insert(nid, X2[j]) == 0
+    gi, gd, gc = sh.search_batch(Q, k, 64)
+    wi, wd, wc = _oracle_sharded(orc, oracles, Q, k, 64)
+    assert np.array_equal(gi, wi) and np.array_equal(gd.view(np.int32), wd.view(np.int32)) and np.array_equal(gc, wc)
+    one_i, one_d = sh.search(Q[3], k, 64)  # the single-query entry (one xFilter): the same list
+    assert np.array_equal(one_i, wi[3][: wc[3]]) and np.array_equal(one_d.view(np.int32), wd[3][: wc[3]].view(np.int32))
+    sh.close()
+
+
+@pytest.mark.gpu
+def test_in_process_shards_bulk_build_searches_every_shard(gpu):
+    """mn_shards_build: the shards are built side by side (one host thread per shard, batch-synchronous build) and a
+    search returns exactly what each shard's own index returns, merged; near-exact recall on an easy set."""
+    n, d, k, ns = 20000, 32, 10, 4
+    rng = np.random.default_rng(11)
+    X = rng.standard_normal((n, d), dtype=np.float32)
+    ids = np.arange(1, n + 1, dtype=np.int64)
+    Q = X[rng.choice(n, 64, replace=False)] + 0.01 * rng.standard_normal((64, d), dtype=np.float32)
+    sh = gpu.ShardedIndex(d, "l2", 16, 100, devices=[0] * ns)
+    assert sh.build(ids, X) == 0, sh._err()
+    gi, gd, gc = sh.search_batch(Q, k, 200)
+    # the same shards built one by one with the single-index entry point give the same lists → same merged result
+    per = []
+    for r in range(ns):
+        g = gpu.HnswIndex(d, "l2", 16, 100)
+        m = ids % ns == r
+        assert g.build(ids[m], X[m]) == 0
+        per.append(g.search_batch(Q, k, 200))
+        g.close()
+    for qi in range(len(Q)):
+        cand = [(per[r][1][qi][p], r, p, per[r][0][qi][p]) for r in range(ns) for p in range(per[r][2][qi])]
+        cand.sort(key=lambda t: (t[0], t[1], t[2]))
+        assert [c[3] for c in cand[:k]] == gi[qi].tolist()
+        assert np.array_equal(np.array([c[0] for c in cand[:k]], np.float32).view(np.int32), gd[qi].view(np.int32))
+    D = ((Q[:, None, :] - X[None, :, :]) ** 2).sum(2)
+    truth = np.argsort(D, axis=1, kind="stable")[:, :k] + 1
+    assert np.mean([len(set(gi[i]) & set(truth[i])) / k for i in range(len(Q))]) >= 0.97
+    assert (gc == k).all()
+    sh.close()
