@@ -451,7 +451,7 @@ struct LeiArgs {
 #define LEI_FX 1048576.0
 #define LEI_GROW 4       // tail rule of the batched schedule: round size factor ...
 #define LEI_GROW_DIV 256 // ... once a sweep commits fewer than N / 256 moves
-#define LEI_GROW_MAX 64  // (upper bound of the MN_LEIDEN_GROW tuning knob; sizes the round buffers)
+#define LEI_GROW_MAX 64  // (upper bound of the MN_LEIDEN_GROW tuning knob)
 DEVI unsigned long long fx_up(double k) { return (unsigned long long)ceil(k * LEI_FX); }
 
 DEVI int node_degree(const LeiArgs &a, int v) {
@@ -1165,6 +1165,17 @@ struct HostState {
     double *d_sdval;
 };
 
+// the tail rule's constants; MN_LEIDEN_GROW="factor,divisor" is a tuning knob (the oracle reads ORC_LEI_GROW the same way:
+// other values give another — equally valid — schedule, so parity holds only when both sides are set alike)
+static void lei_grow_setting(int *grow, int *grow_div) {
+    *grow = LEI_GROW;
+    *grow_div = LEI_GROW_DIV;
+    if (const char *e = getenv("MN_LEIDEN_GROW"))
+        sscanf(e, "%d,%d", grow, grow_div);
+    *grow = std::min(std::max(*grow, 1), LEI_GROW_MAX);
+    *grow_div = std::max(*grow_div, 1);
+}
+
 // one phase (local moving when elig_part == nullptr, refinement otherwise); returns moves, -1 on error
 static long long run_phase(mn_graph *g, LeiArgs a, int mode, int batch, int64_t *sweeps_out, HostState *hs) {
     hipStream_t st = g->stream;
@@ -1185,7 +1196,9 @@ static long long run_phase(mn_graph *g, LeiArgs a, int mode, int batch, int64_t 
     const std::vector<int> &big = g->work->h_big;
     long long total = 0;
     int improved = 1, sweeps = 0, parity = 0;
-    const size_t round_cap = (size_t)std::min<long long>((long long)batch * LEI_GROW_MAX, std::max(batch, g->n));
+    int grow_cap, div_unused;
+    lei_grow_setting(&grow_cap, &div_unused);
+    const size_t round_cap = (size_t)std::min<long long>((long long)batch * grow_cap, std::max(batch, g->n));
     std::vector<int> h_dec(round_cap), ch_idx, ch_ival, touched;
     std::vector<unsigned char> h_win(round_cap);
     std::vector<double> ch_dval;
@@ -1199,11 +1212,8 @@ static long long run_phase(mn_graph *g, LeiArgs a, int mode, int batch, int64_t 
     // previous one committed fewer than N / LEI_GROW_DIV moves, rounds are LEI_GROW times larger — few movers, few
     // conflicts, and a round's cost is mostly its three launches.  "Before the previous one" because the previous sweep's
     // count is still on its way to the host when this sweep is queued.
-    int grow = LEI_GROW, grow_div = LEI_GROW_DIV;
-    if (const char *e = getenv("MN_LEIDEN_GROW")) // tuning knob "factor,divisor" (results then differ from the oracle's)
-        sscanf(e, "%d,%d", &grow, &grow_div);
-    grow = std::min(std::max(grow, 1), LEI_GROW_MAX);
-    grow_div = std::max(grow_div, 1);
+    int grow, grow_div;
+    lei_grow_setting(&grow, &grow_div);
     const int batch0 = batch;
     long long moves_prev = -1, moves_prev2 = -1; // sweeps s-1 and s-2 (as far as the host has seen them)
     while (improved && sweeps < a.max_sweeps) {
@@ -1356,7 +1366,9 @@ extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int
     DevGraph dg = {N, g->off_out, g->tgt_out, g->w_out, g->off_in, g->tgt_in, g->w_in};
     const int max_deg = ((use_both ? g->max_deg_both : g->max_deg_out) + 7) & ~3; // int4-aligned scratch stride
     // buffers hold the largest round of the schedule (run_phase's tail rule)
-    const int round_cap = (int)std::min<long long>((long long)batch * LEI_GROW_MAX, std::max(batch, N));
+    int grow_cap, div_unused;
+    lei_grow_setting(&grow_cap, &div_unused);
+    const int round_cap = (int)std::min<long long>((long long)batch * grow_cap, std::max(batch, N));
     if (lei_prepare(g, mode, mode == MN_LEIDEN_BATCHED ? round_cap : batch, use_both, max_deg))
         return -1;
     LeiWork &d = *g->work;
