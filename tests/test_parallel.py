@@ -436,3 +436,50 @@ def test_in_process_shards_bulk_build_searches_every_shard(gpu):
     assert np.mean([len(set(gi[i]) & set(truth[i])) / k for i in range(len(Q))]) >= 0.97
     assert (gc == k).all()
     sh.close()
+
+
+_NCCL_COEXIST = r"""
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))   # torch's own RCCL communicator first, as bench.py does
+t = torch.ones(4, device="cuda"); dist.all_reduce(t)                 # ... and used
+sys.path.insert(0, os.environ["MN_ROOT"])
+import muninn_amd
+pkg = muninn_amd.pkg
+comm = pkg.parallel.Comm(0)                                          # mn_comm: id via broadcast_object_list, ncclCommInitRank
+n, d = 6000, 24
+X = np.random.default_rng(1).standard_normal((n, d), dtype=np.float32)
+ids = np.arange(1, n + 1, dtype=np.int64)
+Q = np.random.default_rng(2).standard_normal((50, d), dtype=np.float32)
+a = pkg.HnswIndex(d, "cosine", 8, 60); b = pkg.HnswIndex(d, "cosine", 8, 60)
+pkg.parallel.build_distributed(a, ids, X, 16, 1024, comm=comm)       # all-gathers through ncclAllGather on the index's stream
+assert b.build(ids, X, 16, 1024) == 0
+assert a.graph(ids) == b.graph(ids)
+si, sd, sc = pkg.parallel.search_sharded(a, comm, Q, 10, 64)
+pi, pd, pc = b.search_batch(Q, 10, 64)
+assert np.array_equal(si, pi) and np.array_equal(sd.view(np.int32), pd.view(np.int32)) and np.array_equal(sc, pc)
+off = np.arange(0, 2 * 400 + 1, 2, dtype=np.int32); adj = np.stack([(np.arange(400) + 1) % 400, (np.arange(400) - 1) % 400], 1).astype(np.int32).ravel()
+e1, st1 = pkg.parallel.node2vec_train_distributed(off, adj, 16, num_walks=2, walk_length=10, device=0, comm=comm)
+e2, st2 = pkg.graph.node2vec_train(off, adj, 16, num_walks=2, walk_length=10, mode=pkg.N2V_BATCHED)
+assert np.array_equal(e1.view(np.int32), e2.view(np.int32))
+t2 = torch.ones(4, device="cuda"); dist.all_reduce(t2)               # torch's communicator still works afterwards
+comm.close(); dist.destroy_process_group()
+print("NCCL_COEXIST_OK")
+"""
+
+
+@pytest.mark.gpu
+def test_mn_comm_next_to_torchs_own_rccl_communicator(gpu):
+    """bench.py's N > 1 flow inside one process of world 1 (all one GPU allows): torch.distributed's RCCL process group is
+    created and used first, then mn_comm creates its own communicator from an id sent with broadcast_object_list, and
+    the shared build, the sharded search and the data-parallel Node2Vec run their all-gathers through it — same results
+    as the single-GPU entry points, and torch's communicator is still usable afterwards."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               MN_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _NCCL_COEXIST], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "NCCL_COEXIST_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
