@@ -277,7 +277,9 @@ const char *mn_node2vec_last_error(void);
 /* The batched schedule as a session, so that several GPUs can share one training run: every rank produces the
  * samples of its slice of a batch's walks, the (centre, target, err) triples are exchanged (RCCL all-gather, rank
  * order = walk order) and every replica applies the whole batch — the N-GPU embeddings are bit-identical to the
- * 1-GPU ones.  Buffers passed to samples/apply are DEVICE pointers on the session's device. */
+ * 1-GPU ones.  Buffers passed to samples/apply are DEVICE pointers on the session's device; both calls are queued on the
+ * session's own stream (in call order) and return at once — mn_n2v_sync before another stream or the host touches the
+ * buffers. */
 typedef struct mn_n2v_session mn_n2v_session;
 mn_n2v_session *mn_n2v_begin(int n_nodes, const int *off, const int *adj, const mn_n2v_params *prm, int device);
 int mn_n2v_batch_walks(mn_n2v_session *s);  /* resolved walks per batch */

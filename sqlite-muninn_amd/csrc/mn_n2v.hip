@@ -360,8 +360,9 @@ static int session_init(mn_n2v_session *S, int n, const int *off, const int *adj
     NCHK(hipMemcpy(S->neg, neg.data(), N2V_NEG_TABLE * sizeof(int), hipMemcpyHostToDevice));
     NCHK(hipMemcpy(S->sig, sig.data(), sig.size() * sizeof(float), hipMemcpyHostToDevice));
     NCHK(hipMemcpy(S->syn0, syn0.data(), nd * sizeof(float), hipMemcpyHostToDevice));
-    NCHK(hipMemset(S->syn1, 0, nd * sizeof(float)));
-    NCHK(hipMemset(S->pairs, 0, 2 * sizeof(unsigned long long)));
+    NCHK(hipStreamCreateWithFlags(&S->st, hipStreamNonBlocking));
+    NCHK(hipMemsetAsync(S->syn1, 0, nd * sizeof(float), S->st));
+    NCHK(hipMemsetAsync(S->pairs, 0, 2 * sizeof(unsigned long long), S->st));
     NCHK(hipEventCreate(&S->e0));
     NCHK(hipEventCreate(&S->e1));
     N2vArgs &a = S->a;
@@ -423,7 +424,7 @@ static int session_init(mn_n2v_session *S, int n, const int *off, const int *adj
     S->bits = 1;
     while ((1u << S->bits) <= (unsigned)n)
         S->bits++;
-    if (rocprim::radix_sort_pairs(nullptr, S->tmp_bytes, S->keys, S->keys_s, S->vals, S->vals_s, S->ns_max, 0, S->bits, nullptr) !=
+    if (rocprim::radix_sort_pairs(nullptr, S->tmp_bytes, S->keys, S->keys_s, S->vals, S->vals_s, S->ns_max, 0, S->bits, S->st) !=
         hipSuccess) {
         nset_err("rocprim::radix_sort_pairs (size query) failed");
         return -1;
@@ -442,7 +443,7 @@ extern "C" mn_n2v_session *mn_n2v_begin(int n, const int *off, const int *adj, c
         delete S;
         return nullptr;
     }
-    (void)hipEventRecord(S->e0, nullptr);
+    (void)hipEventRecord(S->e0, S->st);
     return S;
 }
 extern "C" int mn_n2v_batch_walks(mn_n2v_session *S) { return S->B; }
@@ -470,8 +471,8 @@ extern "C" int mn_n2v_sync(mn_n2v_session *S) {
 extern "C" int mn_n2v_finish(mn_n2v_session *S, float *out, mn_n2v_stats *stats) {
     NCHK(hipSetDevice(S->device));
     const int n = S->a.n, dim = S->a.dim;
-    hipLaunchKernelGGL(k_n2v_normalize, dim3(n), dim3(64), (size_t)dim * sizeof(float), nullptr, S->syn0, n, dim);
-    NCHK(hipEventRecord(S->e1, nullptr));
+    hipLaunchKernelGGL(k_n2v_normalize, dim3(n), dim3(64), (size_t)dim * sizeof(float), S->st, S->syn0, n, dim);
+    NCHK(hipEventRecord(S->e1, S->st));
     NCHK(hipDeviceSynchronize());
     unsigned long long o[2];
     NCHK(hipMemcpy(o, S->pairs, sizeof(o), hipMemcpyDeviceToHost));
@@ -537,10 +538,10 @@ extern "C" int mn_node2vec_train_shared(mn_comm *c, int n, const int *off, const
                 const int per = (b1 - b0 + world - 1) / world;
                 const int lo = std::min(b1, b0 + rank * per), hi = std::min(b1, lo + per);
                 // unused slots carry -1 (ranks with a short or empty slice still contribute `per` walks' worth of slots)
-                if (hipMemsetAsync(lc, 0xFF, (size_t)per * cap * 4, nullptr) != hipSuccess ||
-                    hipMemsetAsync(lt, 0xFF, (size_t)per * cap * 4, nullptr) != hipSuccess ||
-                    hipMemsetAsync(le, 0, (size_t)per * cap * 4, nullptr) != hipSuccess ||
-                    hipMemsetAsync(lpc, 0xFF, (size_t)per * pcap * 4, nullptr) != hipSuccess) {
+                if (hipMemsetAsync(lc, 0xFF, (size_t)per * cap * 4, S->st) != hipSuccess ||
+                    hipMemsetAsync(lt, 0xFF, (size_t)per * cap * 4, S->st) != hipSuccess ||
+                    hipMemsetAsync(le, 0, (size_t)per * cap * 4, S->st) != hipSuccess ||
+                    hipMemsetAsync(lpc, 0xFF, (size_t)per * pcap * 4, S->st) != hipSuccess) {
                     nset_err("mn_node2vec_train_shared: memset failed");
                     rc = -1;
                     break;
@@ -549,11 +550,11 @@ extern "C" int mn_node2vec_train_shared(mn_comm *c, int n, const int *off, const
                     rc = n2v_samples(S, epoch, w, lo, hi, lc, lt, le, lpc, lpn);
                 if (rc)
                     break;
-                if (mn_comm_allgather_dev(c, lc, gc, (size_t)per * cap * 4, nullptr) ||
-                    mn_comm_allgather_dev(c, lt, gt, (size_t)per * cap * 4, nullptr) ||
-                    mn_comm_allgather_dev(c, le, ge, (size_t)per * cap * 4, nullptr) ||
-                    mn_comm_allgather_dev(c, lpc, gpc, (size_t)per * pcap * 4, nullptr) ||
-                    mn_comm_allgather_dev(c, lpn, gpn, (size_t)per * pcap * dim * 4, nullptr)) {
+                if (mn_comm_allgather_dev(c, lc, gc, (size_t)per * cap * 4, S->st) ||
+                    mn_comm_allgather_dev(c, lt, gt, (size_t)per * cap * 4, S->st) ||
+                    mn_comm_allgather_dev(c, le, ge, (size_t)per * cap * 4, S->st) ||
+                    mn_comm_allgather_dev(c, lpc, gpc, (size_t)per * pcap * 4, S->st) ||
+                    mn_comm_allgather_dev(c, lpn, gpn, (size_t)per * pcap * dim * 4, S->st)) {
                     nset_err("mn_node2vec_train_shared: %s", mn_comm_last_error_str());
                     rc = -1;
                     break;
@@ -609,8 +610,8 @@ extern "C" int mn_node2vec_train(int n, const int *off, const int *adj, const mn
     const int dim = prm->dim;
     size_t lds = N2V_LDS_DEG * sizeof(double) + 3 * (size_t)dim * sizeof(float) + (N2V_SIG_SIZE + 1) * sizeof(float) +
                  (size_t)std::min(prm->walk_length, N2V_LDS_WALK) * sizeof(int) + 64;
-    NCHK(hipEventRecord(S->e0, nullptr));
-    hipLaunchKernelGGL(k_n2v_seq, dim3(1), dim3(64), lds, nullptr, S->a);
+    NCHK(hipEventRecord(S->e0, S->st));
+    hipLaunchKernelGGL(k_n2v_seq, dim3(1), dim3(64), lds, S->st, S->a);
     NCHK(hipGetLastError());
     return mn_n2v_finish(S, out, stats) < 0 ? -1 : n;
 }

@@ -454,6 +454,7 @@ struct mn_n2v_session {
     void *tmp = nullptr;
     unsigned long long *pairs = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t st = nullptr; // the session's own stream: every launch, memset, sort and exchange of a training run
     ~mn_n2v_session() {
         (void)hipFree(off); (void)hipFree(adj); (void)hipFree(neg); (void)hipFree(syn0); (void)hipFree(syn1); (void)hipFree(sig);
         (void)hipFree(staged); (void)hipFree(s_center); (void)hipFree(s_target); (void)hipFree(keys); (void)hipFree(vals);
@@ -461,6 +462,7 @@ struct mn_n2v_session {
         (void)hipFree(nseg); (void)hipFree(nseg_c); (void)hipFree(s_err); (void)hipFree(p_neu); (void)hipFree(p_center); (void)hipFree(cum); (void)hipFree(tmp); (void)hipFree(pairs);
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
+        if (st) (void)hipStreamDestroy(st);
     }
 };
 
@@ -494,7 +496,7 @@ static int n2v_samples_t(mn_n2v_session *S, int epoch, int w, int lo, int hi, in
     b.split = split;
     const size_t lds = (uniform ? 0 : N2VB_LDS_DEG * sizeof(double)) + (size_t)((S->a.walk_length + 3) & ~3) * sizeof(int) +
                        (N2V_SIG_SIZE + 1) * sizeof(float) + 64;
-    hipLaunchKernelGGL((k_n2v_walk_grad<NR>), dim3((unsigned)(hi - lo) * split), dim3(64), lds, nullptr, b);
+    hipLaunchKernelGGL((k_n2v_walk_grad<NR>), dim3((unsigned)(hi - lo) * split), dim3(64), lds, S->st, b);
     NCHK(hipGetLastError());
     return 0;
 }
@@ -514,28 +516,28 @@ static int n2v_apply_t(mn_n2v_session *S, const int *d_center, const int *d_targ
     const int ns = (int)ns64, np = (int)np64;
     const unsigned g256 = (unsigned)((ns + 255) / 256), p256 = (unsigned)((np + 255) / 256);
     // centres: syn0[c] + Σ neu1e(position)  → staged (targets below still read the old centres)
-    hipLaunchKernelGGL(k_n2v_keys, dim3(p256), dim3(256), 0, nullptr, d_pcenter, np, N, S->keys, S->vals);
-    if (rocprim::radix_sort_pairs(S->tmp, S->tmp_bytes, S->keys, S->keys_c, S->vals, S->vals_s, (size_t)np, 0, S->bits, nullptr) !=
+    hipLaunchKernelGGL(k_n2v_keys, dim3(p256), dim3(256), 0, S->st, d_pcenter, np, N, S->keys, S->vals);
+    if (rocprim::radix_sort_pairs(S->tmp, S->tmp_bytes, S->keys, S->keys_c, S->vals, S->vals_s, (size_t)np, 0, S->bits, S->st) !=
         hipSuccess) {
         nset_err("rocprim::radix_sort_pairs failed");
         return -1;
     }
-    NCHK(hipMemsetAsync(S->seg_c, 0xFF, (size_t)N * sizeof(int), nullptr));
-    hipLaunchKernelGGL(k_n2v_segments, dim3(p256), dim3(256), 0, nullptr, S->keys_c, np, N, S->seg_c);
-    hipLaunchKernelGGL((k_n2v_apply_centers<NR>), dim3(N), dim3(64), 0, nullptr, S->keys_c, S->vals_s, S->seg_c, np, d_pneu, a.syn0,
+    NCHK(hipMemsetAsync(S->seg_c, 0xFF, (size_t)N * sizeof(int), S->st));
+    hipLaunchKernelGGL(k_n2v_segments, dim3(p256), dim3(256), 0, S->st, S->keys_c, np, N, S->seg_c);
+    hipLaunchKernelGGL((k_n2v_apply_centers<NR>), dim3(N), dim3(64), 0, S->st, S->keys_c, S->vals_s, S->seg_c, np, d_pneu, a.syn0,
                        S->staged, dim);
     // targets: syn1neg[t] += Σ err · syn0_old[c]  (syn0 is still the old one) → in place
-    hipLaunchKernelGGL(k_n2v_keys, dim3(g256), dim3(256), 0, nullptr, d_target, ns, N, S->keys, S->vals);
-    if (rocprim::radix_sort_pairs(S->tmp, S->tmp_bytes, S->keys, S->keys_s, S->vals, S->vals_s, (size_t)ns, 0, S->bits, nullptr) !=
+    hipLaunchKernelGGL(k_n2v_keys, dim3(g256), dim3(256), 0, S->st, d_target, ns, N, S->keys, S->vals);
+    if (rocprim::radix_sort_pairs(S->tmp, S->tmp_bytes, S->keys, S->keys_s, S->vals, S->vals_s, (size_t)ns, 0, S->bits, S->st) !=
         hipSuccess) {
         nset_err("rocprim::radix_sort_pairs failed");
         return -1;
     }
-    NCHK(hipMemsetAsync(S->seg, 0xFF, (size_t)N * sizeof(int), nullptr));
-    hipLaunchKernelGGL(k_n2v_segments, dim3(g256), dim3(256), 0, nullptr, S->keys_s, ns, N, S->seg);
-    hipLaunchKernelGGL((k_n2v_apply<NR>), dim3(N), dim3(64), 0, nullptr, S->keys_s, S->vals_s, S->seg, ns, d_center, d_err,
+    NCHK(hipMemsetAsync(S->seg, 0xFF, (size_t)N * sizeof(int), S->st));
+    hipLaunchKernelGGL(k_n2v_segments, dim3(g256), dim3(256), 0, S->st, S->keys_s, ns, N, S->seg);
+    hipLaunchKernelGGL((k_n2v_apply<NR>), dim3(N), dim3(64), 0, S->st, S->keys_s, S->vals_s, S->seg, ns, d_center, d_err,
                        a.syn1neg, a.syn0, a.syn1neg, dim);
-    hipLaunchKernelGGL(k_n2v_commit, dim3(N), dim3(64), 0, nullptr, S->seg_c, S->staged, a.syn0, dim);
+    hipLaunchKernelGGL(k_n2v_commit, dim3(N), dim3(64), 0, S->st, S->seg_c, S->staged, a.syn0, dim);
     NCHK(hipGetLastError());
     return 0;
 }
