@@ -26,6 +26,21 @@ def test_oracle_matches_reference_golden(name):
     assert qbits(q) == z[f"{name}_q"][0]
 
 
+@pytest.mark.parametrize("name", ["karate", "er200", "er2000", "er2000w", "planted600"])
+@pytest.mark.parametrize("batch", [16, 1000])
+def test_batched_schedule_pin(name, batch):
+    """The batch-synchronous schedule is this repository's own (the reference has no such mode), so nothing in the
+    reference pins it: this file does (oracle/gen_golden.py leiden_schedule_pins).  A change of round sizes, commit rule
+    or tail rule shows up here, on CPU, and has to be made on purpose on both sides (device vs live oracle: -m gpu)."""
+    z = np.load(os.path.join(G, "leiden_schedule_pins.npz"))
+    s, d, w, res = CASES[name]
+    comm, q, st = og.leiden(og.Csr(s, d, w, "both"), res, batch)
+    key = f"{name}_b{batch}"
+    assert np.array_equal(comm, z[key + "_community"])
+    assert qbits(q) == z[key + "_q"][0]
+    assert [st["move_sweeps"], st["refine_sweeps"], st["moves"]] == z[key + "_sweeps"].tolist()
+
+
 def test_reference_structural_contracts():
     """pytests/test_graph_community.py:129-287 restated on the oracle: barbell → {0,1,2},{3,4,5}; triangle → 1;
     disconnected → 2; Q > 0; ids contiguous from 0; resolution monotone."""
