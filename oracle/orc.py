@@ -106,6 +106,17 @@ def pq_trace(ops, ids, dists):
     return oi[:n].copy(), od[:n].copy()
 
 
+def graph_digest(g):
+    """sha256 over a graph() result: levels, then every (id, level) list in key order, entry point, top level"""
+    import hashlib
+
+    flat = list(g["levels"])
+    for (i, l) in sorted(g["nbrs"]):
+        flat += [i, l, len(g["nbrs"][(i, l)])] + list(g["nbrs"][(i, l)])
+    flat += [g["entry"], g["max_level"]]
+    return np.frombuffer(hashlib.sha256(np.array(flat, np.int64).tobytes()).digest(), np.uint8)
+
+
 class _IndexBase:
     """Common Python surface over the oracle and the compiled reference."""
 
