@@ -483,3 +483,26 @@ def test_mn_comm_next_to_torchs_own_rccl_communicator(gpu):
                MN_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", _NCCL_COEXIST], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "NCCL_COEXIST_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_in_process_shards_with_empty_and_short_shards(gpu):
+    """fewer nodes than shards / than k: empty shards contribute nothing, the merged list is as long as the index"""
+    d, k = 8, 5
+    rng = np.random.default_rng(3)
+    sh = gpu.ShardedIndex(d, "l2", 4, 20, devices=[0, 0, 0])
+    Q = rng.standard_normal((3, d), dtype=np.float32)
+    gi, gd, gc = sh.search_batch(Q, k, 10)  # nothing inserted yet
+    assert (gc == 0).all() and (gi == -1).all()
+    X = rng.standard_normal((2, d), dtype=np.float32)
+    assert sh.insert(3, X[0]) == 0 and sh.insert(7, X[1]) == 0  # shards 0 and 1; shard 2 stays empty
+    assert sh.insert(3, X[0]) == -1  # duplicate rowid, as hnsw_insert
+    gi, gd, gc = sh.search_batch(Q, k, 10)
+    assert (gc == 2).all() and (gi[:, 2:] == -1).all()
+    for qi in range(3):
+        want = sorted([(float(((Q[qi] - X[0]) ** 2).sum()), 3), (float(((Q[qi] - X[1]) ** 2).sum()), 7)])
+        assert gi[qi, :2].tolist() == [w[1] for w in want]
+        assert (np.diff(gd[qi, :2]) >= 0).all()
+    ids1, _ = sh.search(Q[0], k, 10)
+    assert ids1.tolist() == gi[0, :2].tolist()
+    sh.close()
