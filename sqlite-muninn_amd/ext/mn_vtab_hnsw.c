@@ -538,8 +538,10 @@ static int x_create(sqlite3 *db, void *aux, int argc, const char *const *argv, s
     }
     mn_index *ix = mn_hnsw_create_on(p.dimensions, p.metric, p.m, p.efc, mn_env_device());
     if (!ix) {
+        /* (the reference reports SQLITE_NOMEM here, src/hnsw_vtab.c:380-383: its only cause is malloc; here the usual cause
+         * is the device — a wrong MUNINN_DEVICE, no GPU — and SQLITE_NOMEM would drop the message) */
         *err = sqlite3_mprintf("hnsw_index: failed to allocate index (%s)", mn_last_error());
-        return SQLITE_NOMEM;
+        return SQLITE_ERROR;
     }
     VtabHnsw *v = new_vtab(db, argv[2], &p, ix);
     if (!v) {
@@ -571,8 +573,10 @@ static int x_connect(sqlite3 *db, void *aux, int argc, const char *const *argv, 
         return rc;
     mn_index *ix = mn_hnsw_create_on(p.dimensions, p.metric, p.m, p.efc, mn_env_device());
     if (!ix) {
+        /* (the reference reports SQLITE_NOMEM here, src/hnsw_vtab.c:380-383: its only cause is malloc; here the usual cause
+         * is the device — a wrong MUNINN_DEVICE, no GPU — and SQLITE_NOMEM would drop the message) */
         *err = sqlite3_mprintf("hnsw_index: failed to allocate index (%s)", mn_last_error());
-        return SQLITE_NOMEM;
+        return SQLITE_ERROR;
     }
     VtabHnsw *v = new_vtab(db, argv[2], &p, ix);
     if (!v) {

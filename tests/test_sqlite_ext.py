@@ -581,3 +581,39 @@ def test_session_with_lists_longer_than_m_max_equals_the_reference(ext_built, gp
     assert np.array_equal(np.array(nodes, np.int64), z["nodes"])
     assert np.array_equal(np.array([e[:3] for e in edges], np.int64), z["edges_int"])
     assert np.array_equal(np.array([e[3] for e in edges], np.float64), z["edges_dist"])
+
+
+_DEVICE_ENV = r"""
+import os, sqlite3, sys
+c = sqlite3.connect(":memory:"); c.enable_load_extension(True)
+c.load_extension(os.path.join(os.environ["MN_ROOT"], "sqlite-muninn_amd", "ext", "muninn"))
+try:
+    c.execute("CREATE VIRTUAL TABLE t USING hnsw_index(dimensions=4, metric='l2')")
+    c.execute("INSERT INTO t(rowid, vector) VALUES (1, ?)", (b"\0" * 16,))
+    print("CREATED", c.execute("SELECT count(*) FROM t_nodes").fetchone()[0])
+except sqlite3.Error as e:
+    print("SQLERR", e)
+try:
+    c.execute("CREATE TABLE e(src TEXT, dst TEXT)"); c.executemany("INSERT INTO e VALUES (?,?)", [("a", "b"), ("b", "c")])
+    print("PR", len(c.execute("SELECT * FROM graph_pagerank WHERE edge_table='e' AND src_col='src' AND dst_col='dst'").fetchall()))
+except sqlite3.Error as e:
+    print("SQLERR2", e)
+"""
+
+
+@pytest.mark.gpu
+def test_muninn_device_env_selects_the_ordinal_and_fails_loudly_on_a_bad_one(ext_conn):
+    """MUNINN_DEVICE=<ordinal>: 0 works as the default does; an ordinal the box does not have is an SQL error from
+    CREATE VIRTUAL TABLE and from the graph TVFs (no crash, no silent fallback to another device or to the CPU)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dev, ok in (("0", True), ("63", False)):
+        env = dict(os.environ, MUNINN_DEVICE=dev, MN_ROOT=root)
+        r = subprocess.run([sys.executable, "-c", _DEVICE_ENV], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        if ok:
+            assert "CREATED 1" in r.stdout and "PR 3" in r.stdout, r.stdout
+        else:
+            assert "SQLERR" in r.stdout and "SQLERR2" in r.stdout and "CREATED" not in r.stdout and "PR 3" not in r.stdout, r.stdout
