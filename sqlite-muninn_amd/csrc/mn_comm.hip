@@ -36,7 +36,13 @@ Rccl g_rccl;
 std::once_flag g_rccl_once;
 bool rccl_load() {
     std::call_once(g_rccl_once, [] {
-        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        // a process that already carries RCCL (torch.distributed's backend "nccl") gets THAT copy: one RCCL per process, so the
+        // host's communicators and this library's share its state; only otherwise is the library loaded here
+        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+        if (!h)
+            h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+        if (!h)
+            h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
         if (!h)
             h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
         if (!h)
@@ -119,6 +125,10 @@ extern "C" int mn_comm_rank(mn_comm *c) { return c->rank; }
 extern "C" void mn_comm_destroy(mn_comm *c) {
     if (!c)
         return;
+    if (c->d_status) {
+        (void)hipSetDevice(c->device);
+        (void)hipFree(c->d_status);
+    }
     if (c->nccl && g_rccl.lib) {
         (void)hipSetDevice(c->device);
         (void)g_rccl.CommDestroy(c->nccl);
@@ -160,5 +170,42 @@ int mn_comm_allgather_dev(mn_comm *c, const void *d_send, void *d_recv, size_t b
         cset_err("mn_comm: staging from the host failed");
         return -1;
     }
+    return 0;
+}
+
+// Every rank contributes one status word; every rank learns all of them.  A rank whose local step failed must still make
+// this call — its peers are already inside (or about to enter) the matching collective and would wait for ever — and all
+// ranks then fail together.  Returns 0 (all ranks fine), 1 (*failed_rank = the lowest rank that reported a failure), or -1
+// when the exchange itself failed.
+int mn_comm_agree(mn_comm *c, int my_status, hipStream_t st, int *failed_rank) {
+    *failed_rank = -1;
+    if (!c || (c->world == 1 && !c->nccl)) {
+        if (my_status)
+            *failed_rank = c ? c->rank : 0;
+        return my_status ? 1 : 0;
+    }
+    if (!c->d_status && hipMalloc(&c->d_status, (size_t)(c->world + 1) * sizeof(int)) != hipSuccess) {
+        cset_err("mn_comm: status buffer allocation failed");
+        return -1;
+    }
+    std::vector<int> h((size_t)c->world, 0);
+    int *mine = c->d_status + c->world; // (send and receive do not overlap: RCCL's in-place rule is about exact offsets)
+    if (hipMemcpyAsync(mine, &my_status, sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) { // (my_status is a stack word)
+        cset_err("mn_comm: status upload failed");
+        return -1;
+    }
+    if (mn_comm_allgather_dev(c, mine, c->d_status, sizeof(int), st))
+        return -1;
+    if (hipMemcpyAsync(h.data(), c->d_status, (size_t)c->world * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+        cset_err("mn_comm: status download failed");
+        return -1;
+    }
+    for (int r = 0; r < c->world; r++)
+        if (h[(size_t)r]) {
+            *failed_rank = r;
+            return 1;
+        }
     return 0;
 }

@@ -15,9 +15,13 @@ struct mn_comm {
     mn_host_allgather_fn host_fn = nullptr;
     void *host_user = nullptr;
     std::vector<unsigned char> h_send, h_recv;
+    int *d_status = nullptr; // [world + 1] status words of mn_comm_agree
 };
 
 // d_recv[r * bytes .. (r+1) * bytes) = rank r's d_send, for every r; in place (d_send == d_recv + rank * bytes) allowed.
 // Stream-ordered for RCCL; the host transport synchronises the stream.  0 / -1 (message via mn_comm_last_error).
 int mn_comm_allgather_dev(mn_comm *c, const void *d_send, void *d_recv, size_t bytes, hipStream_t st);
 const char *mn_comm_last_error_str();
+// One status word per rank, all-gathered: 0 = every rank is fine, 1 = *failed_rank (the lowest) reported a failure, -1 = the
+// exchange itself failed.  A rank whose local step failed MUST still call this: its peers are in the matching collective.
+int mn_comm_agree(mn_comm *c, int my_status, hipStream_t st, int *failed_rank);

@@ -99,6 +99,8 @@ int mn_launch_bruteforce_mfma(const MnDevIndex &ix, const float *d_queries, long
 
 // sharded index (config 3): per-shard top-k lists gathered as [world][nq][k] → global top-k per query in the total order
 // (distance, shard rank, position)  (mn_kernels.hip)
+// synchronises the index's stream; *n_overflow = queries of its last search that exceeded their heap workspace.  0 / -1
+int mn_index_search_overflow(struct mn_index *x, long long *n_overflow);
 void mn_launch_merge_topk(const long long *g_ids, const float *g_dists, const int *g_counts, int world, long long nq, int k,
                           long long *out_ids, float *out_dists, int *out_counts, hipStream_t st);
 

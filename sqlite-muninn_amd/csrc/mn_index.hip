@@ -126,6 +126,8 @@ struct mn_index {
     DevBuf<int> d_staged;
     // multi-GPU exchange buffers (mn_hnsw_build_shared / mn_hnsw_search_sharded)
     DevBuf<int> sh_sel, sh_nsel, sh_gcnt, sh_lcnt;
+    DevBuf<unsigned long long> sh_ovf; // [world] heap-workspace overflow counts of the last sharded search, all-gathered
+    int sh_ovf_pending = 0;             // entries of sh_ovf not yet looked at by the host (0: none)
     DevBuf<long long> sh_gids, sh_lids;
     DevBuf<float> sh_gd, sh_ld;
     long long last_spec_searched = 0; // searches the last speculative build ran (≥ nodes inserted)
@@ -583,7 +585,7 @@ extern "C" void mn_hnsw_destroy(mn_index *x) {
     x->lk_newrows.release(); x->ws_counters.release(); x->ws_state.release();
     x->er_slot.release(); x->er_level.release(); x->er_nbr.release(); x->er_dist.release();
     x->d_staged.release();
-    x->sh_sel.release(); x->sh_nsel.release(); x->sh_gcnt.release(); x->sh_lcnt.release(); x->sh_gids.release();
+    x->sh_sel.release(); x->sh_nsel.release(); x->sh_gcnt.release(); x->sh_lcnt.release(); x->sh_ovf.release(); x->sh_gids.release();
     x->sh_lids.release(); x->sh_gd.release(); x->sh_ld.release();
     x->ws_readlog.release(); x->ws_nread.release(); x->ws_ncommit.release(); x->d_stamp0.release(); x->d_stampU.release();
     if (x->ev0) (void)hipEventDestroy(x->ev0);
@@ -722,11 +724,41 @@ extern "C" int mn_hnsw_search_batch_dev(mn_index *x, const float *d_queries, int
     return 0;
 }
 
+// A sharded search all-gathers every shard's overflow count next to its top-k (mn_hnsw_search_sharded_dev): every rank sees
+// the same counts, so every rank fails alike — and names the shard — the first time its host looks (any synchronising call).
+static int check_sharded_overflow(mn_index *x) {
+    if (!x->sh_ovf_pending)
+        return 0;
+    const int world = x->sh_ovf_pending;
+    x->sh_ovf_pending = 0;
+    std::vector<unsigned long long> h((size_t)world);
+    HIPCHK(hipMemcpyAsync(h.data(), x->sh_ovf.p, (size_t)world * sizeof(unsigned long long), hipMemcpyDeviceToHost, x->stream));
+    HIPCHK(hipStreamSynchronize(x->stream));
+    for (int r = 0; r < world; r++)
+        if (h[(size_t)r]) {
+            set_err("mn_hnsw_search_sharded: shard %d: %llu queries exceeded heap workspace (its top-k lists are truncated)", r,
+                    h[(size_t)r]);
+            return -1;
+        }
+    return 0;
+}
+
+// for mn_shards.hip (one process, several GPUs): synchronises the index's stream and reports an overflow of its last search
+int mn_index_search_overflow(mn_index *x, long long *n_overflow) {
+    *n_overflow = 0;
+    if (x->entry_id == -1 || x->node_count == 0)
+        return 0;
+    if (fetch_counters(x))
+        return -1;
+    *n_overflow = (long long)x->last.last_n_overflow;
+    return 0;
+}
+
 extern "C" int mn_hnsw_sync(mn_index *x) {
     if (use_device(x))
         return -1;
     HIPCHK(hipStreamSynchronize(x->stream));
-    return 0;
+    return check_sharded_overflow(x);
 }
 
 extern "C" int mn_hnsw_search_batch(mn_index *x, const float *queries, int64_t nq, int k, int ef, int64_t *out_ids,
@@ -1276,27 +1308,61 @@ extern "C" int mn_hnsw_build_shared(mn_index *x, mn_comm *c, const int64_t *ids,
         int64_t b = std::max<int64_t>(1, x->node_count / grow_div); // the batches of mn_hnsw_build
         b = std::min<int64_t>(b, max_batch);
         b = std::min<int64_t>(b, n - pos);
+        // A rank whose local step fails (staging, workspace, its slice of the searches: overflow, out of memory) may not simply
+        // return: its peers are in — or about to enter — the batch's all-gather and would wait for ever.  Every rank finishes
+        // its local step, the ranks exchange one status word, and all of them fail together (mn_comm_agree).
+        int status = 0;
         const int m = mn_hnsw_batch_stage(x, ids + pos, vectors + (size_t)pos * x->dim, b);
         if (m < 0)
-            return -1;
+            status = 1;
+        if (const char *fi = getenv("MN_FAULT_INJECT")) { // test hook: "build_shared:<rank>:<first id position of the batch>"
+            int fr = -1;
+            long long fp = -1;
+            if (sscanf(fi, "build_shared:%d:%lld", &fr, &fp) == 2 && fr == rank && fp >= pos && fp < pos + b && !status) {
+                set_err("injected failure (MN_FAULT_INJECT)");
+                status = 1;
+            }
+        }
         pos += b;
-        if (m == 0)
-            continue;
         const int nlev = x->max_level + 1, w0 = x->M_max0;
         const bool split = world > 1 && m >= min_split;
-        const int per = split ? (m + world - 1) / world : m;
-        const int rows = split ? per * world : m;
+        const int per = split ? (m + world - 1) / world : std::max(m, 0);
+        const int rows = split ? per * world : std::max(m, 0);
         const size_t row_sel = (size_t)nlev * w0;
-        if (x->sh_sel.reserve((size_t)rows * row_sel, false, st) || x->sh_nsel.reserve((size_t)rows * nlev, false, st))
-            return -1;
-        HIPCHK(hipMemsetAsync(x->sh_sel.p, 0xFF, (size_t)rows * row_sel * sizeof(int), st));
-        HIPCHK(hipMemsetAsync(x->sh_nsel.p, 0, (size_t)rows * nlev * sizeof(int), st));
-        const int lo = split ? std::min(m, rank * per) : 0, hi = split ? std::min(m, rank * per + per) : m;
-        // from here on the batch's nodes are in the host tables but not linked: a failure must not leave a half-built index in use
-        if (mn_hnsw_batch_search(x, lo, hi, x->sh_sel.p, x->sh_nsel.p)) { // this rank's slice of the batch's searches
-            x->broken = true;
+        if (!status && m > 0) {
+            if (x->sh_sel.reserve((size_t)rows * row_sel, false, st) || x->sh_nsel.reserve((size_t)rows * nlev, false, st) ||
+                hipMemsetAsync(x->sh_sel.p, 0xFF, (size_t)rows * row_sel * sizeof(int), st) != hipSuccess ||
+                hipMemsetAsync(x->sh_nsel.p, 0, (size_t)rows * nlev * sizeof(int), st) != hipSuccess) {
+                status = 1;
+            } else {
+                const int lo = split ? std::min(m, rank * per) : 0, hi = split ? std::min(m, rank * per + per) : m;
+                // from here on the batch's nodes are in the host tables but not linked: a failure must not leave a half-built
+                // index in use
+                if (mn_hnsw_batch_search(x, lo, hi, x->sh_sel.p, x->sh_nsel.p)) { // this rank's slice of the batch's searches
+                    x->broken = true;
+                    status = 1;
+                }
+            }
+        }
+        if (world > 1) {
+            int failed = -1;
+            const std::string mine = status ? std::string(mn_last_error()) : std::string();
+            const int ag = mn_comm_agree(c, status, st, &failed);
+            if (ag) {
+                if (ag < 0)
+                    set_err("mn_hnsw_build_shared: %s", mn_comm_last_error_str());
+                else if (failed == rank)
+                    set_err("mn_hnsw_build_shared: rank %d failed: %s", rank, mine.c_str());
+                else
+                    set_err("mn_hnsw_build_shared: rank %d failed in this batch; all ranks stop", failed);
+                x->broken = true;
+                return -1;
+            }
+        } else if (status) {
             return -1;
         }
+        if (m == 0)
+            continue;
         if (split) { // in place: rank r's rows already sit at r * per
             if (mn_comm_allgather_dev(c, x->sh_sel.p + (size_t)rank * per * row_sel, x->sh_sel.p, (size_t)per * row_sel * sizeof(int), st) ||
                 mn_comm_allgather_dev(c, x->sh_nsel.p + (size_t)rank * per * nlev, x->sh_nsel.p, (size_t)per * nlev * sizeof(int), st)) {
@@ -1335,9 +1401,18 @@ extern "C" int mn_hnsw_search_sharded_dev(mn_index *x, mn_comm *c, const float *
     int *my_c = x->sh_gcnt.p + (size_t)nq * rank;
     if (mn_hnsw_search_batch_dev(x, d_queries, nq, k, ef, (int64_t *)my_ids, my_d, my_c))
         return -1;
+    // this shard's heap-workspace overflow count travels with its lists: a truncated list must not be merged silently
+    if (x->sh_ovf.reserve((size_t)world, false, st))
+        return -1;
+    if (x->entry_id == -1 || x->node_count == 0 || !x->ws_counters.p)
+        HIPCHK(hipMemsetAsync(x->sh_ovf.p + rank, 0, sizeof(unsigned long long), st));
+    else
+        HIPCHK(hipMemcpyAsync(x->sh_ovf.p + rank, x->ws_counters.p + 2, sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
+    x->sh_ovf_pending = world;
     if (world > 1 || (c && c->nccl)) {
         if (mn_comm_allgather_dev(c, my_ids, x->sh_gids.p, per * sizeof(long long), st) ||
             mn_comm_allgather_dev(c, my_d, x->sh_gd.p, per * sizeof(float), st) ||
+            mn_comm_allgather_dev(c, x->sh_ovf.p + rank, x->sh_ovf.p, sizeof(unsigned long long), st) ||
             mn_comm_allgather_dev(c, my_c, x->sh_gcnt.p, (size_t)nq * sizeof(int), st)) {
             set_err("mn_hnsw_search_sharded: %s", mn_comm_last_error_str());
             return -1;
@@ -1365,7 +1440,7 @@ extern "C" int mn_hnsw_search_sharded(mn_index *x, mn_comm *c, const float *quer
     HIPCHK(hipMemcpyAsync(out_dists, x->sh_ld.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(out_counts, x->sh_lcnt.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    return 0;
+    return check_sharded_overflow(x);
 }
 
 // ───────────────────────── delete (cold path, host-side list surgery) ─────────────────────────

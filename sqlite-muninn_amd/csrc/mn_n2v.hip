@@ -530,24 +530,57 @@ extern "C" int mn_node2vec_train_shared(mn_comm *c, int n, const int *off, const
         nset_err("mn_node2vec_train_shared: out of device memory for the exchange buffers");
         return cleanup(-1);
     }
-    int rc = 0;
+    // A rank whose local step fails may not leave the loop on its own: its peers are in — or about to enter — the batch's
+    // all-gathers and would wait for ever.  `status` carries a local failure (this batch's samples, or the previous batch's
+    // apply) into the status exchange at the head of the next collective; all ranks stop together (mn_comm_agree).
+    int rc = 0, status = 0;
+    std::string mine;
+    auto agree = [&]() {
+        if (world == 1) {
+            if (status)
+                rc = -1;
+            return;
+        }
+        int failed = -1;
+        const int ag = mn_comm_agree(c, status, S->st, &failed);
+        if (ag == 0)
+            return;
+        if (ag < 0)
+            nset_err("mn_node2vec_train_shared: %s", mn_comm_last_error_str());
+        else if (failed == rank)
+            nset_err("mn_node2vec_train_shared: rank %d failed: %s", rank, mine.c_str());
+        else
+            nset_err("mn_node2vec_train_shared: rank %d failed; all ranks stop", failed);
+        rc = -1;
+    };
     for (int epoch = 0; epoch < prm->epochs && rc == 0; epoch++)
         for (int w = 0; w < prm->num_walks && rc == 0; w++)
             for (int b0 = 0; b0 < n && rc == 0; b0 += B) {
                 const int b1 = std::min(n, b0 + B);
                 const int per = (b1 - b0 + world - 1) / world;
                 const int lo = std::min(b1, b0 + rank * per), hi = std::min(b1, lo + per);
-                // unused slots carry -1 (ranks with a short or empty slice still contribute `per` walks' worth of slots)
-                if (hipMemsetAsync(lc, 0xFF, (size_t)per * cap * 4, S->st) != hipSuccess ||
-                    hipMemsetAsync(lt, 0xFF, (size_t)per * cap * 4, S->st) != hipSuccess ||
-                    hipMemsetAsync(le, 0, (size_t)per * cap * 4, S->st) != hipSuccess ||
-                    hipMemsetAsync(lpc, 0xFF, (size_t)per * pcap * 4, S->st) != hipSuccess) {
-                    nset_err("mn_node2vec_train_shared: memset failed");
-                    rc = -1;
-                    break;
+                if (!status) {
+                    // unused slots carry -1 (ranks with a short or empty slice still contribute `per` walks' worth of slots)
+                    if (hipMemsetAsync(lc, 0xFF, (size_t)per * cap * 4, S->st) != hipSuccess ||
+                        hipMemsetAsync(lt, 0xFF, (size_t)per * cap * 4, S->st) != hipSuccess ||
+                        hipMemsetAsync(le, 0, (size_t)per * cap * 4, S->st) != hipSuccess ||
+                        hipMemsetAsync(lpc, 0xFF, (size_t)per * pcap * 4, S->st) != hipSuccess) {
+                        nset_err("mn_node2vec_train_shared: memset failed");
+                        status = 1;
+                    } else if (hi > lo && n2v_samples(S, epoch, w, lo, hi, lc, lt, le, lpc, lpn)) {
+                        status = 1;
+                    }
+                    if (const char *fi = getenv("MN_FAULT_INJECT")) { // test hook: "n2v_shared:<rank>:<first node of the batch>"
+                        int fr = -1, fb = -1;
+                        if (sscanf(fi, "n2v_shared:%d:%d", &fr, &fb) == 2 && fr == rank && fb == b0 && !status) {
+                            nset_err("injected failure (MN_FAULT_INJECT)");
+                            status = 1;
+                        }
+                    }
+                    if (status)
+                        mine = mn_node2vec_last_error();
                 }
-                if (hi > lo)
-                    rc = n2v_samples(S, epoch, w, lo, hi, lc, lt, le, lpc, lpn);
+                agree();
                 if (rc)
                     break;
                 if (mn_comm_allgather_dev(c, lc, gc, (size_t)per * cap * 4, S->st) ||
@@ -559,8 +592,13 @@ extern "C" int mn_node2vec_train_shared(mn_comm *c, int n, const int *off, const
                     rc = -1;
                     break;
                 }
-                rc = n2v_apply(S, gc, gt, ge, (int64_t)world * per * cap, gpc, gpn, (int64_t)world * per * pcap);
+                if (n2v_apply(S, gc, gt, ge, (int64_t)world * per * cap, gpc, gpn, (int64_t)world * per * pcap)) {
+                    status = 1; // (reported to the peers at the head of the next batch, or below after the last one)
+                    mine = mn_node2vec_last_error();
+                }
             }
+    if (rc == 0)
+        agree();
     if (rc == 0)
         rc = mn_n2v_finish(S, out, stats);
     return cleanup(rc < 0 ? -1 : n);

@@ -209,8 +209,13 @@ extern "C" int mn_shards_search_batch(mn_shards *s, const float *queries, int64_
         return -1;
     // the shards' lists → shard 0's GPU, slot r of the gather buffers (the one exchange step of config 3)
     for (int r = 0; r < ns; r++) {
-        if (mn_hnsw_sync(s->ix[r])) {
+        long long novf = 0;
+        if (mn_index_search_overflow(s->ix[r], &novf)) { // (synchronises the shard's stream)
             sset_err("mn_shards_search_batch: shard %d: %s", r, mn_last_error());
+            return -1;
+        }
+        if (novf) { // the unsharded path fails the same way (mn_hnsw_search_batch): a truncated list is not merged
+            sset_err("mn_shards_search_batch: shard %d: %lld queries exceeded heap workspace", r, novf);
             return -1;
         }
         const ShardBuf &b = s->buf[r];
@@ -228,6 +233,8 @@ extern "C" int mn_shards_search_batch(mn_shards *s, const float *queries, int64_
 }
 
 extern "C" int mn_shards_search(mn_shards *s, const float *query, int k, int ef_search, mn_search_result *results) {
+    if (k < 1) // (before anything is sized by k: nothing may throw across the C boundary)
+        return 0;
     std::vector<int64_t> ids((size_t)k);
     std::vector<float> ds((size_t)k);
     int cnt = 0;

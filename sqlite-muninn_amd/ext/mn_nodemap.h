@@ -2,6 +2,7 @@
  * (a hash map where the reference scans linearly: src/node2vec.c:72-77, src/graph_tvf.c:1231-1235,1591-1595). */
 #ifndef MN_NODEMAP_H
 #define MN_NODEMAP_H
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #define MN_UNUSED __attribute__((unused))
@@ -11,8 +12,22 @@
  * mn_comm entry points (include/muninn_hip.h "multi-GPU"). */
 MN_UNUSED static int mn_env_device(void) {
     const char *e = getenv("MUNINN_DEVICE");
-    int d = e ? atoi(e) : 0;
-    return d < 0 ? 0 : d;
+    if (!e)
+        return 0;
+    char *end = NULL;
+    long d = strtol(e, &end, 10);
+    if (end == e || *end != '\0' || d < 0 || d > 1023)
+        return -1; /* malformed ("abc", "", "1x", "-1"): no device has this ordinal, so creation fails and says so */
+    return (int)d;
+}
+/* for error messages about a device: " (MUNINN_DEVICE='...')" when the variable is set, else "" (static buffer, one thread's use) */
+MN_UNUSED static const char *mn_env_device_hint(void) {
+    static _Thread_local char buf[96];
+    const char *e = getenv("MUNINN_DEVICE");
+    if (!e)
+        return "";
+    snprintf(buf, sizeof(buf), " (MUNINN_DEVICE='%.60s')", e);
+    return buf;
 }
 
 /* ───────────────────────── shared: identifiers, string→index map ───────────────────────── */

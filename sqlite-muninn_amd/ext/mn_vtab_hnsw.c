@@ -540,7 +540,7 @@ static int x_create(sqlite3 *db, void *aux, int argc, const char *const *argv, s
     if (!ix) {
         /* (the reference reports SQLITE_NOMEM here, src/hnsw_vtab.c:380-383: its only cause is malloc; here the usual cause
          * is the device — a wrong MUNINN_DEVICE, no GPU — and SQLITE_NOMEM would drop the message) */
-        *err = sqlite3_mprintf("hnsw_index: failed to allocate index (%s)", mn_last_error());
+        *err = sqlite3_mprintf("hnsw_index: failed to allocate index (%s)%s", mn_last_error(), mn_env_device_hint());
         return SQLITE_ERROR;
     }
     VtabHnsw *v = new_vtab(db, argv[2], &p, ix);
@@ -575,7 +575,7 @@ static int x_connect(sqlite3 *db, void *aux, int argc, const char *const *argv, 
     if (!ix) {
         /* (the reference reports SQLITE_NOMEM here, src/hnsw_vtab.c:380-383: its only cause is malloc; here the usual cause
          * is the device — a wrong MUNINN_DEVICE, no GPU — and SQLITE_NOMEM would drop the message) */
-        *err = sqlite3_mprintf("hnsw_index: failed to allocate index (%s)", mn_last_error());
+        *err = sqlite3_mprintf("hnsw_index: failed to allocate index (%s)%s", mn_last_error(), mn_env_device_hint());
         return SQLITE_ERROR;
     }
     VtabHnsw *v = new_vtab(db, argv[2], &p, ix);

@@ -201,6 +201,59 @@ def test_build_shared_by_two_ranks_equals_one_gpu_build(gpu):
         assert (ep, ml) == want[2:]
 
 
+def _fault_worker(rank, world, port, q, what):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    # the failure is injected on rank 1 only, in the second batch: rank 0 is healthy and must not be left inside a collective
+    os.environ["MN_FAULT_INJECT"] = {"build": "build_shared:1:2000", "n2v": "n2v_shared:1:50"}[what]
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import muninn_amd
+
+    pkg = muninn_amd.pkg
+    msg = "no error"
+    try:
+        if what == "build":
+            X = np.random.default_rng(77).standard_normal((6000, 24)).astype(np.float32)
+            g = pkg.HnswIndex(24, "cosine", 8, 60)
+            pkg.parallel.build_distributed(g, np.arange(5, 6005, dtype=np.int64), X, 16, 1024, min_split=64)
+        else:
+            from oracle import orc_graph as og
+            from oracle.graph_cases import planted
+
+            s, d, _ = planted(1200, 6, 0.08, 0.002, 7)
+            gr = og.N2vGraph(s, d)
+            pkg.parallel.node2vec_train_distributed(gr.off, gr.adj, 32, 1.0, 1.0, 2, 20, 3, 3, 0.025, 1, batch_walks=50)
+    except pkg.hnsw.MuninnHipError as e:
+        msg = str(e)
+    q.put((rank, msg))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("what", ["build", "n2v"])
+def test_a_rank_local_failure_stops_every_rank_instead_of_hanging_the_job(gpu, what):
+    """mn_hnsw_build_shared / mn_node2vec_train_shared: a rank whose local step fails (here injected on rank 1 in its second
+    batch) still enters the status exchange, so the healthy rank is not left waiting inside the batch's all-gather: both ranks
+    return an error that names the failing rank."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fault_worker, args=(r, world, port, q, what)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(_collect(procs, q, world, 300))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert "rank 1 failed" in res[0] and "all ranks stop" in res[0], res
+    assert "rank 1 failed" in res[1] and "injected failure" in res[1], res
+
+
 def _run_entry(script, extra):
     """`python <script> --gpus 2 ...` exactly as the driver starts it (no torchrun on the command line): the script
     itself must start its two ranks; both share the box's one GPU (gloo exchange)."""

@@ -228,6 +228,48 @@ def test_shadow_tables_identical_to_reference(ext_built, gpu, tmp_path, monkeypa
     c.close()
 
 
+@gpu_mark
+def test_config1_at_its_own_parameters_equals_the_reference_extension(ext_built, gpu, monkeypatch):
+    """BASELINE config 1 exactly as SURVEY §8(d) defines it — 10 000 x 128 default_rng(42), cosine, M = 16,
+    efConstruction = 200, one INSERT per row in one transaction, 100 queries x ef {20, 64, 128, 256} — through ext/muninn.so
+    in exact mode, against what the REFERENCE's extension produced for the same statements (tests/golden/vtab_cfg1.npz,
+    oracle/gen_golden.py vtab_cfg1): _config, every node level, every _edges row (hash over ids, levels and REAL distance
+    bits), every returned rowid and distance."""
+    import hashlib
+
+    monkeypatch.setenv("MUNINN_HNSW_MODE", "exact")
+    z = np.load(os.path.join(ROOT, "tests", "golden", "vtab_cfg1.npz"))
+    rng = np.random.default_rng(42)
+    X = rng.standard_normal((10_000, 128), dtype=np.float32)
+    Q = rng.standard_normal((100, 128), dtype=np.float32)
+    c = sqlite3.connect(":memory:")
+    c.enable_load_extension(True)
+    c.load_extension(ext_built)
+    c.execute("CREATE VIRTUAL TABLE v USING hnsw_index(dimensions=128, metric='cosine', m=16, ef_construction=200)")
+    with c:
+        for i in range(len(X)):
+            c.execute("INSERT INTO v (rowid, vector) VALUES (?, ?)", (i + 1, X[i].tobytes()))
+    assert [f"{k}={v}" for k, v in c.execute("SELECT key, value FROM v_config ORDER BY key")] == z["config"].tolist()
+    levels = np.array([r[0] for r in c.execute("SELECT level FROM v_nodes ORDER BY id")], np.int8)
+    assert np.array_equal(levels, z["levels"])
+    h = hashlib.sha256()
+    n_edges, head = 0, []
+    for s_, t_, l_, d_ in c.execute("SELECT source_id, target_id, level, distance FROM v_edges ORDER BY 1,3,2"):
+        h.update(np.array([s_, t_, l_], np.int64).tobytes() + np.array([d_], np.float64).tobytes())
+        if n_edges < 400:
+            head.append((s_, t_, l_, d_))
+        n_edges += 1
+    assert np.array_equal(np.array([e[:3] for e in head], np.int64), z["edges_head_int"])
+    assert np.array_equal(np.array([e[3] for e in head], np.float64), z["edges_head_dist"])
+    assert n_edges == int(z["n_edges"][0]) and h.hexdigest() == str(z["edges_sha256"][0])
+    for ef in (20, 64, 128, 256):
+        for qi, q in enumerate(Q):
+            got = c.execute("SELECT rowid, distance FROM v WHERE vector MATCH ? AND k = 10 AND ef_search = ?", (q.tobytes(), ef)).fetchall()
+            assert [g[0] for g in got] == z[f"ids_ef{ef}"][qi].tolist(), (ef, qi)
+            assert [g[1] for g in got] == z[f"dist_ef{ef}"][qi].tolist(), (ef, qi)
+    c.close()
+
+
 # ───────────────────────── node2vec_train / graph_leiden through SQL ─────────────────────────
 
 def test_graph_functions_registered_and_validate_args(conn):
@@ -556,6 +598,72 @@ def test_integrated_build_keeps_the_rest_of_the_reference_surface_loadable():
     c.execute("CREATE VIRTUAL TABLE g USING graph_adjacency(edge_table='e', src_col='s', dst_col='d')")
     assert c.execute("SELECT count(*) FROM g").fetchone()[0] == 4  # the reference's graph_adjacency vtab, unchanged
     c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [33, 34])
+def test_incremental_graph_adjacency_rebuild_runs_the_device_merge_and_equals_the_reference(gpu, seed):
+    """SURVEY §8 f-2 through the boundary: in the integrated build (oracle/Makefile) the reference's UNMODIFIED graph_adjacency.c
+    calls csr_apply_delta (src/graph_adjacency.c:864,910) and reaches ext/mn_csr_adapter.c — the reference's signature over
+    mn_csr_apply_delta on the GPU.  A graph of two CSR blocks (5 000 nodes), then INSERTs (new nodes included), DELETEs and an
+    incremental rebuild: the stored blocks, the node registry and the vtab's rows must equal, byte for byte, what the
+    reference's own extension (its CPU merge) produces for the same statements.  Both libraries are built in the build
+    container (`make -C oracle ref integrated`) and travel to the GPU box as built objects.  (The edge table carries a weight
+    column: without one the reference's own delta triggers do not compile — "no such column: NEW.NULL" — so its incremental
+    path is only reachable on weighted tables.)"""
+    weighted = True
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "muninn")
+    int_so = os.path.join(ROOT, "oracle", "_ref", "integrated", "muninn")
+    if not (os.path.exists(ref_so + ".so") and os.path.exists(int_so + ".so")):
+        pytest.skip("oracle/_ref (compiled reference + integrated build) not present")
+    syms = subprocess.run(["nm", "-D", int_so + ".so"], capture_output=True, text=True).stdout
+    assert " T csr_apply_delta" in syms and "mn_csr_apply_delta" in syms  # the strong definition is the adapter's
+
+    rng = np.random.default_rng(seed)
+    n, m = 5000, 14000
+    s0, d0 = rng.integers(0, n, m), rng.integers(0, n, m)
+    w0 = rng.integers(1, 13, m) * 0.25
+    ins = [(f"n{int(a)}", f"n{int(b)}" if i % 5 else f"new{int(b) % 40}", float(x))
+           for i, (a, b, x) in enumerate(zip(rng.integers(0, n, 300), rng.integers(0, n, 300), rng.integers(1, 9, 300) * 0.5))]
+    dele = rng.permutation(m)[:250]
+
+    def session(so):
+        c = sqlite3.connect(":memory:")
+        c.enable_load_extension(True)
+        c.load_extension(so)
+        if weighted:
+            c.execute("CREATE TABLE edges (src TEXT, dst TEXT, weight REAL)")
+            c.executemany("INSERT INTO edges VALUES (?,?,?)", [(f"n{a}", f"n{b}", float(x)) for a, b, x in zip(s0, d0, w0)])
+            c.execute("CREATE VIRTUAL TABLE g USING graph_adjacency(edge_table='edges', src_col='src', dst_col='dst', weight_col='weight')")
+        else:
+            c.execute("CREATE TABLE edges (src TEXT, dst TEXT)")
+            c.executemany("INSERT INTO edges VALUES (?,?)", [(f"n{a}", f"n{b}") for a, b in zip(s0, d0)])
+            c.execute("CREATE VIRTUAL TABLE g USING graph_adjacency(edge_table='edges', src_col='src', dst_col='dst')")
+        c.execute("INSERT INTO g(g) VALUES ('rebuild')")
+        assert c.execute("SELECT COUNT(*) FROM g_csr_fwd").fetchone()[0] >= 2
+        if weighted:  # (the reference's DELETE trigger names OLD.<weight_col>: without a weight column it cannot be created
+            #  usefully — "no such column: OLD.NULL" — so deletes are exercised on the weighted table only)
+            for i in dele:  # (a duplicated (src, dst) pair loses every copy: one DELETE statement, several delta rows)
+                c.execute("DELETE FROM edges WHERE src = ? AND dst = ?", (f"n{s0[i]}", f"n{d0[i]}"))
+        if weighted:
+            c.executemany("INSERT INTO edges VALUES (?,?,?)", ins)
+        else:
+            c.executemany("INSERT INTO edges VALUES (?,?)", [r[:2] for r in ins])
+        nd = c.execute("SELECT COUNT(*) FROM g_delta").fetchone()[0]
+        assert nd >= (500 if weighted else 300)
+        c.execute("INSERT INTO g(g) VALUES ('incremental_rebuild')")
+        assert c.execute("SELECT COUNT(*) FROM g_delta").fetchone()[0] == 0
+        out = {"rows": c.execute("SELECT * FROM g ORDER BY 1").fetchall(),
+               "fwd": c.execute("SELECT * FROM g_csr_fwd ORDER BY 1").fetchall(),
+               "rev": c.execute("SELECT * FROM g_csr_rev ORDER BY 1").fetchall(),
+               "nodes": c.execute("SELECT * FROM g_nodes ORDER BY 1").fetchall(),
+               "degree": c.execute("SELECT * FROM g_degree ORDER BY 1").fetchall()}
+        c.close()
+        return out
+
+    want, got = session(ref_so), session(int_so)
+    for k in ("nodes", "degree", "rows", "fwd", "rev"):
+        assert len(got[k]) == len(want[k]) and got[k] == want[k], k
 
 
 @pytest.mark.gpu
