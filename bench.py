@@ -55,36 +55,69 @@ def spawn_ranks_if_needed(gpus: int, script: str, argv: list) -> None:
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
+def dataset_spec(dataset):
+    """("gaussian" | "lowrank" | "clustered", parameter): "lowrank16" = intrinsic dimension 16 (default 32);
+    "clustered0.01" = within-cluster sigma 0.01 (default 0.1)."""
+    for kind in ("lowrank", "clustered", "gaussian"):
+        if dataset.startswith(kind):
+            rest = dataset[len(kind):]
+            return kind, (float(rest) if rest else {"lowrank": 32.0, "clustered": 0.1, "gaussian": 0.0}[kind])
+    raise SystemExit(f"bench.py: unknown dataset {dataset!r}")
+
+
+def dataset_note(dataset, dim):
+    """what the data is, with an intrinsic dimension a reader can hold the recall against"""
+    kind, par = dataset_spec(dataset)
+    if kind == "gaussian":
+        return f"isotropic standard normal, intrinsic dimension {dim} (the worst case for any graph index)"
+    if kind == "lowrank":
+        return f"x = zA + 0.02 eps, z in R^{int(par)}: intrinsic dimension {int(par)} + 2% isotropic noise, unit-normalised"
+    # 64 unit centres (nearly orthogonal in 768-d) + sigma*eps: covariance eigenvalues 64 x (1/64 + s^2), (dim-64) x s^2
+    s2 = par * par
+    pr = (1 + dim * s2) ** 2 / (64 * (1 / 64 + s2) ** 2 + (dim - 64) * s2 * s2)
+    return (f"64 Gaussian clusters, sigma {par:g}, unit-normalised (SURVEY 8d): participation-ratio dimension {pr:.0f}; inside a "
+            f"cluster the data is isotropic in all {dim} dimensions")
+
+
+def _gen_chunk(kind, par, dim, seed, c, m, shared):
+    """chunk c of a derived dataset: its own generator seeded by (seed, c), so that chunks can be drawn side by side"""
+    rng = np.random.default_rng([seed, c])
+    if kind == "lowrank":
+        r = int(par)
+        v = rng.standard_normal((m, r), dtype=np.float32) @ shared
+        v += np.float32(0.02) * rng.standard_normal((m, dim), dtype=np.float32)
+    else:
+        v = np.float32(par) * rng.standard_normal((m, dim), dtype=np.float32)
+        v += shared[rng.integers(0, 64, m)]
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    return v
+
+
 def gen_chunks(n, dim, seed, dataset, chunk=65536):
-    """Seeded synthetic vectors as a stream of 64k-row chunks — the same rows whatever is done with them."""
-    rng = np.random.default_rng(seed)
-    if dataset == "gaussian":
+    """Seeded synthetic vectors as a stream of 64k-row chunks — the same rows whatever is done with them.
+    gaussian: ONE default_rng(seed) stream, as the survey defines it.  The derived sets (lowrank*, clustered*) draw every chunk
+    from default_rng([seed, chunk index]), which lets a few host threads generate a million rows in seconds."""
+    kind, par = dataset_spec(dataset)
+    if kind == "gaussian":
+        rng = np.random.default_rng(seed)
         for a in range(0, n, chunk):
             yield rng.standard_normal((min(n, a + chunk) - a, dim), dtype=np.float32)
         return
-    if dataset == "lowrank":
-        # embedding-like data: intrinsic dimension 32 embedded in `dim` (x = zA + 0.02 eps), unit-normalised.
-        # Isotropic Gaussian and the sigma=0.1 "clustered" set are both ~768-dimensional intrinsically (the
-        # cluster noise 0.1*sqrt(768) dwarfs the unit centres), where every graph index has poor recall.
-        arng = np.random.default_rng(777)
-        A = arng.standard_normal((32, dim), dtype=np.float32) / np.float32(np.sqrt(32))
-        for a in range(0, n, chunk):
-            m = min(n, a + chunk) - a
-            v = rng.standard_normal((m, 32), dtype=np.float32) @ A
-            v += np.float32(0.02) * rng.standard_normal((m, dim), dtype=np.float32)
-            v /= np.linalg.norm(v, axis=1, keepdims=True)
+    if kind == "lowrank":
+        # embedding-like data: intrinsic dimension r embedded in `dim` (x = zA + 0.02 eps), unit-normalised.  Isotropic Gaussian
+        # and the sigma = 0.1 "clustered" set are both ~768-dimensional intrinsically (the cluster noise 0.1*sqrt(768) dwarfs
+        # the unit centres), where every graph index has poor recall.
+        r = int(par)
+        shared = np.random.default_rng(777).standard_normal((r, dim), dtype=np.float32) / np.float32(np.sqrt(r))
+    else:  # "clustered": 64 Gaussian clusters, sigma par, unit-normalised (SURVEY §8d); centres shared by base vectors and queries
+        shared = np.random.default_rng(4242).standard_normal((64, dim), dtype=np.float32)
+        shared /= np.linalg.norm(shared, axis=1, keepdims=True)
+    from concurrent.futures import ThreadPoolExecutor
+
+    starts = list(range(0, n, chunk))
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:  # (numpy's generators release the GIL)
+        for v in ex.map(lambda a: _gen_chunk(kind, par, dim, seed, a // chunk, min(n, a + chunk) - a, shared), starts):
             yield v
-        return
-    # "clustered": 64 Gaussian clusters, sigma 0.1, unit-normalised (SURVEY §8d) — mimics embeddings
-    crng = np.random.default_rng(4242)  # centres shared by base vectors and queries
-    centres = crng.standard_normal((64, dim), dtype=np.float32)
-    centres /= np.linalg.norm(centres, axis=1, keepdims=True)
-    for a in range(0, n, chunk):
-        m = min(n, a + chunk) - a
-        c = rng.integers(0, 64, m)
-        v = centres[c] + np.float32(0.1) * rng.standard_normal((m, dim), dtype=np.float32)
-        v /= np.linalg.norm(v, axis=1, keepdims=True)
-        yield v
 
 
 def gen_vectors(n, dim, seed, dataset, chunk=65536):
@@ -228,54 +261,91 @@ def wave_order_leg(pkg, args, dev_ord, M, EFC, X, Q):
     return out
 
 
-def recall_target_leg(pkg, args, dev_ord, order, M, EFC, target):
+def recall_target_leg(pkg, args, dev_ord, order, M, EFC, target, datasets):
     """north_star's target reads "kNN queries/s at recall@10 >= 0.95": isotropic 768-d Gaussian data cannot reach that
-    with the reference's algorithm at any practical ef, so the same measurement is repeated on
-    embedding-like data (intrinsic dimension 32, unit-normalised) with the smallest ef of a fixed ladder that reaches
-    the target.  Same index parameters, same kernel, same batch size; recall against device brute force."""
+    with the reference's algorithm at any practical ef.  The same measurement — same index parameters, same
+    kernel, same batch size, recall against device brute force over all queries — is therefore repeated on data whose
+    intrinsic dimension is STATED (embedding-like sets of intrinsic dimension 16 / 32 / 64, and SURVEY §8d's clustered set at
+    two sigmas), each with the smallest ef of a fixed ladder that reaches the target, or "not reached" up to ef 1024."""
     N, D, NQ, K = args.n, args.dim, args.nq, args.k
-    X = gen_vectors(N, D, 42, "lowrank")
-    Q = gen_vectors(NQ, D, 43, "lowrank")
-    g = pkg.HnswIndex(D, args.metric, M, EFC, order=order, device=dev_ord)
-    t0 = time.perf_counter()
-    if g.build(np.arange(1, N + 1, dtype=np.int64), X, 16, 8192) != 0:
-        raise SystemExit("build failed: " + pkg.hnsw._err())
-    g.sync()
-    build_s = time.perf_counter() - t0
-    dq = g.dev_malloc(Q.nbytes)
-    g.dev_upload(dq, Q)
-    d_ids, d_ds, d_cnt = g.dev_malloc(NQ * K * 8), g.dev_malloc(NQ * K * 4), g.dev_malloc(NQ * 4)
-    nrec = min(max(args.recall_queries, 1), NQ)
-    truth = g.bruteforce_topk(dq, nrec, K)
-    ladder, hit = [], None
-    for ef in (64, 128, 192, 256, 384, 512, 768, 1024):
-        if ef < K:
-            continue
-        g.search_batch_dev(dq, NQ, K, ef, d_ids, d_ds, d_cnt)  # warm-up
-        kms = []
-        for _ in range(5):
-            g.search_batch_dev(dq, NQ, K, ef, d_ids, d_ds, d_cnt)
-            st = g.last_launch()
-            kms.append(st["last_kernel_ms"])
+    rows = []
+    for ds in datasets:
+        progress(f"recall-target leg: {ds}")
+        X = gen_vectors(N, D, 42, ds)
+        Q = gen_vectors(NQ, D, 43, ds)
+        g = pkg.HnswIndex(D, args.metric, M, EFC, order=order, device=dev_ord)
         t0 = time.perf_counter()
-        for _ in range(5):
-            g.search_batch_dev(dq, NQ, K, ef, d_ids, d_ds, d_cnt)
+        if g.build(np.arange(1, N + 1, dtype=np.int64), X, 16, 8192) != 0:
+            raise SystemExit("build failed: " + pkg.hnsw._err())
         g.sync()
-        wall = (time.perf_counter() - t0) / 5
-        out = np.empty((NQ, K), np.int64)
-        g.dev_download(out, d_ids)
-        rec = recall_of(out[:nrec], truth, K)
-        alg = st["last_n_dist"] * D * 4 + st["last_n_expanded"] * (2 * M) * 4 + st["last_n_dist"] * 4
-        row = {"ef": ef, "queries_per_s": NQ / wall, "recall_at_10": rec, "n_dist_per_query": st["last_n_dist"] / NQ,
-               "kernel_ms": float(np.mean(kms)), "roofline_frac": alg / (np.mean(kms) * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        ladder.append(row)
-        if rec >= target:
-            hit = row
-            break
-    g.close()
-    return {"target_recall_at_10": target, "dataset": f"{N}x{D} f32 lowrank (intrinsic dim 32 + 2% noise, unit-normalised), "
-            f"{NQ} queries, k={K}, {args.metric}, M={M} efC={EFC}", "recall_queries": nrec,
-            "build_vectors_per_s": N / build_s, "reached": hit, "ladder": ladder}
+        build_s = time.perf_counter() - t0
+        del X
+        dq = g.dev_malloc(Q.nbytes)
+        g.dev_upload(dq, Q)
+        d_ids, d_ds, d_cnt = g.dev_malloc(NQ * K * 8), g.dev_malloc(NQ * K * 4), g.dev_malloc(NQ * 4)
+        nrec = min(max(args.recall_queries, 1), NQ)
+        truth = g.bruteforce_topk(dq, nrec, K)
+        ladder, hit = [], None
+        for ef in (64, 128, 256, 512, 1024):
+            if ef < K:
+                continue
+            g.search_batch_dev(dq, NQ, K, ef, d_ids, d_ds, d_cnt)  # warm-up
+            g.sync()
+            kms = []
+            t0 = time.perf_counter()
+            for _ in range(3):  # (per-launch HIP-event time and the wall time of the same three launches)
+                g.search_batch_dev(dq, NQ, K, ef, d_ids, d_ds, d_cnt)
+                st = g.last_launch()
+                kms.append(st["last_kernel_ms"])
+            wall = (time.perf_counter() - t0) / 3
+            out = np.empty((NQ, K), np.int64)
+            g.dev_download(out, d_ids)
+            rec = recall_of(out[:nrec], truth, K)
+            alg = st["last_n_dist"] * D * 4 + st["last_n_expanded"] * (2 * M) * 4 + st["last_n_dist"] * 4
+            row = {"ef": ef, "queries_per_s": NQ / wall, "recall_at_10": rec, "n_dist_per_query": st["last_n_dist"] / NQ,
+                   "kernel_ms": float(np.mean(kms)), "roofline_frac": alg / (np.mean(kms) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            ladder.append(row)
+            if rec >= target:
+                hit = row
+                break
+        g.close()
+        rows.append({"dataset": ds, "what": dataset_note(ds, D), "build_vectors_per_s": N / build_s,
+                     "reached": hit if hit else f"not reached up to ef {ladder[-1]['ef']} (recall {ladder[-1]['recall_at_10']:.3f})",
+                     "ladder": ladder})
+    return {"target_recall_at_10": target,
+            "setup": f"{N}x{D} f32, {NQ} queries, k={K}, {args.metric}, M={M} efC={EFC}; recall over {min(max(args.recall_queries, 1), NQ)} "
+                     f"queries against k_brute_mfma", "datasets": rows}
+
+
+def host_cpu():
+    """model name and core counts of the host the CPU baselines ran on (north_star: "count stated")"""
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        vis = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        vis = os.cpu_count()
+    return {"model": model, "logical_cpus": os.cpu_count(), "visible_to_this_process": vis}
+
+
+def kernel_sources_sha(files):
+    """sha-256 over the sources a kernel is compiled from: profiles/traffic.json stamps a PMC measurement with it, and a
+    measurement whose kernel has changed since is not reported (it would silently go stale otherwise)"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in files:
+        try:
+            h.update(open(os.path.join(ROOT, "sqlite-muninn_amd", "csrc", f), "rb").read())
+        except OSError:
+            return None
+    return h.hexdigest()
 
 
 def main():
@@ -290,7 +360,8 @@ def main():
     ap.add_argument("--ef", type=int, default=128)
     ap.add_argument("--metric", default="cosine")
     ap.add_argument("--order", default="sse", choices=["sse", "wave"])
-    ap.add_argument("--dataset", default="gaussian", choices=["gaussian", "clustered", "lowrank"])
+    ap.add_argument("--dataset", default="gaussian",
+                    help="gaussian | lowrank[R] (intrinsic dimension R, default 32) | clustered[SIGMA] (default 0.1)")
     ap.add_argument("--recall-queries", type=int, default=-1,
                     help="queries whose exact top-k (k_brute_mfma, the MFMA GEMM + fused top-k) recall is measured against; -1 = all")
     ap.add_argument("--quality-n", type=int, default=50_000,
@@ -310,7 +381,11 @@ def main():
     ap.add_argument("--recall-target", type=float, default=0.95,
                     help="N=1, gaussian only: also report q/s at the smallest ef reaching this recall@10 on "
                          "embedding-like data (0 = skip)")
-    ap.add_argument("--ef-sweep", default="", help="comma list of extra ef values to report (q/s, recall)")
+    ap.add_argument("--ef-sweep", default="auto",
+                    help="comma list of ef values reported next to the headline (q/s, recall, distances per query) on the same "
+                         "index; auto = 128,256,512 at N=1 and nothing for N>1; '' = none")
+    ap.add_argument("--target-datasets", default="lowrank16,lowrank32,lowrank64,clustered,clustered0.01",
+                    help="datasets of the recall-target leg (each builds its own full-size index)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL over xGMI; gloo only to rehearse the N>1 path on one GPU)")
     ap.add_argument("--device", type=int, default=-1, help="HIP device ordinal (default: LOCAL_RANK)")
@@ -318,6 +393,7 @@ def main():
                     help="N>1: replica = same index on every GPU, queries sharded (no collective); sharded = config 3: "
                          "rowid mod N shards, same queries everywhere, RCCL all-gather + merge of per-shard top-k")
     args = ap.parse_args()
+    dataset_spec(args.dataset)
     spawn_ranks_if_needed(args.gpus, os.path.abspath(__file__), sys.argv[1:])
 
     rank = int(os.environ.get("RANK", "0"))
@@ -454,7 +530,9 @@ def main():
     run_steps(args.warmup, EF)
     barrier()
     t0 = time.perf_counter()
-    run_steps(args.steps, EF)  # K launches back-to-back on the index's stream
+    # K launches on the index's stream; every launch is followed by the read-back of its HIP events and device counters (a
+    # few bytes; its synchronisation is inside the timed region), so that kernel_ms and ms_per_step come from the SAME launches
+    kms, n_dist, n_exp = run_steps(args.steps, EF, collect=True)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -464,8 +542,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- per-kernel time + algorithmic bytes, measured live with HIP events ----
-    kms, n_dist, n_exp = run_steps(max(3, min(args.steps, 10)), EF, collect=True)
+    # ---- per-kernel time + algorithmic bytes, measured live with HIP events over the timed launches ----
     kernel_ms = float(np.mean(kms))
     # bytes/query = n_dist*dim*4 (candidate rows) + n_expanded*2M*4 (link rows) + n_dist*4 (visited)
     alg_bytes = n_dist * D * 4 + n_exp * (2 * M) * 4 + n_dist * 4
@@ -486,6 +563,8 @@ def main():
         recall = recall_of(out_ids[:nrec], truth, K)
 
     sweep = []
+    if args.ef_sweep == "auto":
+        args.ef_sweep = "128,256,512" if world == 1 and not streamed else ""
     for ef2 in [int(x) for x in args.ef_sweep.split(",") if x]:
         run_steps(1, ef2)
         g.sync()
@@ -493,7 +572,9 @@ def main():
         o2 = np.empty((NQ, K), np.int64)
         g.dev_download(o2, d_ids)
         r2 = recall_of(o2[:nrec], truth, K) if nrec else None
-        sweep.append({"ef": ef2, "queries_per_s": NQ / (np.mean(k2) * 1e-3), "recall_at_k": r2, "n_dist_per_query": nd2 / NQ})
+        ab2 = nd2 * D * 4 + ne2 * (2 * M) * 4 + nd2 * 4
+        sweep.append({"ef": ef2, "queries_per_s": NQ / (np.mean(k2) * 1e-3), "recall_at_k": r2, "n_dist_per_query": nd2 / NQ,
+                      "kernel_ms": float(np.mean(k2)), "roofline_frac": ab2 / (np.mean(k2) * 1e-3) / 1e9 / HBM_PEAK_GBS})
 
     # ---- CPU baseline: the oracle (single-threaded port of the reference algorithm) on the SAME
     #      graph and the SAME queries; also a full-size parity check of the returned ids ----
@@ -580,13 +661,21 @@ def main():
                                  "new_nodes_lists_identical_to_reference": bool(same)}
             del r
 
-    # HBM traffic per launch from the committed PMC passes (profiles/traffic.json), when this exact workload was profiled
-    traffic = None
+    # HBM traffic per launch from the committed PMC passes (profiles/traffic.json), when this exact workload was profiled AND
+    # the kernel's sources are still the ones it was measured on (the entry carries their sha-256)
+    traffic, traffic_note = None, None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         key = f"{N}x{D}_{args.dataset}_{args.order}_nq{NQ}_k{K}_ef{EF}"
         if key in tj:
-            traffic = tj[key]["traffic_bytes"]
+            ent = tj[key]
+            now = kernel_sources_sha(ent.get("kernel_sources", []))
+            if ent.get("kernel_sources_sha256") and now == ent["kernel_sources_sha256"]:
+                traffic = ent["traffic_bytes"]
+                traffic_note = f"rocprofv3 --pmc passes of round {ent.get('measured_in_round')} at commit {ent.get('measured_at_commit')}; " \
+                               f"kernel sources unchanged since (sha-256 {now[:12]})"
+            else:
+                traffic_note = "the committed PMC measurement is for other kernel sources than the ones built here: not reported"
     except (OSError, ValueError):
         pass
 
@@ -603,8 +692,8 @@ def main():
             g.close()  # make room: the second index is the same size
         g = None
         X = None
-        progress("recall-target leg: lowrank data, ef ladder")
-        at_target = recall_target_leg(pkg, args, dev_ord, order, M, EFC, args.recall_target)
+        at_target = recall_target_leg(pkg, args, dev_ord, order, M, EFC, args.recall_target,
+                                      [d for d in args.target_datasets.split(",") if d])
     if rank == 0 and world == 1 and args.quality_n > 0:
         quality = graph_quality_leg(pkg, args, dev_ord, order, M, EFC, min(args.quality_n, N),
                                     [d for d in args.quality_datasets.split(",") if d], (128, 256))
@@ -659,7 +748,7 @@ def main():
             "ef_sweep": sweep,
             "at_recall_target": at_target,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_beam",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note, "kernel": "k_beam",
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          # also against what a float4 copy kernel reaches on this part
                          "frac_of_measured_copy_bw": achieved / HBM_COPY_GBS, "measured_copy_bw": HBM_COPY_GBS},
@@ -667,7 +756,7 @@ def main():
                 "kernel": "k_brute_mfma (v_mfma_f32_32x32x2_f32 GEMM tile + fused top-k)", "queries": nrec,
                 "kernel_ms": brute_ms, "wall_s": brute_s,
                 "tflops": 2.0 * nrec * N * D / (brute_ms * 1e-3) / 1e12 if brute_ms else None},
-            "cpu_baseline": cpu,
+            "cpu_baseline": dict(cpu, host=host_cpu()) if cpu else None,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -24,14 +24,21 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0
+from bench import host_cpu  # noqa: E402  (model name and core counts of the host the CPU baselines ran on)
 
 
 def _traffic(key):
-    """HBM-side bytes of one run from the committed PMC passes (profiles/traffic.json), when this workload was profiled."""
+    """HBM-side bytes of one run from the committed PMC passes (profiles/traffic.json), when this workload was profiled and
+    the kernel's sources are still the ones it was measured on (bench.py kernel_sources_sha)."""
+    from bench import kernel_sources_sha
+
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[key]["traffic_bytes"]
+        ent = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[key]
     except (OSError, ValueError, KeyError):
         return None
+    if not ent.get("kernel_sources_sha256") or kernel_sources_sha(ent.get("kernel_sources", [])) != ent["kernel_sources_sha256"]:
+        return None
+    return ent["traffic_bytes"]
 
 
 def er_edges(n, m, seed=42):
@@ -152,7 +159,7 @@ def bench_node2vec(pkg, args):
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "k_n2v_walk_grad + rocPRIM radix sort + k_n2v_apply (whole pipeline)",
                      "kernel_ms": dev_ms, "algorithmic_bytes_per_launch": alg},
-        "cpu_baseline": {"value": cpairs / cpu_s, "unit": "pairs/s", "cores": 1, "kind": "port",
+        "cpu_baseline": {"value": cpairs / cpu_s, "unit": "pairs/s", "cores": 1, "kind": "port", "host": host_cpu(),
                          "sample": f"serial walk+SGNS restatement (oracle/mn_graph_oracle.c) on an ER graph of {cn} nodes with "
                                    f"the same mean degree and parameters: {cpairs} pairs in {cpu_s:.1f}s"},
     }
@@ -225,7 +232,7 @@ def bench_leiden(pkg, args):
                      "traffic": _traffic("leiden_lfr500k_9.27M_batched_default") if n == 500_000 else None,
                      "kernel": "k_leiden_eval / k_leiden_win / k_leiden_apply rounds (whole run_leiden)", "kernel_ms": dev_ms,
                      "algorithmic_bytes_per_launch": alg},
-        "cpu_baseline": {"value": E / cpu_s, "unit": "edges/s", "cores": 1, "kind": "port",
+        "cpu_baseline": {"value": E / cpu_s, "unit": "edges/s", "cores": 1, "kind": "port", "host": host_cpu(),
                          "sample": f"the same graph, reference's sequential schedule (oracle/mn_graph_oracle.c, dedup by hashing "
                                    f"instead of the reference's O(n_neigh^2) scan): {cpu_s:.1f}s"},
     }
