@@ -999,6 +999,7 @@ static int run_speculative(mn_index *x, const std::vector<int> &slots) {
     if (x->ws_ncommit.reserve(1, false, st)) return -1;
     int window = 16, poor = 0;
     long long searched = 0, rounds = 0, plain = 0;
+    double t_search = 0, t_commit = 0; // device ms (HIP events), reported under MN_SPEC_TRACE
     for (int pos = 0; pos < n;) {
         if (poor >= 8) {
             // a small index: nearly every search crosses the previous insert's rows, so windows commit one insert at a
@@ -1030,10 +1031,17 @@ static int run_speculative(mn_index *x, const std::vector<int> &slots) {
         mn_launch_spec_commit(v, x->ws_qslots.p, W, a.nlev, x->ws_sel.p, x->ws_nsel.p, x->ws_readlog.p, LOG_CAP, x->ws_nread.p,
                               x->d_stamp0.p, x->d_stampU.p, x->spec_epoch, x->ws_ncommit.p, st);
         HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(x->ev2, st));
         int done = 0;
         HIPCHK(hipMemcpyAsync(&done, x->ws_ncommit.p, sizeof(int), hipMemcpyDeviceToHost, st));
         if (fetch_counters(x)) // synchronises
             return -1;
+        {
+            float ms = 0;
+            t_search += x->last.last_kernel_ms;
+            if (hipEventElapsedTime(&ms, x->ev1, x->ev2) == hipSuccess)
+                t_commit += ms;
+        }
         if (x->last.last_n_overflow) {
             set_err("mn_hnsw_insert: heap workspace exceeded");
             return -1;
@@ -1060,8 +1068,9 @@ static int run_speculative(mn_index *x, const std::vector<int> &slots) {
     x->host_links_valid = false;
     x->last_spec_searched = searched;
     if (getenv("MN_SPEC_TRACE"))
-        fprintf(stderr, "[mn_spec] %d inserts: %lld rounds (%.1f committed per round), %lld searches, %lld by k_insert_seq\n", n,
-                rounds, rounds ? (double)(n - plain) / rounds : 0.0, searched, plain);
+        fprintf(stderr, "[mn_spec] %d inserts: %lld rounds (%.1f committed per round), %lld searches, %lld by k_insert_seq; device ms "
+                        "per round: search %.2f commit %.2f\n", n, rounds, rounds ? (double)(n - plain) / rounds : 0.0, searched, plain,
+                rounds ? t_search / rounds : 0.0, rounds ? t_commit / rounds : 0.0);
     return 0;
 }
 
