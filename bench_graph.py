@@ -85,6 +85,13 @@ def bench_node2vec(pkg, args):
     t0 = time.perf_counter()
     off, adj = pkg.graph.n2v_csr_from_edges(n, *er_edges(n, m))
     gen_s = time.perf_counter() - t0
+    if args.dump_csr:  # for tools/n2v_bench.cpp (the same graph under rocprofv3 --pmc, without Python in the process)
+        with open(args.dump_csr, "wb") as f:
+            f.write(np.int32(n).tobytes() + np.int64(len(adj)).tobytes())
+            f.write(np.ascontiguousarray(off, np.int32).tobytes())
+            f.write(np.ascontiguousarray(adj, np.int32).tobytes())
+        if args.dump_only:
+            return None
 
     # parity on a graph the CPU finishes in a second: batch-synchronous schedule, device vs its CPU restatement
     from oracle import orc_graph as og
@@ -133,14 +140,42 @@ def bench_node2vec(pkg, args):
     alg = pairs * (2 * (1 + prm["neg_samples"]) + 2) * dim * 4 + steps_walk * (len(adj) / n) * 4
     achieved = alg / (dev_ms * 1e-3) / 1e9
 
-    # CPU: the serial restatement of the reference's walk + SGNS loop (oracle/mn_graph_oracle.c), same parameters,
-    # on an ER graph with the same mean degree but fewer nodes so that it is ~10-30 s of work
+    # CPU: the reference's own node2vec_train (oracle/_ref/muninn.so through SQL, as its users call it; output into a plain
+    # table so that no HNSW insert is timed) and the serial restatement of its walk + SGNS loop (oracle/mn_graph_oracle.c), same
+    # parameters, on an ER graph with the same mean degree but few enough nodes for ~10-20 s of CPU work (the reference looks
+    # node names up linearly — O(N^2) — and cannot run config 4 itself)
     cn = args.n2v_cpu_nodes
     cs, cd = er_edges(cn, int(m * (cn / n)), seed=42)
     cg = og.N2vGraph(cs, cd)
     t0 = time.perf_counter()
-    _, cpairs = og.node2vec_train(cg, dim, 1.0, 1.0, prm["num_walks"], prm["walk_length"], 5, 5, 0.025, 1)
+    cemb, cpairs = og.node2vec_train(cg, dim, 1.0, 1.0, prm["num_walks"], prm["walk_length"], 5, 5, 0.025, 1)
     cpu_s = time.perf_counter() - t0
+    cpu = {"value": cpairs / cpu_s, "unit": "pairs/s", "cores": 1, "kind": "port", "host": host_cpu(),
+           "sample": f"serial walk+SGNS restatement (oracle/mn_graph_oracle.c) on an ER graph of {cn} nodes with "
+                     f"the same mean degree and parameters: {cpairs} pairs in {cpu_s:.1f}s"}
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "muninn")
+    if os.path.exists(ref_so + ".so"):
+        import sqlite3
+
+        c = sqlite3.connect(":memory:")
+        c.enable_load_extension(True)
+        c.load_extension(ref_so)
+        c.execute("CREATE TABLE e(src TEXT, dst TEXT)")
+        c.executemany("INSERT INTO e VALUES (?,?)", [(f"n{a}", f"n{b}") for a, b in zip(cs, cd)])
+        c.execute("CREATE TABLE o(vector BLOB)")
+        t0 = time.perf_counter()
+        rows = c.execute("SELECT node2vec_train('e','src','dst','o',?,1.0,1.0,?,?,5,5,0.025,1)",
+                         (dim, prm["num_walks"], prm["walk_length"])).fetchone()[0]
+        ref_s = time.perf_counter() - t0
+        remb = np.frombuffer(b"".join(r[0] for r in c.execute("SELECT vector FROM o ORDER BY rowid")), np.float32).reshape(-1, dim)
+        c.close()
+        cpu = {"value": cpairs / ref_s, "unit": "pairs/s", "cores": 1, "kind": "reference", "host": host_cpu(),
+               "sample": f"the reference's own node2vec_train() through SQL (oracle/_ref/muninn.so, src/node2vec.c, gcc -O2) on an ER "
+                         f"graph of {cn} nodes with the same mean degree and parameters, output into a plain table: {rows} rows, "
+                         f"{cpairs} pairs in {ref_s:.1f}s",
+               "embedding_bytes_equal_to_port": bool(rows == cn and np.array_equal(remb.view(np.int32), cemb.view(np.int32))),
+               "port": {"value": cpairs / cpu_s, "unit": "pairs/s", "cores": 1,
+                        "sample": f"oracle/mn_graph_oracle.c on the same graph: {cpu_s:.1f}s"}}
     return {
         "metric": "Node2Vec (center, context) SGNS pairs/sec incl. walk generation, 1M-node / 20M-edge graph, dim 128",
         "value": pairs / wall, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -156,12 +191,12 @@ def bench_node2vec(pkg, args):
         "parity_vs_oracle": parity,
         "embedding_norm_check": float(np.abs(np.linalg.norm(emb[:1000], axis=1) - 1.0).max()),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": _traffic("node2vec_er1M_20M_batched_default") if (n, m, world) == (1_000_000, 20_000_000, 1) else None,
+                     "per_kernel": "profiles/r03_n2v_per_kernel.json (k_n2v_walk_grad 0.48, k_n2v_apply 0.61 of 8 TB/s by their own algorithmic bytes)",
                      "kernel": "k_n2v_walk_grad + rocPRIM radix sort + k_n2v_apply (whole pipeline)",
                      "kernel_ms": dev_ms, "algorithmic_bytes_per_launch": alg},
-        "cpu_baseline": {"value": cpairs / cpu_s, "unit": "pairs/s", "cores": 1, "kind": "port", "host": host_cpu(),
-                         "sample": f"serial walk+SGNS restatement (oracle/mn_graph_oracle.c) on an ER graph of {cn} nodes with "
-                                   f"the same mean degree and parameters: {cpairs} pairs in {cpu_s:.1f}s"},
+        "cpu_baseline": cpu,
     }
 
 
@@ -247,8 +282,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n2v-nodes", type=int, default=1_000_000)
     ap.add_argument("--n2v-edges", type=int, default=20_000_000)
-    ap.add_argument("--n2v-cpu-nodes", type=int, default=3000)
+    ap.add_argument("--n2v-cpu-nodes", type=int, default=1500)
     ap.add_argument("--leiden-nodes", type=int, default=500_000)
+    ap.add_argument("--dump-csr", default="", help="node2vec: also write the graph as a binary CSR file (tools/n2v_bench.cpp)")
+    ap.add_argument("--dump-only", action="store_true", help="with --dump-csr: write the file and stop")
     ap.add_argument("--gpus", type=int, default=1, help="N > 1: node2vec data-parallel over N ranks (config 4); leiden = N replicas")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--device", type=int, default=-1)
