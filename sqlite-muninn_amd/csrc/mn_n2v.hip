@@ -351,8 +351,9 @@ static int session_init(mn_n2v_session *S, int n, const int *off, const int *adj
     NCHK(hipMalloc(&S->adj, std::max<size_t>(1, ne) * sizeof(int)));
     NCHK(hipMalloc(&S->neg, N2V_NEG_TABLE * sizeof(int)));
     NCHK(hipMalloc(&S->sig, (N2V_SIG_SIZE + 1) * sizeof(float)));
-    NCHK(hipMalloc(&S->syn0, nd * sizeof(float)));
-    NCHK(hipMalloc(&S->syn1, nd * sizeof(float)));
+    // (+ 64 rows: the data-parallel mode all-gathers equal row shards of up to 64 ranks in place, ceil(n / world) * world rows)
+    NCHK(hipMalloc(&S->syn0, (nd + (size_t)64 * dim) * sizeof(float)));
+    NCHK(hipMalloc(&S->syn1, (nd + (size_t)64 * dim) * sizeof(float)));
     NCHK(hipMalloc(&S->pairs, 2 * sizeof(unsigned long long)));
     NCHK(hipMemcpy(S->off, off, ((size_t)n + 1) * sizeof(int), hipMemcpyHostToDevice));
     if (ne)
@@ -511,6 +512,12 @@ extern "C" int mn_node2vec_train_shared(mn_comm *c, int n, const int *off, const
         return -1;
     const int B = S->B, cap = S->cap, pcap = prm->walk_length, dim = prm->dim;
     const int per_max = (B + world - 1) / world;
+    const int rows_per = (n + world - 1) / world; // destination rows per rank (equal shards: the last one is padded)
+    if (world > 64) {
+        nset_err("mn_node2vec_train_shared: more than 64 ranks");
+        mn_n2v_end(S);
+        return -1;
+    }
     int *lc = nullptr, *lt = nullptr, *lpc = nullptr, *gc = nullptr, *gt = nullptr, *gpc = nullptr;
     float *le = nullptr, *lpn = nullptr, *ge = nullptr, *gpn = nullptr;
     auto cleanup = [&](int rc) {
@@ -592,9 +599,20 @@ extern "C" int mn_node2vec_train_shared(mn_comm *c, int n, const int *off, const
                     rc = -1;
                     break;
                 }
-                if (n2v_apply(S, gc, gt, ge, (int64_t)world * per * cap, gpc, gpn, (int64_t)world * per * pcap)) {
+                // every rank has the whole batch's samples; it applies them to ITS shard of the destination rows only (a row's
+                // additions are the same, in the same order, whoever owns it) and the updated shards of both matrices are
+                // all-gathered in place: the apply half — 38 % of a batch on one GPU — is divided by the rank count too
+                if (n2v_apply(S, gc, gt, ge, (int64_t)world * per * cap, gpc, gpn, (int64_t)world * per * pcap, rank * rows_per,
+                              (rank + 1) * rows_per)) {
                     status = 1; // (reported to the peers at the head of the next batch, or below after the last one)
                     mine = mn_node2vec_last_error();
+                }
+                if (world > 1 &&
+                    (mn_comm_allgather_dev(c, S->syn1 + (size_t)rank * rows_per * dim, S->syn1, (size_t)rows_per * dim * 4, S->st) ||
+                     mn_comm_allgather_dev(c, S->syn0 + (size_t)rank * rows_per * dim, S->syn0, (size_t)rows_per * dim * 4, S->st))) {
+                    nset_err("mn_node2vec_train_shared: %s", mn_comm_last_error_str());
+                    rc = -1;
+                    break;
                 }
             }
     if (rc == 0)

@@ -320,8 +320,8 @@ __global__ void k_n2v_segments(const int *keys_sorted, int n_samples, int n_node
 template <int NR>
 __global__ void __launch_bounds__(64)
     k_n2v_apply(const int *keys_sorted, const int *vals_sorted, const int *seg_start, int n_samples, const int *other,
-                const float *s_err, const float *dst_old, const float *src_mat, float *dst_out, int dim) {
-    const int k = blockIdx.x; // destination row
+                const float *s_err, const float *dst_old, const float *src_mat, float *dst_out, int dim, int row0) {
+    const int k = row0 + blockIdx.x; // destination row (row0: first row of this rank's shard)
     int j = seg_start[k];
     if (j < 0)
         return;
@@ -392,8 +392,8 @@ __global__ void __launch_bounds__(64)
 template <int NR>
 __global__ void __launch_bounds__(64)
     k_n2v_apply_centers(const int *keys_sorted, const int *vals_sorted, const int *seg_start, int n_pos, const float *p_neu,
-                        const float *dst_old, float *dst_out, int dim) {
-    const int k = blockIdx.x;
+                        const float *dst_old, float *dst_out, int dim, int row0) {
+    const int k = row0 + blockIdx.x;
     int j = seg_start[k];
     if (j < 0)
         return;
@@ -424,8 +424,8 @@ __global__ void __launch_bounds__(64)
 }
 
 __global__ void __launch_bounds__(64)
-    k_n2v_commit(const int *seg_start, const float *staged, float *dst, int dim) {
-    const int k = blockIdx.x;
+    k_n2v_commit(const int *seg_start, const float *staged, float *dst, int dim, int row0) {
+    const int k = row0 + blockIdx.x;
     if (seg_start[k] < 0)
         return;
     for (int d = threadIdx.x; d < dim; d += 64)
@@ -503,9 +503,12 @@ static int n2v_samples_t(mn_n2v_session *S, int epoch, int w, int lo, int hi, in
 
 template <int NR>
 static int n2v_apply_t(mn_n2v_session *S, const int *d_center, const int *d_target, const float *d_err, int64_t ns64,
-                       const int *d_pcenter, const float *d_pneu, int64_t np64) {
+                       const int *d_pcenter, const float *d_pneu, int64_t np64, int row0, int row1) {
+    // rows [row0, row1): the destination rows this call updates (everything: 0, n; a rank of the data-parallel mode: its shard)
     const N2vArgs &a = S->a;
     const int N = a.n, dim = a.dim;
+    row1 = std::min(row1, N);
+    const unsigned nrows = (unsigned)std::max(0, row1 - row0);
     if (ns64 <= 0 || np64 <= 0)
         return 0;
     if ((size_t)ns64 > S->ns_max || (size_t)np64 > S->np_max) {
@@ -524,8 +527,9 @@ static int n2v_apply_t(mn_n2v_session *S, const int *d_center, const int *d_targ
     }
     NCHK(hipMemsetAsync(S->seg_c, 0xFF, (size_t)N * sizeof(int), S->st));
     hipLaunchKernelGGL(k_n2v_segments, dim3(p256), dim3(256), 0, S->st, S->keys_c, np, N, S->seg_c);
-    hipLaunchKernelGGL((k_n2v_apply_centers<NR>), dim3(N), dim3(64), 0, S->st, S->keys_c, S->vals_s, S->seg_c, np, d_pneu, a.syn0,
-                       S->staged, dim);
+    if (nrows)
+        hipLaunchKernelGGL((k_n2v_apply_centers<NR>), dim3(nrows), dim3(64), 0, S->st, S->keys_c, S->vals_s, S->seg_c, np, d_pneu,
+                           a.syn0, S->staged, dim, row0);
     // targets: syn1neg[t] += Σ err · syn0_old[c]  (syn0 is still the old one) → in place
     hipLaunchKernelGGL(k_n2v_keys, dim3(g256), dim3(256), 0, S->st, d_target, ns, N, S->keys, S->vals);
     if (rocprim::radix_sort_pairs(S->tmp, S->tmp_bytes, S->keys, S->keys_s, S->vals, S->vals_s, (size_t)ns, 0, S->bits, S->st) !=
@@ -535,9 +539,11 @@ static int n2v_apply_t(mn_n2v_session *S, const int *d_center, const int *d_targ
     }
     NCHK(hipMemsetAsync(S->seg, 0xFF, (size_t)N * sizeof(int), S->st));
     hipLaunchKernelGGL(k_n2v_segments, dim3(g256), dim3(256), 0, S->st, S->keys_s, ns, N, S->seg);
-    hipLaunchKernelGGL((k_n2v_apply<NR>), dim3(N), dim3(64), 0, S->st, S->keys_s, S->vals_s, S->seg, ns, d_center, d_err,
-                       a.syn1neg, a.syn0, a.syn1neg, dim);
-    hipLaunchKernelGGL(k_n2v_commit, dim3(N), dim3(64), 0, S->st, S->seg_c, S->staged, a.syn0, dim);
+    if (nrows) {
+        hipLaunchKernelGGL((k_n2v_apply<NR>), dim3(nrows), dim3(64), 0, S->st, S->keys_s, S->vals_s, S->seg, ns, d_center, d_err,
+                           a.syn1neg, a.syn0, a.syn1neg, dim, row0);
+        hipLaunchKernelGGL(k_n2v_commit, dim3(nrows), dim3(64), 0, S->st, S->seg_c, S->staged, a.syn0, dim, row0);
+    }
     NCHK(hipGetLastError());
     return 0;
 }
@@ -556,6 +562,6 @@ static int n2v_samples(mn_n2v_session *S, int epoch, int w, int lo, int hi, int 
     N2V_DISPATCH(n2v_samples_t, S, epoch, w, lo, hi, c, t, e, pc, pn);
 }
 static int n2v_apply(mn_n2v_session *S, const int *c, const int *t, const float *e, int64_t ns, const int *pc, const float *pn,
-                     int64_t np) {
-    N2V_DISPATCH(n2v_apply_t, S, c, t, e, ns, pc, pn, np);
+                     int64_t np, int row0 = 0, int row1 = 0x7fffffff) {
+    N2V_DISPATCH(n2v_apply_t, S, c, t, e, ns, pc, pn, np, row0, row1);
 }
