@@ -110,7 +110,7 @@ def test_merge_tie_rule_single_process():
         dist.destroy_process_group()
 
 
-def _n2v_worker(rank, world, port, q):
+def _n2v_worker(rank, world, port, q, n_nodes=1200):
     import sys
 
     sys.path.insert(0, ROOT)
@@ -121,7 +121,7 @@ def _n2v_worker(rank, world, port, q):
     from oracle import orc_graph as og
     from oracle.graph_cases import planted
 
-    s, d, _ = planted(1200, 6, 0.08, 0.002, 7)
+    s, d, _ = planted(n_nodes, 6, 0.08, 0.002, 7)
     g = og.N2vGraph(s, d)
     emb, st = muninn_amd.pkg.parallel.node2vec_train_distributed(g.off, g.adj, 32, 1.0, 1.0, 2, 20, 3, 3, 0.025, 1, batch_walks=50)
     q.put((rank, emb, st))
@@ -130,20 +130,21 @@ def _n2v_worker(rank, world, port, q):
 
 
 @pytest.mark.gpu
-def test_node2vec_data_parallel_world2_bit_identical_to_one_gpu(gpu):
-    """Two ranks (gloo exchange, both on the one GPU of the box) train data-parallel; every replica must equal the
-    single-process MN_N2V_BATCHED result bit for bit, which itself equals the CPU restatement."""
+@pytest.mark.parametrize("world,n_nodes", [(2, 1200), (4, 1206)])
+def test_node2vec_data_parallel_world2_bit_identical_to_one_gpu(gpu, world, n_nodes):
+    """Several ranks (gloo exchange, all on the one GPU of the box) train data-parallel — walk slices, samples all-gathered,
+    the apply half sharded by destination row (1 206 rows over 4 ranks: a padded last shard) and the row shards all-gathered;
+    every replica must equal the single-process MN_N2V_BATCHED result bit for bit, which itself equals the CPU restatement."""
     from oracle import orc_graph as og
     from oracle.graph_cases import planted
 
-    s, d, _ = planted(1200, 6, 0.08, 0.002, 7)
+    s, d, _ = planted(n_nodes, 6, 0.08, 0.002, 7)
     g = og.N2vGraph(s, d)
     single, st1 = gpu.node2vec_train(g.off, g.adj, 32, 1.0, 1.0, 2, 20, 3, 3, 0.025, 1, mode=gpu.N2V_BATCHED, batch_walks=50)
-    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_n2v_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_n2v_worker, args=(r, world, port, q, n_nodes)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(_collect(procs, q, world, 300), key=lambda r: r[0])
@@ -254,14 +255,14 @@ def test_a_rank_local_failure_stops_every_rank_instead_of_hanging_the_job(gpu, w
     assert "rank 1 failed" in res[1] and "injected failure" in res[1], res
 
 
-def _run_entry(script, extra):
-    """`python <script> --gpus 2 ...` exactly as the driver starts it (no torchrun on the command line): the script
-    itself must start its two ranks; both share the box's one GPU (gloo exchange)."""
+def _run_entry(script, extra, gpus=2):
+    """`python <script> --gpus N ...` exactly as the driver starts it (no torchrun on the command line): the script
+    itself must start its N ranks; they all share the box's one GPU (gloo exchange)."""
     import json
     import subprocess
     import sys
 
-    cmd = [sys.executable, os.path.join(ROOT, script), "--gpus", "2", "--backend", "gloo"] + extra
+    cmd = [sys.executable, os.path.join(ROOT, script), "--gpus", str(gpus), "--backend", "gloo"] + extra
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -286,6 +287,33 @@ def test_bench_graph_entry_runs_node2vec_data_parallel(gpu):
                                           "--n2v-edges", "200000", "--n2v-cpu-nodes", "300"])
     assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["value"] > 0
     assert lines[0]["parity_vs_oracle"]["embedding_bits_identical"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["replica", "sharded"])
+def test_bench_entry_with_more_ranks_and_sizes_the_rank_count_does_not_divide(gpu, mode):
+    """Rehearsal of the driver's N = 4 / 8 runs as far as one box allows (at most 6 processes may hold its GPU, this one
+    included): 4 ranks, with a vector count, a query count and a batch schedule that 4 does not divide — joint build (search
+    slices of unequal size, padded all-gather), query shards of unequal size, the sharded index with its 4-way merge — through
+    the same entry point and the same code below the C-ABI (host transport instead of RCCL)."""
+    lines = _run_entry("bench.py", ["--steps", "2", "--warmup", "1", "--num-vectors", "20003", "--dim", "48", "--nq", "501",
+                                    "--recall-queries", "100", "--no-cpu-baseline", "--recall-target", "0", "--mode", mode], gpus=4)
+    assert len(lines) == 1
+    j = lines[0]
+    assert j["n_gpus"] == 4 and j["value"] > 0 and j["roofline"]["frac"] > 0
+    if mode == "replica":
+        assert j["recall_at_10"] is not None and j["recall_at_10"] > 0.5  # the jointly built graph answers queries
+
+
+@pytest.mark.gpu
+def test_bench_graph_entry_with_four_ranks(gpu):
+    """Node2Vec data-parallel over 4 ranks: walk slices, the sample all-gather and the row shards of the apply half (20 001
+    rows: the last shard is padded) — embeddings of every rank equal the one-GPU bits (checked inside on a small graph)."""
+    lines = _run_entry("bench_graph.py", ["--workload", "node2vec", "--steps", "1", "--warmup", "0", "--n2v-nodes", "20001",
+                                          "--n2v-edges", "200000", "--n2v-cpu-nodes", "300"], gpus=4)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 4 and lines[0]["value"] > 0
+    assert lines[0]["parity_vs_oracle"]["embedding_bits_identical"]
+    assert abs(lines[0]["embedding_norm_check"]) < 1e-5
 
 
 def test_bench_refuses_a_gpus_flag_that_disagrees_with_the_launcher():
