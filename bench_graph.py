@@ -275,9 +275,146 @@ def bench_leiden(pkg, args):
     return out
 
 
+# ───────────────────────── SURVEY §8 f-4: graph_pagerank / graph_components / graph_node_betweenness ─────────────────────────
+# Published reference numbers (benchmarks/charts/graph_query_time_{pagerank,components,betweenness}.json, series
+# "muninn / erdos-renyi-20", query time through SQL): ms by node count
+PUBLISHED_MS = {"pagerank": {1000: 44.423, 5000: 947.58, 10000: 3756.147, 50000: 299032.738},
+                "components": {1000: 42.074, 5000: 948.109, 10000: 3747.119, 50000: 143310.545},
+                "betweenness": {1000: 130.058, 5000: 3496.249, 10000: 16663.205}}
+TVF_SQL = {"pagerank": "SELECT node, rank FROM graph_pagerank WHERE edge_table = 'bench_edges' AND src_col = 'src' AND dst_col = 'dst' "
+                       "AND damping = 0.85 AND iterations = 100",
+           "components": "SELECT node, component_id FROM graph_components WHERE edge_table = 'bench_edges' AND src_col = 'src' "
+                         "AND dst_col = 'dst'",
+           "betweenness": "SELECT node, centrality FROM graph_node_betweenness WHERE edge_table = 'bench_edges' AND src_col = 'src' "
+                          "AND dst_col = 'dst' AND direction = 'both'"}
+
+
+def er_rows(n, avg_degree, seed=42):
+    """the reference harness's Erdos-Renyi model (benchmarks/harness/common.py:658-686: every pair with probability
+    avg_degree / (n - 1), both directions as rows) drawn with numpy instead of n^2 / 2 calls of random.random()"""
+    rng = np.random.default_rng(seed)
+    m = rng.binomial(n * (n - 1) // 2, avg_degree / max(1, n - 1))
+    a, b = rng.integers(0, n, int(m * 1.02) + 16), rng.integers(0, n, int(m * 1.02) + 16)
+    keep = a != b
+    lo, hi = np.minimum(a, b)[keep], np.maximum(a, b)[keep]
+    _, first = np.unique(lo.astype(np.int64) * n + hi, return_index=True)
+    first = np.sort(first)[:m]
+    lo, hi = lo[first], hi[first]
+    src = np.empty(2 * len(lo), np.int32)
+    dst = np.empty(2 * len(lo), np.int32)
+    src[0::2], src[1::2], dst[0::2], dst[1::2] = lo, hi, hi, lo
+    return src, dst
+
+
+def _sql_time(so, src, dst, sql):
+    """the harness's own methodology: edge table of TEXT ids, one SELECT, fetchall (graph_traversal.py:145-162)"""
+    import sqlite3
+
+    c = sqlite3.connect(":memory:")
+    c.enable_load_extension(True)
+    c.load_extension(so)
+    c.execute("CREATE TABLE bench_edges (src TEXT, dst TEXT, weight REAL)")
+    c.executemany("INSERT INTO bench_edges VALUES (?,?,1.0)", [(str(a), str(b)) for a, b in zip(src.tolist(), dst.tolist())])
+    c.execute(sql).fetchall() if so.endswith("ext/muninn") else None  # (ours: one warm-up for the device's first touch)
+    t0 = time.perf_counter()
+    rows = c.execute(sql).fetchall()
+    ms = (time.perf_counter() - t0) * 1e3
+    c.close()
+    return ms, rows
+
+
+def bench_tvf(pkg, args, what):
+    """One f-4 algorithm: (1) at the reference's published size through SQL — this extension and the compiled reference's,
+    same rows, same statement, results compared; (2) at a size the device is for, through the C-ABI, with a roofline."""
+    rank, world, dist, dev = args.ctx
+    if rank != 0:
+        return None
+    ours_so = os.path.join(ROOT, "sqlite-muninn_amd", "ext", "muninn")
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "muninn")
+    n_pub = args.tvf_published_nodes
+    src, dst = er_rows(n_pub, 20)
+    sql = TVF_SQL[what]
+    ours_ms, ours_rows = _sql_time(ours_so, src, dst, sql)
+    ref_ms, same = None, None
+    if os.path.exists(ref_so + ".so") and not args.no_ref_sql:
+        ref_ms, ref_rows = _sql_time(ref_so, src, dst, sql)
+        if what == "components":  # ids are union-find roots (order-dependent): compare the partition
+            def part(rows):
+                g = {}
+                for node, cid in rows:
+                    g.setdefault(cid, []).append(node)
+                return sorted(sorted(v) for v in g.values())
+            same = part(ours_rows) == part(ref_rows)
+        else:
+            same = sorted(ours_rows) == sorted(ref_rows)
+    # (2) the large case through the C-ABI
+    if what == "betweenness":
+        n_big = args.tvf_betweenness_nodes
+        bs, bd = er_rows(n_big, 20)
+        g = pkg.graph.graph_from_edges(n_big, bs[0::2], bd[0::2], device=dev)  # (each undirected edge once: out + in lists)
+        g.betweenness("both")
+        t0 = time.perf_counter()
+        cb, _, dev_ms = g.betweenness("both")
+        wall = time.perf_counter() - t0
+        g.close()
+        E = len(bs)
+        # Brandes: every source walks every adjacency entry twice (BFS + accumulation): n * E_dir * 2 visits of (target 4 B +
+        # sigma / dist / delta gathers 20 B)
+        alg = float(n_big) * E * 2 * 24
+        big = {"nodes": n_big, "edge_rows": int(E), "device_ms": dev_ms, "wall_ms": wall * 1e3,
+               "sources_per_s": n_big / (dev_ms * 1e-3)}
+        unit, value = "sources/s", n_big / wall
+    else:
+        n_big = args.tvf_nodes
+        bs, bd = er_rows(n_big, 20)
+        E = len(bs)
+        if what == "pagerank":
+            pkg.graph.pagerank(n_big, bs, bd, 0.85, 2, device=dev)
+            t0 = time.perf_counter()
+            _, st = pkg.graph.pagerank(n_big, bs, bd, 0.85, 100, device=dev)
+            wall = time.perf_counter() - t0
+            alg = 100.0 * (E * 12 + n_big * 16)  # per iteration: E (source 4 B + share 8 B) + N (rank 8 B in, 8 B out)
+            big = {"nodes": n_big, "edge_rows": int(E), "iterations": 100, "device_ms": st["device_ms"], "wall_ms": wall * 1e3}
+            dev_ms = st["device_ms"]
+            unit, value = "edge-iterations/s", 100.0 * E / wall
+        else:
+            pkg.graph.components(n_big, bs, bd, pkg.graph.COMPONENTS_FAST, device=dev)
+            t0 = time.perf_counter()
+            _, _, st = pkg.graph.components(n_big, bs, bd, pkg.graph.COMPONENTS_FAST, device=dev)
+            wall = time.perf_counter() - t0
+            alg = float(st["rounds"]) * E * 16 + n_big * 12  # per hook round: E (two ends 8 B + their two parents 8 B)
+            big = {"nodes": n_big, "edge_rows": int(E), "hook_rounds": st["rounds"], "device_ms": st["device_ms"], "wall_ms": wall * 1e3}
+            dev_ms = st["device_ms"]
+            unit, value = "edges/s", E / wall
+    achieved = alg / (dev_ms * 1e-3) / 1e9
+    return {
+        "metric": f"graph_{'node_betweenness' if what == 'betweenness' else what} (SURVEY 8 f-4)", "value": value, "unit": unit,
+        "n_gpus": 1, "steps": 1, "warmup": 1, "ms_per_step": big["wall_ms"], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64" if what != "components" else "int32", "data": "synthetic",
+        "config": {"workload": f"{what}: Erdos-Renyi avg degree 20 (the reference harness's model), {big['nodes']} nodes / "
+                               f"{big['edge_rows']} edge rows through the C-ABI (host arrays in, result out: wall includes the "
+                               f"upload and the host-side CSR build)", **big},
+        "at_published_size_through_sql": {
+            "graph": f"Erdos-Renyi avg degree 20, {n_pub} nodes / {len(src)} edge rows, TEXT ids, the harness's statement",
+            "this_extension_ms": ours_ms, "compiled_reference_ms_on_this_host": ref_ms, "host": host_cpu(),
+            "reference_published_ms": PUBLISHED_MS[what].get(n_pub), "rows_equal_to_reference": same},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel_ms": dev_ms, "algorithmic_bytes_per_launch": alg},
+        "cpu_baseline": None if ref_ms is None else {
+            "value": ref_ms, "unit": "ms per query (lower is better)", "cores": 1, "kind": "reference", "host": host_cpu(),
+            "sample": f"the compiled reference's own TVF through SQL at the published size ({n_pub} nodes): {ref_ms:.0f} ms; this "
+                      f"extension on the same rows: {ours_ms:.0f} ms"},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="both", choices=["node2vec", "leiden", "both"])
+    ap.add_argument("--workload", default="both", choices=["node2vec", "leiden", "both", "pagerank", "components", "betweenness", "tvf"],
+                    help="both = node2vec + leiden (configs 4 and 5); tvf = pagerank + components + betweenness (SURVEY 8 f-4)")
+    ap.add_argument("--tvf-published-nodes", type=int, default=10_000, help="f-4: node count of the reference's published point")
+    ap.add_argument("--tvf-nodes", type=int, default=1_000_000, help="f-4: pagerank / components through the C-ABI")
+    ap.add_argument("--tvf-betweenness-nodes", type=int, default=20_000)
+    ap.add_argument("--no-ref-sql", action="store_true", help="f-4: skip the compiled reference's SQL run")
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n2v-nodes", type=int, default=1_000_000)
@@ -306,6 +443,11 @@ def main():
         if args.workload in (name, "both"):
             line = fn(pkg, args)
             if line is not None:  # rank 0
+                print(json.dumps(line), flush=True)
+    for name in ("pagerank", "components", "betweenness"):
+        if args.workload in (name, "tvf"):
+            line = bench_tvf(pkg, args, name)
+            if line is not None:
                 print(json.dumps(line), flush=True)
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         import torch.distributed as dist
