@@ -134,6 +134,28 @@ def bench_node2vec(pkg, args):
     wall, dev_ms = float(np.mean(walls)), float(np.mean(devs))
     if rank != 0:
         return None
+    # config 4's last leg, "-> hnsw0 index" (src/node2vec.c:540-583 INSERTs every embedding into an hnsw_index): the index
+    # built from the embeddings (a) as the C-ABI's host path does it — embeddings down to the host, back up inside
+    # mn_hnsw_build — and (b) device-resident: mn_node2vec_train_into trains and builds without the embeddings leaving HBM
+    to_index = None
+    if world == 1 and not args.no_index_leg:
+        ids = np.arange(1, n + 1, dtype=np.int64)
+        ixh = pkg.HnswIndex(dim, "cosine", 16, 200, device=dev)
+        t0 = time.perf_counter()
+        if ixh.build(ids, emb, 16, 8192) != 0:
+            raise SystemExit("index build failed: " + pkg.hnsw._err())
+        ixh.sync()
+        host_build_s = time.perf_counter() - t0
+        ixh.close()
+        ixd = pkg.HnswIndex(dim, "cosine", 16, 200, device=dev)
+        t0 = time.perf_counter()
+        _, sti = pkg.graph.node2vec_train_into(off, adj, dim, ixd, 1, False, **prm)
+        total_s = time.perf_counter() - t0
+        ixd.close()
+        to_index = {"index": f"hnsw_index {n} x {dim} cosine M=16 efC=200, batch-synchronous build",
+                    "via_host_index_build_s": host_build_s, "via_host_total_s": wall + host_build_s,
+                    "device_resident_index_build_s": sti["build_seconds"], "device_resident_total_s": total_s,
+                    "index_vectors_per_s_device_resident": n / max(sti["build_seconds"], 1e-9)}
     # SGNS reads+writes (1+neg) context rows and the centre row per pair: (2(1+neg)+2)·dim·4 B;
     # the walk adds deg(cur)·4 B per step
     steps_walk = n * prm["num_walks"] * (prm["walk_length"] - 1)
@@ -189,6 +211,7 @@ def bench_node2vec(pkg, args):
                                   f"data-parallel over {world} ranks ({args.backend}): walk/error phase split, samples all-gathered in walk "
                                   f"order, every replica applies the batch (embeddings bit-identical to 1 GPU)"},
         "parity_vs_oracle": parity,
+        "to_hnsw_index": to_index,
         "embedding_norm_check": float(np.abs(np.linalg.norm(emb[:1000], axis=1) - 1.0).max()),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
@@ -421,6 +444,7 @@ def main():
     ap.add_argument("--n2v-edges", type=int, default=20_000_000)
     ap.add_argument("--n2v-cpu-nodes", type=int, default=1500)
     ap.add_argument("--leiden-nodes", type=int, default=500_000)
+    ap.add_argument("--no-index-leg", action="store_true", help="node2vec: skip the '-> hnsw index' leg (two 1M-row index builds)")
     ap.add_argument("--dump-csr", default="", help="node2vec: also write the graph as a binary CSR file (tools/n2v_bench.cpp)")
     ap.add_argument("--dump-only", action="store_true", help="with --dump-csr: write the file and stop")
     ap.add_argument("--gpus", type=int, default=1, help="N > 1: node2vec data-parallel over N ranks (config 4); leiden = N replicas")

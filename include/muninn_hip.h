@@ -86,6 +86,9 @@ int mn_hnsw_insert_batch(mn_index *idx, const int64_t *ids, const float *vectors
 /* Bulk build helper: splits [n] into batches growing with the index (batch ≤ max(1, count/grow_div),
  * capped at max_batch) and calls the batched schedule on each.  grow_div ≤ 0 → 16, max_batch ≤ 0 → 8192. */
 int mn_hnsw_build(mn_index *idx, const int64_t *ids, const float *vectors, int64_t n, int grow_div, int max_batch);
+/* the same from rows already in HBM on the index's device ([n][dim] f32): same batches, same graph; nothing visits the host */
+int mn_hnsw_build_dev(mn_index *idx, const int64_t *ids, const float *d_vectors, int64_t n, int grow_div, int max_batch);
+int mn_hnsw_device(mn_index *idx); /* HIP ordinal the index lives on */
 /* One MN_BUILD_BATCHED batch in three steps, so that several GPUs that each hold a replica of the index can share
  * its search half (the dominant cost) and still all end up with the graph a single GPU builds:
  *   stage  — add the batch's nodes (ids, levels from the index's own level stream, vectors) on this replica;
@@ -273,6 +276,13 @@ typedef struct {
 int mn_node2vec_train(int n_nodes, const int *off, const int *adj, const mn_n2v_params *prm, int mode, int device, float *out,
                       mn_n2v_stats *stats);
 const char *mn_node2vec_last_error(void);
+/* node2vec_train's compute AND its output step (src/node2vec.c:540-583: every embedding INSERTed into the output hnsw_index,
+ * rowid = first-seen index + 1) without the embeddings leaving HBM: trained (MN_N2V_BATCHED) and normalised on idx's device,
+ * then mn_hnsw_build_dev with rowids first_rowid + i.  host_out (or NULL): the embeddings as well, one bulk copy, for a host
+ * that persists them.  *build_seconds (or NULL): wall time of the index build.  Same embedding bytes as mn_node2vec_train, same
+ * graph as mn_hnsw_build on them.  Returns n, or -1. */
+int mn_node2vec_train_into(int n_nodes, const int *off, const int *adj, const mn_n2v_params *prm, int mode, mn_index *idx,
+                           int64_t first_rowid, float *host_out, mn_n2v_stats *stats, double *build_seconds);
 
 /* The batched schedule as a session, so that several GPUs can share one training run: every rank produces the
  * samples of its slice of a batch's walks, the (centre, target, err) triples are exchanged (RCCL all-gather, rank
@@ -295,6 +305,8 @@ int mn_n2v_apply(mn_n2v_session *s, const int *d_center, const int *d_target, co
                  const int *d_pos_center, const float *d_pos_neu, int64_t np);
 int mn_n2v_sync(mn_n2v_session *s);
 int mn_n2v_finish(mn_n2v_session *s, float *out, mn_n2v_stats *stats); /* L2 normalise, download [n][dim] */
+/* L2 normalise and leave the embeddings in HBM: *d_out = [n][dim] f32 on the session's device, valid until mn_n2v_end */
+int mn_n2v_finish_dev(mn_n2v_session *s, const float **d_out, mn_n2v_stats *stats);
 void mn_n2v_end(mn_n2v_session *s);
 
 /* ---- graph_tvf.c's remaining edge-list algorithms ----

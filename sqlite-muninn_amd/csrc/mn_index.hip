@@ -331,7 +331,7 @@ static int host_add_node(mn_index *x, int64_t id, int level, int deleted) {
 }
 
 // upload n vectors (host [n][dim]) into slots [first, first+n), zero padded to ld, and their norms
-static int upload_vectors(mn_index *x, int first, const float *vecs, int n);
+static int upload_vectors(mn_index *x, int first, const float *vecs, int n, bool src_on_device = false);
 
 // make device buffers large enough for the host tables and upload metadata of new slots
 static int sync_meta(mn_index *x) {
@@ -366,16 +366,16 @@ static int sync_meta(mn_index *x) {
     return 0;
 }
 
-static int upload_vectors(mn_index *x, int first, const float *vecs, int n) {
+static int upload_vectors(mn_index *x, int first, const float *vecs, int n, bool src_on_device) {
     hipStream_t st = x->stream;
+    // (src_on_device: the rows are already in HBM — mn_hnsw_build_dev — and never visit the host)
+    const hipMemcpyKind kind = src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     if (x->ld == x->dim) {
-        HIPCHK(hipMemcpyAsync(x->d_vectors.p + (size_t)first * x->ld, vecs, (size_t)n * x->dim * sizeof(float),
-                              hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(x->d_vectors.p + (size_t)first * x->ld, vecs, (size_t)n * x->dim * sizeof(float), kind, st));
     } else {
         HIPCHK(hipMemsetAsync(x->d_vectors.p + (size_t)first * x->ld, 0, (size_t)n * x->ld * sizeof(float), st));
         HIPCHK(hipMemcpy2DAsync(x->d_vectors.p + (size_t)first * x->ld, (size_t)x->ld * sizeof(float), vecs,
-                                (size_t)x->dim * sizeof(float), (size_t)x->dim * sizeof(float), (size_t)n,
-                                hipMemcpyHostToDevice, st));
+                                (size_t)x->dim * sizeof(float), (size_t)x->dim * sizeof(float), (size_t)n, kind, st));
     }
     if (x->metric == MN_METRIC_COSINE)
         mn_launch_norms(dev_view(x), first, n, x->d_norms.p, st);
@@ -1076,7 +1076,7 @@ static int run_speculative(mn_index *x, const std::vector<int> &slots) {
 
 #define MN_BUILD_STAGE_ONLY 100 // internal: add the nodes, leave search + link to mn_hnsw_batch_search / _link
 
-static int insert_impl(mn_index *x, const int64_t *ids, const float *vectors, int64_t n, int mode) {
+static int insert_impl(mn_index *x, const int64_t *ids, const float *vectors, int64_t n, int mode, bool src_on_device = false) {
     if (use_device(x))
         return -1;
     if (n <= 0)
@@ -1136,7 +1136,7 @@ static int insert_impl(mn_index *x, const int64_t *ids, const float *vectors, in
         }
         x->node_count++;
     }
-    if (sync_meta(x) || upload_vectors(x, first, vectors, (int)n)) {
+    if (sync_meta(x) || upload_vectors(x, first, vectors, (int)n, src_on_device)) {
         undo_insert(x, undo);
         return -1;
     }
@@ -1217,8 +1217,8 @@ extern "C" int mn_hnsw_insert_batch(mn_index *x, const int64_t *ids, const float
     return insert_impl(x, ids, vectors, n, mode);
 }
 
-extern "C" int mn_hnsw_build(mn_index *x, const int64_t *ids, const float *vectors, int64_t n, int grow_div,
-                             int max_batch) {
+static int build_impl(mn_index *x, const int64_t *ids, const float *vectors, int64_t n, int grow_div, int max_batch,
+                      bool src_on_device) {
     if (grow_div <= 0)
         grow_div = 16;
     if (max_batch <= 0)
@@ -1228,12 +1228,26 @@ extern "C" int mn_hnsw_build(mn_index *x, const int64_t *ids, const float *vecto
         int64_t b = std::max<int64_t>(1, x->node_count / grow_div);
         b = std::min<int64_t>(b, max_batch);
         b = std::min<int64_t>(b, n - pos);
-        if (insert_impl(x, ids + pos, vectors + (size_t)pos * x->dim, b, MN_BUILD_BATCHED))
+        if (insert_impl(x, ids + pos, vectors + (size_t)pos * x->dim, b, MN_BUILD_BATCHED, src_on_device))
             return -1;
         pos += b;
     }
     return 0;
 }
+
+extern "C" int mn_hnsw_build(mn_index *x, const int64_t *ids, const float *vectors, int64_t n, int grow_div,
+                             int max_batch) {
+    return build_impl(x, ids, vectors, n, grow_div, max_batch, false);
+}
+
+// the same build from rows that are already in HBM on the index's device ([n][dim] f32, e.g. the embeddings a Node2Vec run
+// has just normalised: mn_node2vec_train_into): same batches, same graph as mn_hnsw_build on a host copy of those rows
+extern "C" int mn_hnsw_build_dev(mn_index *x, const int64_t *ids, const float *d_vectors, int64_t n, int grow_div,
+                                 int max_batch) {
+    return build_impl(x, ids, d_vectors, n, grow_div, max_batch, true);
+}
+
+extern "C" int mn_hnsw_device(mn_index *x) { return x->device; }
 
 // ── one batch of the batch-synchronous build in three steps, so that the search half can be split over several GPUs
 //    that each hold a replica of the index (sqlite-muninn_amd/parallel.py build_distributed) ──

@@ -16,6 +16,7 @@
 // LUT (:247-258, expf) — these are inputs of the hot loop, not part of it.
 #include "../../include/muninn_hip.h"
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <cmath>
 #include <cstdarg>
@@ -486,6 +487,26 @@ extern "C" int mn_n2v_finish(mn_n2v_session *S, float *out, mn_n2v_stats *stats)
     }
     return n;
 }
+// the same, with the normalised embeddings left where they are: *d_out = [n][dim] f32 in HBM on the session's device, valid
+// until mn_n2v_end (config 4's "-> hnsw index" leg feeds them to mn_hnsw_build_dev without a host round trip)
+extern "C" int mn_n2v_finish_dev(mn_n2v_session *S, const float **d_out, mn_n2v_stats *stats) {
+    NCHK(hipSetDevice(S->device));
+    const int n = S->a.n, dim = S->a.dim;
+    hipLaunchKernelGGL(k_n2v_normalize, dim3(n), dim3(64), (size_t)dim * sizeof(float), S->st, S->syn0, n, dim);
+    NCHK(hipEventRecord(S->e1, S->st));
+    NCHK(hipStreamSynchronize(S->st));
+    unsigned long long o[2];
+    NCHK(hipMemcpy(o, S->pairs, sizeof(o), hipMemcpyDeviceToHost));
+    *d_out = S->syn0;
+    if (stats) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, S->e0, S->e1);
+        stats->pairs = (int64_t)o[0];
+        stats->device_ms = ms;
+    }
+    return n;
+}
+
 extern "C" void mn_n2v_end(mn_n2v_session *S) {
     if (!S)
         return;
@@ -620,6 +641,64 @@ extern "C" int mn_node2vec_train_shared(mn_comm *c, int n, const int *off, const
     if (rc == 0)
         rc = mn_n2v_finish(S, out, stats);
     return cleanup(rc < 0 ? -1 : n);
+}
+
+// node2vec_train's compute followed by its output step (src/node2vec.c:540-583: INSERT every embedding into the output
+// hnsw_index) with the embeddings never leaving HBM: trained and normalised on the index's device, then handed to
+// mn_hnsw_build_dev with rowids first_rowid + i (the reference's rowid = first-seen index + 1).  host_out (or NULL) also
+// receives the embeddings — one bulk copy, for a host that persists them (the extension's "{t}_nodes" shadow table).
+// Same embedding bytes as mn_node2vec_train, same graph as mn_hnsw_build on them.  Returns n, or -1.
+extern "C" int mn_node2vec_train_into(int n, const int *off, const int *adj, const mn_n2v_params *prm, int mode, mn_index *idx,
+                                      int64_t first_rowid, float *host_out, mn_n2v_stats *stats, double *build_seconds) {
+    if (stats)
+        memset(stats, 0, sizeof(*stats));
+    if (build_seconds)
+        *build_seconds = 0.0;
+    if (n == 0)
+        return 0;
+    if (!valid_params(prm) || !idx) {
+        nset_err("mn_node2vec_train_into: invalid parameters (src/node2vec.c:443-464)");
+        return -1;
+    }
+    if (mode != MN_N2V_BATCHED) {
+        nset_err("mn_node2vec_train_into: MN_N2V_BATCHED only (the serial stream is latency-bound: nothing to gain from HBM residency)");
+        return -1;
+    }
+    const int device = mn_hnsw_device(idx);
+    mn_n2v_session *S = mn_n2v_begin(n, off, adj, prm, device);
+    if (!S)
+        return -1;
+    int rc = 0;
+    for (int epoch = 0; epoch < prm->epochs && rc == 0; epoch++)
+        for (int w = 0; w < prm->num_walks && rc == 0; w++)
+            for (int b0 = 0; b0 < n && rc == 0; b0 += S->B) {
+                const int b1 = std::min(n, b0 + S->B);
+                rc = n2v_samples(S, epoch, w, b0, b1, S->s_center, S->s_target, S->s_err, S->p_center, S->p_neu);
+                if (rc == 0)
+                    rc = n2v_apply(S, S->s_center, S->s_target, S->s_err, (int64_t)(b1 - b0) * S->cap, S->p_center, S->p_neu,
+                                   (int64_t)(b1 - b0) * prm->walk_length);
+            }
+    const float *d_emb = nullptr;
+    if (rc == 0 && mn_n2v_finish_dev(S, &d_emb, stats) < 0)
+        rc = -1;
+    if (rc == 0) {
+        std::vector<int64_t> ids((size_t)n);
+        for (int i = 0; i < n; i++)
+            ids[(size_t)i] = first_rowid + i;
+        const auto t0 = std::chrono::steady_clock::now();
+        if (mn_hnsw_build_dev(idx, ids.data(), d_emb, n, 0, 0) != 0 || mn_hnsw_sync(idx) != 0) {
+            nset_err("mn_node2vec_train_into: %s", mn_last_error());
+            rc = -1;
+        }
+        if (build_seconds)
+            *build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    if (rc == 0 && host_out && hipMemcpy(host_out, d_emb, (size_t)n * prm->dim * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+        nset_err("mn_node2vec_train_into: download of the embeddings failed");
+        rc = -1;
+    }
+    mn_n2v_end(S);
+    return rc < 0 ? -1 : n;
 }
 
 extern "C" int mn_node2vec_train(int n, const int *off, const int *adj, const mn_n2v_params *prm, int mode, int device,

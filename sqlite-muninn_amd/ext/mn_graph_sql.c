@@ -80,6 +80,10 @@ static void lists_to_csr(EList *ls, int n, int with_w, int **off, int **tgt, dou
 
 /* ───────────────────────── node2vec_train ───────────────────────── */
 
+/* mn_vtab_hnsw.c: the output step straight into a live hnsw_index (1 done, 0 not applicable, -1 error) */
+int mn_vtab_hnsw_fill_from_n2v(sqlite3 *db, const char *table, int n, const int *off, const int *adj, const mn_n2v_params *prm,
+                               int *inserted, char **err);
+
 static void fn_node2vec_train(sqlite3_context *ctx, int argc, sqlite3_value **argv) {
     if (argc < 13) {
         sqlite3_result_error(ctx, "node2vec_train: requires 13 arguments", -1);
@@ -171,10 +175,28 @@ static void fn_node2vec_train(sqlite3_context *ctx, int argc, sqlite3_value **ar
     int *off, *tgt;
     double *wdummy;
     lists_to_csr(adj, n, 0, &off, &tgt, &wdummy);
-    float *emb = (float *)malloc((size_t)n * (size_t)prm.dim * sizeof(float));
     /* pairs ≈ n · walks · length · 2·window · epochs; the serial stream handles ~0.4 M pairs/s */
     long long work = (long long)n * prm.num_walks * prm.walk_length * 2 * prm.window * prm.epochs;
     int mode = graph_mode_fast(work, 4000000LL) && n >= 512 ? MN_N2V_BATCHED : MN_N2V_SEQUENTIAL;
+    if (mode == MN_N2V_BATCHED) {
+        /* output table = a live, empty hnsw_index in fast mode: embeddings go from training into the index inside HBM */
+        int inserted = 0;
+        char *derr = 0;
+        int direct = mn_vtab_hnsw_fill_from_n2v(db, out_table, n, off, tgt, &prm, &inserted, &derr);
+        if (direct != 0) {
+            free(off);
+            free(tgt);
+            nm_free(&nm);
+            if (direct < 0) {
+                sqlite3_result_error(ctx, derr ? derr : "node2vec_train: failed", -1);
+                sqlite3_free(derr);
+            } else {
+                sqlite3_result_int(ctx, inserted);
+            }
+            return;
+        }
+    }
+    float *emb = (float *)malloc((size_t)n * (size_t)prm.dim * sizeof(float));
     int got = emb ? mn_node2vec_train(n, off, tgt, &prm, mode, mn_env_device(), emb, 0) : -1;
     free(off);
     free(tgt);

@@ -1034,6 +1034,53 @@ static sqlite3_module batch_module = {
     .xRowid = b_rowid,
 };
 
+/* node2vec_train's output step (src/node2vec.c:540-583: INSERT every embedding into the output table) when that table is a
+ * live hnsw_index of this connection in fast mode and still empty: the embeddings are trained, normalised and built into the
+ * index without leaving HBM (mn_node2vec_train_into) — no per-row INSERT, no second upload — and the shadow tables are written
+ * once from one bulk copy.  Same rows, same rowids (first-seen index + 1), same "{t}_nodes" / "{t}_edges" as the generic INSERT
+ * path in this mode (MUNINN_N2V_DIRECT=0 forces that path; the tests compare the two).
+ * Returns 1: done, *inserted rows; 0: not applicable, the caller INSERTs as usual; -1: error, *err (sqlite3_mprintf). */
+int mn_vtab_hnsw_fill_from_n2v(sqlite3 *db, const char *table, int n, const int *off, const int *adj, const mn_n2v_params *prm,
+                               int *inserted, char **err) {
+    const char *e = getenv("MUNINN_N2V_DIRECT");
+    VtabHnsw *v = live_find(db, table);
+    if (!v || v->mode != MODE_FAST || v->dim != prm->dim || v->n_pend != 0 || (e && !strcmp(e, "0")))
+        return 0;
+    sqlite3_stmt *st = 0;
+    char *sql = sqlite3_mprintf("SELECT count(*) FROM \"%w_nodes\"", v->name);
+    int rc = sqlite3_prepare_v2(db, sql, -1, &st, 0);
+    sqlite3_free(sql);
+    if (rc != SQLITE_OK)
+        return 0;
+    const int have = sqlite3_step(st) == SQLITE_ROW ? sqlite3_column_int(st, 0) : 1;
+    sqlite3_finalize(st);
+    if (have != 0 || mn_hnsw_node_count(v->index) != 0)
+        return 0; /* rows exist already: the INSERT path has the duplicate-rowid semantics */
+    float *emb = (float *)malloc((size_t)n * (size_t)prm->dim * sizeof(float));
+    if (!emb) {
+        *err = sqlite3_mprintf("node2vec_train: out of memory");
+        return -1;
+    }
+    if (mn_node2vec_train_into(n, off, adj, prm, MN_N2V_BATCHED, v->index, 1, emb, 0, 0) < 0) {
+        free(emb);
+        *err = sqlite3_mprintf("node2vec_train: %s", mn_node2vec_last_error());
+        return -1;
+    }
+    rc = SQLITE_OK;
+    for (int i = 0; i < n && rc == SQLITE_OK; i++) /* (the queue doubles as the "new rows" list of persist_marked) */
+        rc = pend_add(v, (sqlite3_int64)i + 1, emb + (size_t)i * prm->dim);
+    free(emb);
+    if (rc == SQLITE_OK)
+        rc = persist_marked(v, v->pend_ids, v->pend_vecs, v->n_pend);
+    pend_clear(v);
+    if (rc != SQLITE_OK) {
+        *err = sqlite3_mprintf("node2vec_train: writing the shadow tables of \"%s\" failed", table);
+        return -1;
+    }
+    *inserted = n;
+    return 1;
+}
+
 int mn_register_hnsw_module(sqlite3 *db) {
     int rc = sqlite3_create_module(db, "hnsw_index", &hnsw_module, 0); /* src/hnsw_vtab.c:805-807 */
     if (rc == SQLITE_OK)

@@ -51,6 +51,9 @@ GRAPH_SYMBOLS = [
     ("mn_n2v_apply", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64]),
     ("mn_n2v_sync", C.c_int, [C.c_void_p]),
     ("mn_n2v_finish", C.c_int, [C.c_void_p, np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS"), C.POINTER(N2vStats)]),
+    ("mn_n2v_finish_dev", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(N2vStats)]),
+    ("mn_node2vec_train_into", C.c_int, [C.c_int, _i32p, _i32p, C.POINTER(N2vParams), C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
+                                         C.POINTER(N2vStats), C.POINTER(C.c_double)]),
     ("mn_n2v_end", None, [C.c_void_p]),
     ("mn_graph_create", C.c_void_p, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     ("mn_graph_create_blocked", C.c_void_p, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]),
@@ -202,6 +205,25 @@ def csr_pair_from_edges(n, src, dst, weights=None):
 def graph_from_edges(n, src, dst, weights=None, device=0):
     """Graph (Leiden input) from an edge list with integer node indices."""
     return Graph(n, *csr_pair_from_edges(n, src, dst, weights), device=device)
+
+
+def node2vec_train_into(off, adj, dim, index, first_rowid=1, want_embeddings=True, p=1.0, q=1.0, num_walks=10, walk_length=80,
+                        window=5, neg_samples=5, learning_rate=0.025, epochs=1, batch_walks=0):
+    """mn_node2vec_train_into: train (MN_N2V_BATCHED) on the index's device and build `index` (an hnsw.HnswIndex) from the
+    embeddings without a host round trip → (embeddings [n][dim] f32 or None, stats with 'build_seconds')."""
+    L = _glib()
+    off = np.ascontiguousarray(off, np.int32)
+    adj = np.ascontiguousarray(adj if len(adj) else np.zeros(1, np.int32), np.int32)
+    n = len(off) - 1
+    out = np.zeros((max(n, 1), dim), np.float32) if want_embeddings else None
+    prm = N2vParams(dim, p, q, num_walks, walk_length, window, neg_samples, learning_rate, epochs, batch_walks)
+    st = N2vStats()
+    bs = C.c_double(0.0)
+    rc = L.mn_node2vec_train_into(n, off, adj, C.byref(prm), N2V_BATCHED, index.h, int(first_rowid),
+                                  out.ctypes.data if out is not None else None, C.byref(st), C.byref(bs))
+    if rc < 0:
+        raise MuninnHipError((L.mn_node2vec_last_error() or b"").decode())
+    return (out[:n] if out is not None else None), {"pairs": st.pairs, "device_ms": st.device_ms, "build_seconds": bs.value}
 
 
 def n2v_csr_from_edges(n, src, dst):

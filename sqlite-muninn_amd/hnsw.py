@@ -56,6 +56,8 @@ SYMBOLS = [
     ("mn_hnsw_insert", C.c_int, [C.c_void_p, C.c_int64, _f32p]),
     ("mn_hnsw_insert_batch", C.c_int, [C.c_void_p, _i64p, _f32p, C.c_int64, C.c_int]),
     ("mn_hnsw_build", C.c_int, [C.c_void_p, _i64p, _f32p, C.c_int64, C.c_int, C.c_int]),
+    ("mn_hnsw_build_dev", C.c_int, [C.c_void_p, _i64p, C.c_void_p, C.c_int64, C.c_int, C.c_int]),
+    ("mn_hnsw_device", C.c_int, [C.c_void_p]),
     ("mn_hnsw_search", C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.POINTER(_Result)]),
     ("mn_hnsw_search_batch", C.c_int, [C.c_void_p, _f32p, C.c_int64, C.c_int, C.c_int, _i64p, _f32p, _i32p]),
     ("mn_hnsw_search_batch_dev", C.c_int,

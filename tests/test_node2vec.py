@@ -180,3 +180,28 @@ def test_config4_shape_properties_200k_nodes(gpu):
     per_walk = sum(min(L - 1, i + W) - max(0, i - W) for i in range(L))
     assert st["pairs"] == nn * 2 * per_walk  # (mean degree 40: no isolated nodes, no dead ends on an undirected graph)
     assert np.isfinite(emb).all()
+
+
+@pytest.mark.gpu
+def test_train_into_index_keeps_the_embeddings_in_hbm_and_builds_the_same_graph(gpu):
+    """mn_node2vec_train_into (config 4's "-> hnsw0 index" leg, src/node2vec.c:540-583): the embeddings are trained, normalised
+    and handed to the index build inside HBM.  Same embedding bytes as mn_node2vec_train in the same mode, and the index is the
+    graph mn_hnsw_build makes from a host copy of those embeddings with the reference's rowids (first-seen index + 1)."""
+    from oracle.graph_cases import planted
+
+    s, d, _ = planted(3000, 6, 0.05, 0.001, 11)
+    g = og.N2vGraph(s, d)
+    want, st1 = gpu.node2vec_train(g.off, g.adj, 64, 1.0, 1.0, 3, 20, 4, 3, 0.025, 1, mode=gpu.N2V_BATCHED, batch_walks=200)
+    ix = gpu.HnswIndex(64, "cosine", 8, 60)
+    emb, st = gpu.graph.node2vec_train_into(g.off, g.adj, 64, ix, 1, True, 1.0, 1.0, 3, 20, 4, 3, 0.025, 1, 200)
+    assert np.array_equal(emb.view(np.int32), want.view(np.int32)) and st["pairs"] == st1["pairs"]
+    ids = np.arange(1, g.n + 1, dtype=np.int64)
+    ref = gpu.HnswIndex(64, "cosine", 8, 60)
+    assert ref.build(ids, want, 16, 8192) == 0
+    assert ix.node_count == g.n and ix.entry_point == ref.entry_point and ix.max_level == ref.max_level
+    assert np.array_equal(ix.export_links(0), ref.export_links(0)) and np.array_equal(ix.export_links(1), ref.export_links(1))
+    q = want[:50]
+    a, b = ix.search_batch(q, 5, 40), ref.search_batch(q, 5, 40)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.int32), b[1].view(np.int32))
+    ix.close()
+    ref.close()

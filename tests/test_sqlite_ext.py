@@ -600,6 +600,40 @@ def test_integrated_build_keeps_the_rest_of_the_reference_surface_loadable():
     c.close()
 
 
+@gpu_mark
+def test_node2vec_train_into_a_live_hnsw_index_stays_on_the_device_and_equals_the_insert_path(ext_built, gpu, monkeypatch):
+    """node2vec_train(..., output_table) where output_table is a live hnsw_index in fast mode: the extension hands the
+    embeddings to the index inside HBM (mn_vtab_hnsw_fill_from_n2v) instead of one INSERT per row.  The result — returned count,
+    "{t}_nodes" (rowids, vectors, levels), "{t}_edges", "{t}_config", search answers — must equal the generic INSERT path in
+    the same mode (MUNINN_N2V_DIRECT=0)."""
+    from oracle.graph_cases import planted
+
+    monkeypatch.setenv("MUNINN_HNSW_MODE", "fast")
+    monkeypatch.setenv("MUNINN_GRAPH_MODE", "fast")
+    s, d, _ = planted(1500, 5, 0.06, 0.002, 3)
+    out = {}
+    for direct in ("1", "0"):
+        monkeypatch.setenv("MUNINN_N2V_DIRECT", direct)
+        c = sqlite3.connect(":memory:")
+        c.enable_load_extension(True)
+        c.load_extension(ext_built)
+        c.execute("CREATE TABLE e (src TEXT, dst TEXT)")
+        c.executemany("INSERT INTO e VALUES (?,?)", [(f"n{a}", f"n{b}") for a, b in zip(s, d)])
+        c.execute("CREATE VIRTUAL TABLE emb USING hnsw_index(dimensions=32, metric='cosine', m=8, ef_construction=60)")
+        with c:
+            got = c.execute("SELECT node2vec_train('e','src','dst','emb',32,1.0,1.0,4,20,4,3,0.025,1)").fetchone()[0]
+        q = c.execute("SELECT vector FROM emb_nodes WHERE id = 7").fetchone()[0]
+        out[direct] = {"n": got,
+                       "nodes": c.execute("SELECT id, vector, level, deleted FROM emb_nodes ORDER BY id").fetchall(),
+                       "edges": c.execute("SELECT source_id, target_id, level, distance FROM emb_edges ORDER BY 1,3,2").fetchall(),
+                       "config": c.execute("SELECT key, value FROM emb_config ORDER BY key").fetchall(),
+                       "knn": c.execute("SELECT rowid, distance FROM emb WHERE vector MATCH ? AND k = 5 AND ef_search = 40", (q,)).fetchall()}
+        c.close()
+    assert out["1"]["n"] == out["0"]["n"] == len(out["1"]["nodes"]) > 1000
+    for k in ("nodes", "edges", "config", "knn"):
+        assert out["1"][k] == out["0"][k], k
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", [33, 34])
 def test_incremental_graph_adjacency_rebuild_runs_the_device_merge_and_equals_the_reference(gpu, seed):
