@@ -751,7 +751,8 @@ def test_muninn_device_env_selects_the_ordinal_and_fails_loudly_on_a_bad_one(ext
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for dev, ok in (("0", True), ("63", False)):
+    # (malformed values — not a plain ordinal — are errors too, never "device 0": "abc", "1x", "-1", "")
+    for dev, ok in (("0", True), ("63", False), ("abc", False), ("0x", False), ("-1", False), ("", False)):
         env = dict(os.environ, MUNINN_DEVICE=dev, MN_ROOT=root)
         r = subprocess.run([sys.executable, "-c", _DEVICE_ENV], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -759,3 +760,4 @@ def test_muninn_device_env_selects_the_ordinal_and_fails_loudly_on_a_bad_one(ext
             assert "CREATED 1" in r.stdout and "PR 3" in r.stdout, r.stdout
         else:
             assert "SQLERR" in r.stdout and "SQLERR2" in r.stdout and "CREATED" not in r.stdout and "PR 3" not in r.stdout, r.stdout
+            assert "MUNINN_DEVICE=" in r.stdout, r.stdout  # the message names the variable
