@@ -228,7 +228,10 @@ def bench_leiden(pkg, args):
     rank, world, dist, dev = args.ctx  # run_leiden does not shard (1 GPU): N > 1 = N independent replicas
     t0 = time.perf_counter()
     s, d, truth = pkg.lfr.lfr_like(n, 40, min(200, n // 10), 0.3)
-    g = pkg.graph.graph_from_edges(n, s, d, device=dev)
+    # --leiden-weighted: the same graph with edge weights in [0.5, 2.5): list-order f64 sums in the evaluation and the round's
+    # winners applied in the reference's addition order on the device (stable sort by community), instead of integer counts
+    wts = (np.random.default_rng(8).random(len(s)) * 2 + 0.5) if args.leiden_weighted else None
+    g = pkg.graph.graph_from_edges(n, s, d, wts, device=dev)
     gen_s = time.perf_counter() - t0
     E = len(s)
     for _ in range(args.warmup):
@@ -251,16 +254,17 @@ def bench_leiden(pkg, args):
 
     from oracle import orc_graph as og
 
-    csr = og.Csr(s, d, None, "both", n_nodes=n, first_seen=False)
+    csr = og.Csr(s, d, wts, "both", n_nodes=n, first_seen=False)
     t0 = time.perf_counter()
     oc, oq, ost = og.leiden(csr, 1.0, 1)  # the reference's sequential schedule
     cpu_s = time.perf_counter() - t0
     # the device's batched result against the CPU restatement of the same schedule (bit-exact), bounded size
     pn = 20000
     ps, pd, _ = pkg.lfr.lfr_like(pn, 20, 100, 0.3, seed=5)
-    pg = pkg.graph.graph_from_edges(pn, ps, pd)
+    pw = (np.random.default_rng(9).random(len(ps)) * 2 + 0.5) if args.leiden_weighted else None
+    pg = pkg.graph.graph_from_edges(pn, ps, pd, pw)
     pc, pq, _ = pg.leiden(1.0, "both", pkg.LEIDEN_BATCHED, 1024)
-    oc2, oq2, _ = og.leiden(og.Csr(ps, pd, None, "both", n_nodes=pn, first_seen=False), 1.0, 1024)
+    oc2, oq2, _ = og.leiden(og.Csr(ps, pd, pw, "both", n_nodes=pn, first_seen=False), 1.0, 1024)
     pg.close()
     # how well each partition recovers the planted communities (pair-counting F1 is O(n^2); use NMI)
     def nmi(a, b):
@@ -278,7 +282,7 @@ def bench_leiden(pkg, args):
         "value": E * world / wall, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"leiden: LFR-like n={n}, <k>=40, k_max 200, mu=0.3, seed 42 -> {E} edges, unweighted, "
+        "config": {"workload": f"leiden: LFR-like n={n}, <k>=40, k_max 200, mu=0.3, seed 42 -> {E} edges, {'weighted [0.5, 2.5)' if args.leiden_weighted else 'unweighted'}, "
                                f"direction both, resolution 1.0; batch-synchronous schedule (MN_LEIDEN_BATCHED, default batch)",
                    "nodes": n, "edges": int(E), "graph_build_s": gen_s},
         "modularity": q, "communities": int(comm.max()) + 1, "sweeps": int(sweeps), "moves": int(st["moves"]),
@@ -287,7 +291,7 @@ def bench_leiden(pkg, args):
         "parity_vs_oracle": {"graph": f"LFR-like n={pn}, batch 1024", "communities_identical": bool(np.array_equal(pc, oc2)),
                              "modularity_bits_identical": bool(np.float64(pq).view(np.int64) == np.float64(oq2).view(np.int64))},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": _traffic("leiden_lfr500k_9.27M_batched_default") if n == 500_000 else None,
+                     "traffic": _traffic("leiden_lfr500k_9.27M_batched_default") if n == 500_000 and not args.leiden_weighted else None,
                      "kernel": "k_leiden_eval / k_leiden_win / k_leiden_apply rounds (whole run_leiden)", "kernel_ms": dev_ms,
                      "algorithmic_bytes_per_launch": alg},
         "cpu_baseline": {"value": E / cpu_s, "unit": "edges/s", "cores": 1, "kind": "port", "host": host_cpu(),
@@ -444,6 +448,7 @@ def main():
     ap.add_argument("--n2v-edges", type=int, default=20_000_000)
     ap.add_argument("--n2v-cpu-nodes", type=int, default=1500)
     ap.add_argument("--leiden-nodes", type=int, default=500_000)
+    ap.add_argument("--leiden-weighted", action="store_true", help="leiden: random edge weights (the f64 list-order path)")
     ap.add_argument("--no-index-leg", action="store_true", help="node2vec: skip the '-> hnsw index' leg (two 1M-row index builds)")
     ap.add_argument("--dump-csr", default="", help="node2vec: also write the graph as a binary CSR file (tools/n2v_bench.cpp)")
     ap.add_argument("--dump-only", action="store_true", help="with --dump-csr: write the file and stop")

@@ -29,6 +29,7 @@
 // All device buffers are allocated once per graph (LeiWork) and reused by later calls.
 #include "../../include/muninn_hip.h"
 #include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
@@ -669,10 +670,12 @@ __global__ void __launch_bounds__(256) k_leiden_apply(LeiArgs a) {
             a.Lq[old] = 0;
             a.Jq[best] = 0;
             const int use_bit = safe > 0 ? 1 : 2;
-            if (a.apply_on_device && (wbits & use_bit)) {
-                // unweighted graph: degrees are integers, f64 atomic adds are exact → order-free
-                atomicAdd(a.sum_tot + old, -k_v);
-                atomicAdd(a.sum_tot + best, k_v);
+            if (wbits & use_bit) {
+                if (a.apply_on_device) {
+                    // unweighted graph: degrees are integers, f64 atomic adds are exact → order-free
+                    atomicAdd(a.sum_tot + old, -k_v);
+                    atomicAdd(a.sum_tot + best, k_v);
+                } // (weighted: sum_tot was brought up to date in the reference's addition order by k_leiden_apply_ops)
                 a.label[v] = best;
                 applied = 1;
             }
@@ -687,16 +690,36 @@ __global__ void __launch_bounds__(256) k_leiden_apply(LeiArgs a) {
         atomicAdd(a.out, blk_moves);
 }
 
-// host-ordered application for weighted graphs: scatter the changed entries back
-__global__ void k_scatter_d(double *dst, const int *idx, const double *val, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n)
-        dst[idx[i]] = val[i];
+// Weighted graphs: a round's winners applied on the device in the reference's order.  f64 addition is not associative, so
+// sum_tot[c] must receive its additions exactly as the sequential loop makes them: winners in node order, each first
+// "sum_tot[old] -= k" then "sum_tot[new] += k" (:220-223).  Operation 2·slot is the subtraction, 2·slot + 1 the addition;
+// k_leiden_ops keys them by community (non-winners: key = n), a STABLE radix sort groups a community's operations without
+// reordering them, and k_leiden_apply_ops lets the lane that holds a community's first operation replay its run.
+__global__ void __launch_bounds__(256) k_leiden_ops(LeiArgs a, int n_nodes, int *keys) {
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= a.b1 - a.b0)
+        return;
+    const int v = a.b0 + slot;
+    const int old = a.label[v], best = a.dec[slot]; // (labels are written by k_leiden_apply, after this)
+    const int use_bit = a.out[1 + a.parity] > 0 ? 1 : 2;
+    const bool winner = best != old && (a.win[slot] & use_bit);
+    keys[2 * slot] = winner ? old : n_nodes;
+    keys[2 * slot + 1] = winner ? best : n_nodes;
 }
-__global__ void k_scatter_i(int *dst, const int *idx, const int *val, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n)
-        dst[idx[i]] = val[i];
+__global__ void k_leiden_apply_ops(LeiArgs a, int n_nodes, const int *keys_sorted, const int *ops_sorted, int n_ops) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_ops)
+        return;
+    const int c = keys_sorted[j];
+    if (c >= n_nodes || (j > 0 && keys_sorted[j - 1] == c))
+        return;
+    double S = a.sum_tot[c];
+    for (int i = j; i < n_ops && keys_sorted[i] == c; i++) {
+        const int op = ops_sorted[i];
+        const double kv = a.kdeg[a.b0 + (op >> 1)];
+        S = (op & 1) ? S + kv : S - kv;
+    }
+    a.sum_tot[c] = S;
 }
 
 // weighted_degree (:95-104) and weight_to_community(v, community[v]) (:75-90), list order, f64
@@ -930,13 +953,18 @@ extern "C" mn_graph *mn_graph_create_blocked(int n_nodes, const mn_csr_block *fw
 
 struct LeiWork {
     int n = 0, batch_cap = 0, big_mode = -1;
-    int *label = nullptr, *refined = nullptr, *out = nullptr, *dec = nullptr, *cmin = nullptr, *sc = nullptr, *sidx = nullptr,
-        *sival = nullptr, *first = nullptr, *flag = nullptr, *rank = nullptr, *biglist = nullptr, *counts = nullptr;
+    int *label = nullptr, *refined = nullptr, *out = nullptr, *dec = nullptr, *cmin = nullptr, *sc = nullptr,
+        *first = nullptr, *flag = nullptr, *rank = nullptr, *biglist = nullptr, *counts = nullptr;
     unsigned char *win = nullptr, *mv = nullptr, *se = nullptr;
-    double *sum_tot = nullptr, *kdeg = nullptr, *tmp = nullptr, *sw = nullptr, *dk = nullptr, *sdval = nullptr, *scal = nullptr,
+    double *sum_tot = nullptr, *kdeg = nullptr, *tmp = nullptr, *sw = nullptr, *dk = nullptr, *scal = nullptr,
            *s_in = nullptr;
     unsigned long long *Jq = nullptr, *Lq = nullptr;
     long long *bigoff = nullptr;
+    // weighted graphs: the round's operations keyed by community, their stable sort (k_leiden_ops / k_leiden_apply_ops)
+    int *okeys = nullptr, *okeys_s = nullptr, *oiota = nullptr, *oops_s = nullptr;
+    void *osort_tmp = nullptr;
+    size_t osort_bytes = 0;
+    int osort_bits = 0, ocap = 0;
     size_t scratch_need = 0, scratch_have = 0; // entries: one region per node with more than LEI_CAP edges
     void *scan_tmp = nullptr;
     size_t scan_bytes = 0;
@@ -944,8 +972,8 @@ struct LeiWork {
     hipEvent_t ev_rd[2] = {nullptr, nullptr};
     std::vector<int> h_big; // nodes with more than LEI_SG_CAP edges (for big_mode = use_both)
     void release() {
-        void *ps[] = {label, refined, out, dec, cmin, sc, sidx, sival, first, flag, rank, biglist, counts, win, mv, se, sum_tot, kdeg,
-                      tmp, sw, dk, sdval, scal, s_in, Jq, Lq, scan_tmp, bigoff};
+        void *ps[] = {label, refined, out, dec, cmin, sc, first, flag, rank, biglist, counts, win, mv, se, sum_tot, kdeg,
+                      tmp, sw, dk, scal, s_in, Jq, Lq, scan_tmp, bigoff, okeys, okeys_s, oiota, oops_s, osort_tmp};
         for (void *q : ps)
             (void)hipFree(q);
         if (h_out)
@@ -1004,6 +1032,8 @@ template <typename T> static int wmalloc(T **p, size_t n) {
     GCHK(hipMalloc(p, (n ? n : 1) * sizeof(T)));
     return 0;
 }
+
+__global__ void k_iota(int *p, int n);
 
 // (re)size the workspace for this call; everything is kept for the next one
 static int lei_prepare(mn_graph *g, int mode, int batch, int use_both, int max_deg) {
@@ -1064,11 +1094,29 @@ static int lei_prepare(mn_graph *g, int mode, int batch, int use_both, int max_d
         w.big_mode = use_both;
     }
     if (mode == MN_LEIDEN_BATCHED && batch > w.batch_cap) {
-        if (wmalloc(&w.dec, (size_t)batch) || wmalloc(&w.dk, (size_t)batch) || wmalloc(&w.win, (size_t)batch) || wmalloc(&w.mv, (size_t)batch) ||
-            wmalloc(&w.sidx, (size_t)2 * batch + 2) || wmalloc(&w.sival, (size_t)2 * batch + 2) ||
-            wmalloc(&w.sdval, (size_t)2 * batch + 2))
+        if (wmalloc(&w.dec, (size_t)batch) || wmalloc(&w.dk, (size_t)batch) || wmalloc(&w.win, (size_t)batch) || wmalloc(&w.mv, (size_t)batch))
             return -1;
         w.batch_cap = batch;
+    }
+    if (mode == MN_LEIDEN_BATCHED && g->weighted && (batch > w.ocap || !w.okeys)) {
+        const size_t n_ops = (size_t)2 * batch;
+        if (wmalloc(&w.okeys, n_ops) || wmalloc(&w.okeys_s, n_ops) || wmalloc(&w.oiota, n_ops) || wmalloc(&w.oops_s, n_ops))
+            return -1;
+        hipLaunchKernelGGL(k_iota, dim3((unsigned)((n_ops + 255) / 256)), dim3(256), 0, st, w.oiota, (int)n_ops);
+        w.osort_bits = 1;
+        while (w.osort_bits < 31 && (1ll << w.osort_bits) <= (long long)N) // keys 0..N (N = "not a winner")
+            w.osort_bits++;
+        size_t bytes = 0;
+        if (rocprim::radix_sort_pairs(nullptr, bytes, w.okeys, w.okeys_s, w.oiota, w.oops_s, n_ops, 0, w.osort_bits, st) != hipSuccess) {
+            gset_err("rocprim::radix_sort_pairs (size query) failed");
+            return -1;
+        }
+        if (w.osort_tmp)
+            (void)hipFree(w.osort_tmp);
+        w.osort_tmp = nullptr;
+        GCHK(hipMalloc(&w.osort_tmp, bytes ? bytes : 16));
+        w.osort_bytes = bytes;
+        w.ocap = batch;
     }
     // global scratch for nodes whose edges do not fit in LDS: the sequential kernel reuses one region of max_deg entries,
     // the batched rounds give every such node its own (bigoff) — sized by those nodes' degrees, not by the round
@@ -1156,15 +1204,6 @@ static int dev_renumber(mn_graph *g, int *label) {
     return 0;
 }
 
-// host mirrors of the phase's label / sum_tot (weighted graphs: winners are applied here in node order)
-struct HostState {
-    std::vector<int> *label;
-    std::vector<double> *sum_tot;
-    const std::vector<double> *k;
-    int *d_sidx, *d_sival;
-    double *d_sdval;
-};
-
 // the tail rule's constants; MN_LEIDEN_GROW="factor,divisor" is a tuning knob (the oracle reads ORC_LEI_GROW the same way:
 // other values give another — equally valid — schedule, so parity holds only when both sides are set alike)
 static void lei_grow_setting(int *grow, int *grow_div) {
@@ -1177,7 +1216,7 @@ static void lei_grow_setting(int *grow, int *grow_div) {
 }
 
 // one phase (local moving when elig_part == nullptr, refinement otherwise); returns moves, -1 on error
-static long long run_phase(mn_graph *g, LeiArgs a, int mode, int batch, int64_t *sweeps_out, HostState *hs) {
+static long long run_phase(mn_graph *g, LeiArgs a, int mode, int batch, int64_t *sweeps_out) {
     hipStream_t st = g->stream;
     int out[3] = {0, 0, 0};
     if (mode == MN_LEIDEN_SEQUENTIAL) {
@@ -1196,12 +1235,6 @@ static long long run_phase(mn_graph *g, LeiArgs a, int mode, int batch, int64_t 
     const std::vector<int> &big = g->work->h_big;
     long long total = 0;
     int improved = 1, sweeps = 0, parity = 0;
-    int grow_cap, div_unused;
-    lei_grow_setting(&grow_cap, &div_unused);
-    const size_t round_cap = (size_t)std::min<long long>((long long)batch * grow_cap, std::max(batch, g->n));
-    std::vector<int> h_dec(round_cap), ch_idx, ch_ival, touched;
-    std::vector<unsigned char> h_win(round_cap);
-    std::vector<double> ch_dval;
     const bool hashed = !g->weighted; // every weight 1.0 → counts (best_move_hash)
     int sg = (double)(a.use_both ? g->e_out + g->e_in : g->e_out) / std::max(1, g->n) > 48.0 ? 32 : 16;
     if (const char *e = getenv("MN_LEIDEN_SG")) // tuning knob: 16 or 32 lanes per node
@@ -1215,7 +1248,7 @@ static long long run_phase(mn_graph *g, LeiArgs a, int mode, int batch, int64_t 
     int grow, grow_div;
     lei_grow_setting(&grow, &grow_div);
     const int batch0 = batch;
-    long long moves_prev = -1, moves_prev2 = -1; // sweeps s-1 and s-2 (as far as the host has seen them)
+    long long moves_prev2 = -1; // sweep s-2 (as far as the host has seen it)
     while (improved && sweeps < a.max_sweeps) {
         improved = 0;
         sweeps++;
@@ -1226,7 +1259,6 @@ static long long run_phase(mn_graph *g, LeiArgs a, int mode, int batch, int64_t 
         a.out = out_base + 8 * blk;
         GCHK(hipMemsetAsync(a.out, 0, 8 * sizeof(int), st));
         parity = 0;
-        long long sweep_moves = 0;
         size_t bigpos = 0;
         for (int b = 0; b < g->n; b += batch) {
             a.b0 = b;
@@ -1255,63 +1287,24 @@ static long long run_phase(mn_graph *g, LeiArgs a, int mode, int batch, int64_t 
                     hipLaunchKernelGGL((k_leiden_eval<16, false>), grid, blk, lds, st, a, nsmall, wlds);
             }
             hipLaunchKernelGGL(k_leiden_win, dim3((nb * 8 + 255) / 256), dim3(256), 0, st, a);
-            ch_idx.clear();
-            ch_ival.clear();
-            touched.clear();
             if (!a.apply_on_device) {
-                // weighted graph: several winners may share a community and f64 addition is not
-                // associative → apply them here, in node order, on the host mirrors
-                GCHK(hipMemcpyAsync(h_dec.data(), a.dec, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, st));
-                GCHK(hipMemcpyAsync(h_win.data(), a.win, (size_t)nb, hipMemcpyDeviceToHost, st));
-                GCHK(hipMemcpyAsync(out, a.out, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
-                GCHK(hipStreamSynchronize(st));
-                const int use_bit = out[1 + parity] > 0 ? 1 : 2;
-                std::vector<int> &L = *hs->label;
-                std::vector<double> &S = *hs->sum_tot;
-                for (int v = a.b0; v < a.b1; v++) {
-                    const int old = L[v], best = h_dec[v - a.b0];
-                    if (best != old && (h_win[v - a.b0] & use_bit)) {
-                        S[old] -= (*hs->k)[v];
-                        S[best] += (*hs->k)[v];
-                        L[v] = best;
-                        ch_idx.push_back(v);
-                        ch_ival.push_back(best);
-                        touched.push_back(old);
-                        touched.push_back(best);
-                        sweep_moves++;
-                    }
+                // weighted graph: several winners may share a community and f64 addition is not associative → the round's
+                // operations are grouped by community with a stable sort and every community replays its own in node order
+                LeiWork &w = *g->work;
+                const int n_ops = 2 * nb;
+                hipLaunchKernelGGL(k_leiden_ops, dim3((nb + 255) / 256), dim3(256), 0, st, a, g->n, w.okeys);
+                size_t bytes = w.osort_bytes;
+                if (rocprim::radix_sort_pairs(w.osort_tmp, bytes, w.okeys, w.okeys_s, w.oiota, w.oops_s, (size_t)n_ops, 0, w.osort_bits,
+                                              st) != hipSuccess) {
+                    gset_err("rocprim::radix_sort_pairs failed");
+                    return -1;
                 }
+                hipLaunchKernelGGL(k_leiden_apply_ops, dim3((n_ops + 255) / 256), dim3(256), 0, st, a, g->n, w.okeys_s, w.oops_s, n_ops);
             }
             hipLaunchKernelGGL(k_leiden_apply, dim3((nb + 255) / 256), dim3(256), 0, st, a); // resets tallies (+ applies)
             parity ^= 1;
-            if (!ch_idx.empty()) {
-                int nc = (int)ch_idx.size();
-                GCHK(hipMemcpyAsync(hs->d_sidx, ch_idx.data(), (size_t)nc * sizeof(int), hipMemcpyHostToDevice, st));
-                GCHK(hipMemcpyAsync(hs->d_sival, ch_ival.data(), (size_t)nc * sizeof(int), hipMemcpyHostToDevice, st));
-                hipLaunchKernelGGL(k_scatter_i, dim3((nc + 255) / 256), dim3(256), 0, st, a.label, hs->d_sidx, hs->d_sival, nc);
-                GCHK(hipStreamSynchronize(st)); // d_sidx is reused for the sum_tot scatter
-                std::sort(touched.begin(), touched.end());
-                touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
-                nc = (int)touched.size();
-                ch_dval.resize((size_t)nc);
-                for (int i = 0; i < nc; i++)
-                    ch_dval[(size_t)i] = (*hs->sum_tot)[touched[(size_t)i]];
-                GCHK(hipMemcpyAsync(hs->d_sidx, touched.data(), (size_t)nc * sizeof(int), hipMemcpyHostToDevice, st));
-                GCHK(hipMemcpyAsync(hs->d_sdval, ch_dval.data(), (size_t)nc * sizeof(double), hipMemcpyHostToDevice, st));
-                hipLaunchKernelGGL(k_scatter_d, dim3((nc + 255) / 256), dim3(256), 0, st, a.sum_tot, hs->d_sidx, hs->d_sdval, nc);
-                GCHK(hipStreamSynchronize(st));
-            }
         }
         GCHK(hipGetLastError());
-        if (!a.apply_on_device) {
-            if (sweep_moves) {
-                improved = 1;
-                total += sweep_moves;
-            }
-            moves_prev2 = moves_prev;
-            moves_prev = sweep_moves;
-            continue;
-        }
         // Moves applied on the device: the count of this sweep travels to pinned memory behind the sweep, and the NEXT sweep
         // is queued before the host looks at the PREVIOUS one — the launch queue never drains.  If that previous sweep
         // moved nothing the state is a fixed point: the sweep just queued moves nothing either and is not counted.
@@ -1402,7 +1395,7 @@ extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int
     }
     hipLaunchKernelGGL(k_iota, dim3(nbN), dim3(256), 0, st, d.label, N);
     GCHK(hipMemcpyAsync(d.sum_tot, d.kdeg, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, st));
-    std::vector<double> sum_tot, r_sum_tot;
+    std::vector<double> sum_tot;
     if (!on_dev) {
         community.resize((size_t)N);
         refined.resize((size_t)N);
@@ -1438,15 +1431,12 @@ extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int
         a.big_log2h++;
     a.biglist = d.biglist;
     a.bigoff = d.bigoff;
-    HostState hs = {&community, &sum_tot, &k, d.sidx, d.sival, d.sdval};
 
     for (int iter = 0; iter < 100; iter++) { // :368-417
         a.label = d.label;
         a.sum_tot = d.sum_tot;
         a.elig_part = nullptr;
-        hs.label = &community;
-        hs.sum_tot = &sum_tot;
-        long long moves = run_phase(g, a, mode, batch, &g->stats.move_sweeps, &hs);
+        long long moves = run_phase(g, a, mode, batch, &g->stats.move_sweeps);
         if (moves < 0)
             return -1;
         g->stats.iterations++;
@@ -1463,11 +1453,8 @@ extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int
             GCHK(hipMemcpyAsync(community.data(), d.label, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, st));
             for (int i = 0; i < N; i++)
                 refined[i] = i;
-            r_sum_tot = k;
-            hs.label = &refined;
-            hs.sum_tot = &r_sum_tot;
         }
-        if (run_phase(g, a, mode, batch, &g->stats.refine_sweeps, &hs) < 0)
+        if (run_phase(g, a, mode, batch, &g->stats.refine_sweeps) < 0)
             return -1;
         if (on_dev) {
             // :388-408 adopt the refinement iff it has no more communities than phase 1; then renumber (:317-331)

@@ -137,7 +137,8 @@ static void fn_node2vec_train(sqlite3_context *ctx, int argc, sqlite3_value **ar
     nm_init(&nm);
     EList *adj = 0;
     int adj_cap = 0;
-    while (sqlite3_step(st) == SQLITE_ROW) {
+    int load_rc = SQLITE_OK, oom = 0;
+    while (!oom && (load_rc = sqlite3_step(st)) == SQLITE_ROW) {
         const char *s = (const char *)sqlite3_column_text(st, 0);
         if (!s)
             continue;
@@ -147,9 +148,13 @@ static void fn_node2vec_train(sqlite3_context *ctx, int argc, sqlite3_value **ar
             sqlite3_free(scopy);
             continue;
         }
-        int si = nm_get(&nm, scopy);
-        int di = nm_get(&nm, d);
+        int si = scopy ? nm_get(&nm, scopy) : -1;
+        int di = si >= 0 ? nm_get(&nm, d) : -1;
         sqlite3_free(scopy);
+        if (si < 0 || di < 0) {
+            oom = 1;
+            break;
+        }
         adj = lists_grow(adj, &adj_cap, nm.n);
         for (int dir = 0; dir < 2; dir++) {
             int a = dir ? di : si, b = dir ? si : di;
@@ -164,6 +169,14 @@ static void fn_node2vec_train(sqlite3_context *ctx, int argc, sqlite3_value **ar
         }
     }
     sqlite3_finalize(st);
+    if (oom || load_rc != SQLITE_DONE) { /* a step error is an error, not the end of the rows */
+        for (int i = 0; adj && i < adj_cap; i++)
+            free(adj[i].v);
+        free(adj);
+        nm_free(&nm);
+        sqlite3_result_error(ctx, oom ? "node2vec_train: out of memory" : "node2vec_train: failed to load edges", -1);
+        return;
+    }
     const int n = nm.n;
     if (n == 0) {
         nm_free(&nm);
@@ -557,7 +570,8 @@ int mn_sql_load_graph(sqlite3 *db, const char *who, const char *edge_table, cons
     nm_init(&nm);
     EList *outl = 0, *inl = 0;
     int ocap = 0, icap = 0;
-    while (sqlite3_step(st) == SQLITE_ROW) {
+    int load_rc = SQLITE_OK, oom = 0;
+    while (!oom && (load_rc = sqlite3_step(st)) == SQLITE_ROW) {
         const char *s = (const char *)sqlite3_column_text(st, 0);
         if (!s)
             continue;
@@ -568,9 +582,13 @@ int mn_sql_load_graph(sqlite3 *db, const char *who, const char *edge_table, cons
             continue;
         }
         double w = with_w ? sqlite3_column_double(st, 2) : 1.0;
-        int si = nm_get(&nm, scopy);
-        int di = nm_get(&nm, d);
+        int si = scopy ? nm_get(&nm, scopy) : -1;
+        int di = si >= 0 ? nm_get(&nm, d) : -1;
         sqlite3_free(scopy);
+        if (si < 0 || di < 0) {
+            oom = 1;
+            break;
+        }
         outl = lists_grow(outl, &ocap, nm.n);
         inl = lists_grow(inl, &icap, nm.n);
         if (add_fwd)
@@ -579,6 +597,17 @@ int mn_sql_load_graph(sqlite3 *db, const char *who, const char *edge_table, cons
             el_push(&inl[di], si, w, with_w);
     }
     sqlite3_finalize(st);
+    if (oom || load_rc != SQLITE_DONE) { /* a step error is an error, not the end of the rows */
+        for (int i = 0; outl && i < ocap; i++)
+            free(outl[i].v), free(outl[i].w);
+        for (int i = 0; inl && i < icap; i++)
+            free(inl[i].v), free(inl[i].w);
+        free(outl);
+        free(inl);
+        nm_free(&nm);
+        *err = sqlite3_mprintf("%s: %s", who, oom ? "out of memory" : "failed to read the edge table");
+        return oom ? SQLITE_NOMEM : SQLITE_ERROR;
+    }
     const int n = nm.n;
     if (n == 0) {
         nm_free(&nm);

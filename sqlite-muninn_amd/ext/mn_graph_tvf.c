@@ -113,23 +113,42 @@ static int read_edges(sqlite3 *db, const char *t, const char *sc, const char *dc
         return rc;
     long long n = 0, cap = 1024;
     int *s = (int *)malloc((size_t)cap * sizeof(int)), *d = (int *)malloc((size_t)cap * sizeof(int));
-    while (sqlite3_step(st) == SQLITE_ROW) {
+    int oom = !s || !d;
+    while (!oom && (rc = sqlite3_step(st)) == SQLITE_ROW) {
         const char *a = (const char *)sqlite3_column_text(st, 0);
         const char *b = (const char *)sqlite3_column_text(st, 1);
         if (!a || !b)
             continue;
         if (n >= cap) {
+            int *s2 = (int *)realloc(s, (size_t)cap * 2 * sizeof(int));
+            if (s2)
+                s = s2;
+            int *d2 = s2 ? (int *)realloc(d, (size_t)cap * 2 * sizeof(int)) : 0;
+            if (d2)
+                d = d2;
+            if (!s2 || !d2) {
+                oom = 1;
+                break;
+            }
             cap *= 2;
-            s = (int *)realloc(s, (size_t)cap * sizeof(int));
-            d = (int *)realloc(d, (size_t)cap * sizeof(int));
         }
         int si = nm_get(nm, a); /* (a's text pointer is only valid until the next column call: nm_get copies) */
         b = (const char *)sqlite3_column_text(st, 1);
+        int di = b ? nm_get(nm, b) : -1;
+        if (si < 0 || di < 0) {
+            oom = 1;
+            break;
+        }
         s[n] = si;
-        d[n] = nm_get(nm, b);
+        d[n] = di;
         n++;
     }
     sqlite3_finalize(st);
+    if (oom || rc != SQLITE_DONE) { /* a step error is an error, not the end of the rows */
+        free(s);
+        free(d);
+        return oom ? SQLITE_NOMEM : rc;
+    }
     *src = s;
     *dst = d;
     *ne = n;

@@ -61,33 +61,44 @@ MN_UNUSED static void nm_init(NodeMap *m) {
     m->ids = (char **)calloc((size_t)m->cap, sizeof(char *));
     m->nslots = 1024;
     m->slots = (int *)malloc((size_t)m->nslots * sizeof(int));
-    for (int i = 0; i < m->nslots; i++)
+    for (int i = 0; m->slots && i < m->nslots; i++)
         m->slots[i] = -1;
 }
 
 MN_UNUSED static void nm_free(NodeMap *m) {
-    for (int i = 0; i < m->n; i++)
+    for (int i = 0; m->ids && i < m->n; i++)
         free(m->ids[i]);
     free(m->ids);
     free(m->slots);
 }
 
-MN_UNUSED static int nm_get(NodeMap *m, const char *id) { /* first-seen index, as graph_node_index / graph_data_find_or_add */
+/* first-seen index, as graph_node_index / graph_data_find_or_add; -1 = out of memory (the map stays consistent) */
+MN_UNUSED static int nm_get(NodeMap *m, const char *id) {
+    if (!m->ids || !m->slots)
+        return -1;
     unsigned long h = djb2(id);
     for (int i = 0;; i++) {
         int s = (int)((h + (unsigned long)i) & (unsigned long)(m->nslots - 1));
         if (m->slots[s] < 0) {
             if (m->n >= m->cap) {
+                char **ni = (char **)realloc(m->ids, (size_t)m->cap * 2 * sizeof(char *));
+                if (!ni)
+                    return -1;
+                m->ids = ni;
                 m->cap *= 2;
-                m->ids = (char **)realloc(m->ids, (size_t)m->cap * sizeof(char *));
             }
             size_t len = strlen(id) + 1;
-            m->ids[m->n] = (char *)malloc(len);
-            memcpy(m->ids[m->n], id, len);
-            m->slots[s] = m->n++;
-            if (m->n * 10 > m->nslots * 7) { /* rehash */
+            char *copy = (char *)malloc(len);
+            if (!copy)
+                return -1;
+            memcpy(copy, id, len);
+            if ((m->n + 1) * 10 > m->nslots * 7) { /* rehash first, so that a failure leaves the map as it was */
                 int ns = m->nslots * 2;
                 int *nsl = (int *)malloc((size_t)ns * sizeof(int));
+                if (!nsl) {
+                    free(copy);
+                    return -1;
+                }
                 for (int k = 0; k < ns; k++)
                     nsl[k] = -1;
                 for (int k = 0; k < m->n; k++) {
@@ -103,7 +114,14 @@ MN_UNUSED static int nm_get(NodeMap *m, const char *id) { /* first-seen index, a
                 free(m->slots);
                 m->slots = nsl;
                 m->nslots = ns;
+                for (int j = 0;; j++) { /* the new id's slot in the grown table */
+                    s = (int)((h + (unsigned long)j) & (unsigned long)(ns - 1));
+                    if (m->slots[s] < 0)
+                        break;
+                }
             }
+            m->ids[m->n] = copy;
+            m->slots[s] = m->n++;
             return m->n - 1;
         }
         if (!strcmp(m->ids[m->slots[s]], id))
