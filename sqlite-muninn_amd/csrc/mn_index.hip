@@ -1431,6 +1431,14 @@ extern "C" int mn_hnsw_search_sharded_dev(mn_index *x, mn_comm *c, const float *
         HIPCHK(hipMemsetAsync(x->sh_ovf.p + rank, 0, sizeof(unsigned long long), st));
     else
         HIPCHK(hipMemcpyAsync(x->sh_ovf.p + rank, x->ws_counters.p + 2, sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
+    if (const char *fi = getenv("MN_FAULT_INJECT")) { // test hook: "search_overflow:<rank>" = this shard reports 3 truncated lists
+        int fr = -1;
+        const unsigned long long three = 3;
+        if (sscanf(fi, "search_overflow:%d", &fr) == 1 && fr == rank) {
+            HIPCHK(hipMemcpyAsync(x->sh_ovf.p + rank, &three, sizeof(three), hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
+    }
     x->sh_ovf_pending = world;
     if (world > 1 || (c && c->nccl)) {
         if (mn_comm_allgather_dev(c, my_ids, x->sh_gids.p, per * sizeof(long long), st) ||

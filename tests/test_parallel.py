@@ -209,7 +209,7 @@ def _fault_worker(rank, world, port, q, what):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     # the failure is injected on rank 1 only, in the second batch: rank 0 is healthy and must not be left inside a collective
-    os.environ["MN_FAULT_INJECT"] = {"build": "build_shared:1:2000", "n2v": "n2v_shared:1:50"}[what]
+    os.environ["MN_FAULT_INJECT"] = {"build": "build_shared:1:2000", "n2v": "n2v_shared:1:50", "search": "search_overflow:1"}[what]
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import muninn_amd
 
@@ -220,6 +220,15 @@ def _fault_worker(rank, world, port, q, what):
             X = np.random.default_rng(77).standard_normal((6000, 24)).astype(np.float32)
             g = pkg.HnswIndex(24, "cosine", 8, 60)
             pkg.parallel.build_distributed(g, np.arange(5, 6005, dtype=np.int64), X, 16, 1024, min_split=64)
+        elif what == "search":  # config 3: a shard whose heap workspace overflowed returns truncated lists
+            X = np.random.default_rng(5 + rank).standard_normal((3000, 16)).astype(np.float32)
+            g = pkg.HnswIndex(16, "l2", 8, 60)
+            assert g.build(np.arange(3000, dtype=np.int64) * world + rank, X, 16, 1024) == 0
+            comm = pkg.parallel.Comm(0)
+            try:
+                pkg.parallel.search_sharded(g, comm, X[:20], 5, 40)
+            finally:
+                comm.close()
         else:
             from oracle import orc_graph as og
             from oracle.graph_cases import planted
@@ -232,6 +241,26 @@ def _fault_worker(rank, world, port, q, what):
     q.put((rank, msg))
     dist.barrier()
     dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_a_shard_whose_search_overflowed_fails_the_sharded_search_on_every_rank(gpu):
+    """mn_hnsw_search_sharded: every shard's heap-workspace overflow count travels with its top-k lists; a shard that
+    overflowed (here injected on rank 1) makes the call fail on EVERY rank, naming the shard, instead of merging a truncated
+    list and returning rc 0 (the unsharded mn_hnsw_search_batch has always failed in that case)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fault_worker, args=(r, world, port, q, "search")) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(_collect(procs, q, world, 300))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert "shard 1" in res[r] and "exceeded heap workspace" in res[r], res
 
 
 @pytest.mark.gpu
