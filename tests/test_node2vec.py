@@ -183,20 +183,22 @@ def test_config4_shape_properties_200k_nodes(gpu):
 
 
 @pytest.mark.gpu
-def test_train_into_index_keeps_the_embeddings_in_hbm_and_builds_the_same_graph(gpu):
+@pytest.mark.parametrize("dim", [64, 30])
+def test_train_into_index_keeps_the_embeddings_in_hbm_and_builds_the_same_graph(gpu, dim):
     """mn_node2vec_train_into (config 4's "-> hnsw0 index" leg, src/node2vec.c:540-583): the embeddings are trained, normalised
     and handed to the index build inside HBM.  Same embedding bytes as mn_node2vec_train in the same mode, and the index is the
-    graph mn_hnsw_build makes from a host copy of those embeddings with the reference's rowids (first-seen index + 1)."""
+    graph mn_hnsw_build makes from a host copy of those embeddings with the reference's rowids (first-seen index + 1).
+    (dim 30: the index pads rows to 32 floats, so the device-to-device hand-off is a strided copy.)"""
     from oracle.graph_cases import planted
 
     s, d, _ = planted(3000, 6, 0.05, 0.001, 11)
     g = og.N2vGraph(s, d)
-    want, st1 = gpu.node2vec_train(g.off, g.adj, 64, 1.0, 1.0, 3, 20, 4, 3, 0.025, 1, mode=gpu.N2V_BATCHED, batch_walks=200)
-    ix = gpu.HnswIndex(64, "cosine", 8, 60)
-    emb, st = gpu.graph.node2vec_train_into(g.off, g.adj, 64, ix, 1, True, 1.0, 1.0, 3, 20, 4, 3, 0.025, 1, 200)
+    want, st1 = gpu.node2vec_train(g.off, g.adj, dim, 1.0, 1.0, 3, 20, 4, 3, 0.025, 1, mode=gpu.N2V_BATCHED, batch_walks=200)
+    ix = gpu.HnswIndex(dim, "cosine", 8, 60)
+    emb, st = gpu.graph.node2vec_train_into(g.off, g.adj, dim, ix, 1, True, 1.0, 1.0, 3, 20, 4, 3, 0.025, 1, 200)
     assert np.array_equal(emb.view(np.int32), want.view(np.int32)) and st["pairs"] == st1["pairs"]
     ids = np.arange(1, g.n + 1, dtype=np.int64)
-    ref = gpu.HnswIndex(64, "cosine", 8, 60)
+    ref = gpu.HnswIndex(dim, "cosine", 8, 60)
     assert ref.build(ids, want, 16, 8192) == 0
     assert ix.node_count == g.n and ix.entry_point == ref.entry_point and ix.max_level == ref.max_level
     assert np.array_equal(ix.export_links(0), ref.export_links(0)) and np.array_equal(ix.export_links(1), ref.export_links(1))
