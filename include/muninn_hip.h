@@ -83,6 +83,23 @@ int mn_hnsw_insert(mn_index *idx, int64_t id, const float *vector);
 /* n inserts in one call.  mode MN_BUILD_SEQUENTIAL ≡ n × mn_hnsw_insert; MN_BUILD_BATCHED is the
  * batch-synchronous schedule.  vectors is host [n][dim].  Returns 0 / -1 (nothing inserted on -1). */
 int mn_hnsw_insert_batch(mn_index *idx, const int64_t *ids, const float *vectors, int64_t n, int mode);
+/* hnsw_insert that also reports which edges it added / removed, for a host that persists the graph edge by edge (the "{t}_edges"
+ * shadow table: src/hnsw_vtab.c:755-776 rewrites every edge of the new node AND of each of its neighbours per insert; with the
+ * log only the changed rows are touched).  *n_log = entries written, or -1 when the log cannot describe this insert: more
+ * than cap changes, a list wider than 64 links, or a touched node whose persisted copy is not known to match the index —
+ * its lists were edited by mn_hnsw_delete (which the reference never persists, src/hnsw_vtab.c:702-706) or the caller said
+ * so with mn_hnsw_log_invalidate.  mn_hnsw_take_dirty is then still complete (and taking a node through it makes the node
+ * known again); with a valid log the persist set is emptied.  Same graph and return convention as mn_hnsw_insert. */
+typedef struct {
+    int op;          /* 1: edge src -> dst added at `level` with `distance`;  2: edge src -> dst removed */
+    int level;
+    int64_t src, dst;
+    float distance;  /* dist_func(src vector, dst vector), as persist_node stores it (src/hnsw_vtab.c:262-280) */
+} mn_edge_change;
+int mn_hnsw_insert_logged(mn_index *idx, int64_t id, const float *vector, mn_edge_change *log, int cap, int *n_log);
+/* the caller's persisted copy of these n nodes — or, ids == NULL, of every node present now (a ROLLBACK took rows away that the
+ * index keeps) — is not what the index holds: unknown until rewritten whole.  Ids that are not in the index are ignored. */
+int mn_hnsw_log_invalidate(mn_index *idx, const int64_t *ids, int64_t n);
 /* Bulk build helper: splits [n] into batches growing with the index (batch ≤ max(1, count/grow_div),
  * capped at max_batch) and calls the batched schedule on each.  grow_div ≤ 0 → 16, max_batch ≤ 0 → 8192. */
 int mn_hnsw_build(mn_index *idx, const int64_t *ids, const float *vectors, int64_t n, int grow_div, int max_batch);

@@ -129,7 +129,10 @@ void mn_launch_link(const MnDevIndex &ix, const MnLinkArgs &a, int max_tuples, h
 size_t mn_insert_seq_lds_bytes(const MnDevIndex &ix);
 void mn_launch_insert_seq(const MnDevIndex &ix, const int *d_slots, int n, int ef, int *d_state, unsigned *bitmap0,
                           long long bm0_words, unsigned *bitmap_up, long long bmu_words, uint2 *cand_ovf, int cand_gcap,
-                          uint2 *res_ovf, int res_gcap, unsigned long long *counters, hipStream_t st);
+                          uint2 *res_ovf, int res_gcap, unsigned long long *counters, hipStream_t st, int *chlog = nullptr,
+                          int chcap = 0); // chlog (n == 1 only): the insert's edge changes, mn_seq.hip MnSeqArgs
+#define MN_CHLOG_CAP 1024 // entries of one insert's change log (more: the caller falls back to the persist set)
+#define MN_CHLOG_INTS 5
 
 // speculative exact inserts (mn_spec.hip): commit a window of searched inserts in order, stop at the first stale one
 void mn_launch_spec_commit(const MnDevIndex &ix, const int *d_slots, int W, int nlev, const int *sel, const int *nsel,

@@ -126,6 +126,13 @@ struct mn_index {
     DevBuf<int> d_staged;
     // multi-GPU exchange buffers (mn_hnsw_build_shared / mn_hnsw_search_sharded)
     DevBuf<int> sh_sel, sh_nsel, sh_gcnt, sh_lcnt;
+    DevBuf<int> ws_chlog;            // change log of a single exact insert (mn_hnsw_insert_logged)
+    bool want_chlog = false;         // the next run_sequential of one node fills it
+    std::vector<int> h_chlog;        // its host copy: [0] entries or -1, then MN_CHLOG_INTS ints each
+    // slots whose lists a delete edited: the reference leaves those edits un-persisted (src/hnsw_vtab.c:702-706) until a later
+    // insert re-persists the node WHOLE, so an insert that touches one cannot be described by a change log
+    std::vector<unsigned char> h_stale;
+    int n_stale = 0;
     DevBuf<unsigned long long> sh_ovf; // [world] heap-workspace overflow counts of the last sharded search, all-gathered
     int sh_ovf_pending = 0;             // entries of sh_ovf not yet looked at by the host (0: none)
     DevBuf<long long> sh_gids, sh_lids;
@@ -585,7 +592,7 @@ extern "C" void mn_hnsw_destroy(mn_index *x) {
     x->lk_newrows.release(); x->ws_counters.release(); x->ws_state.release();
     x->er_slot.release(); x->er_level.release(); x->er_nbr.release(); x->er_dist.release();
     x->d_staged.release();
-    x->sh_sel.release(); x->sh_nsel.release(); x->sh_gcnt.release(); x->sh_lcnt.release(); x->sh_ovf.release(); x->sh_gids.release();
+    x->sh_sel.release(); x->sh_nsel.release(); x->sh_gcnt.release(); x->sh_lcnt.release(); x->sh_ovf.release(); x->ws_chlog.release(); x->sh_gids.release();
     x->sh_lids.release(); x->sh_gd.release(); x->sh_ld.release();
     x->ws_readlog.release(); x->ws_nread.release(); x->ws_ncommit.release(); x->d_stamp0.release(); x->d_stampU.release();
     if (x->ev0) (void)hipEventDestroy(x->ev0);
@@ -965,16 +972,25 @@ static int run_sequential(mn_index *x, const std::vector<int> &slots) {
     HIPCHK(hipMemcpyAsync(x->ws_qslots.p, slots.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(x->ws_state.p, state, sizeof(state), hipMemcpyHostToDevice, st));
     MnDevIndex v = dev_view(x);
+    const bool logged = x->want_chlog && n == 1;
+    x->want_chlog = false;
+    if (logged && x->ws_chlog.reserve((size_t)1 + (size_t)MN_CHLOG_CAP * MN_CHLOG_INTS, false, st))
+        return -1;
     HIPCHK(hipEventRecord(x->ev0, st));
     const int chunk = 1024; // keeps any one launch to about a second
     for (int pos = 0; pos < n; pos += chunk) {
         int m = std::min(chunk, n - pos);
         mn_launch_insert_seq(v, x->ws_qslots.p + pos, m, x->efc, x->ws_state.p, a.bitmap0, a.bm0_words, x->ws_bmu.p,
-                             bmu_words, a.cand_ovf, a.cand_gcap, a.res_ovf, a.res_gcap, a.counters, st);
+                             bmu_words, a.cand_ovf, a.cand_gcap, a.res_ovf, a.res_gcap, a.counters, st,
+                             logged ? x->ws_chlog.p : nullptr, MN_CHLOG_CAP);
     }
     HIPCHK(hipEventRecord(x->ev1, st));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(state, x->ws_state.p, sizeof(state), hipMemcpyDeviceToHost, st));
+    if (logged) {
+        x->h_chlog.assign((size_t)1 + (size_t)MN_CHLOG_CAP * MN_CHLOG_INTS, 0);
+        HIPCHK(hipMemcpyAsync(x->h_chlog.data(), x->ws_chlog.p, x->h_chlog.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+    }
     if (fetch_counters(x))
         return -1;
     if (x->last.last_n_overflow) {
@@ -1203,8 +1219,13 @@ extern "C" int64_t mn_hnsw_take_dirty(mn_index *x, int64_t *ids, int64_t cap) {
         return cnt; // nothing cleared: call again with room for cnt ids
     int64_t o = 0;
     for (size_t s = 0; s < n; s++)
-        if (h[s])
+        if (h[s]) {
             ids[o++] = x->ids[s];
+            if (s < x->h_stale.size() && x->h_stale[s]) { // the caller rewrites this node whole
+                x->h_stale[s] = 0;
+                x->n_stale--;
+            }
+        }
     HIPCHK(hipMemset(x->d_dirty.p, 0, n));
     return cnt;
 }
@@ -1215,6 +1236,77 @@ extern "C" int mn_hnsw_insert(mn_index *x, int64_t id, const float *vector) {
 
 extern "C" int mn_hnsw_insert_batch(mn_index *x, const int64_t *ids, const float *vectors, int64_t n, int mode) {
     return insert_impl(x, ids, vectors, n, mode);
+}
+
+// hnsw_insert (src/hnsw_algo.c:520-666) that also says WHICH edges it added and removed: the caller's persistence
+// (src/hnsw_vtab.c:755-776 rewrites the "{t}_edges" rows of the new node and of every neighbour — ≈ 1 100 rows per insert) can
+// then touch only the ≈ 100 rows that changed.  *n_log = entries written (op 1: edge src -> dst added at `level` with
+// `distance`; op 2: edge src -> dst removed), or -1 when the log cannot describe this insert (more than `cap` changes, a
+// neighbour list wider than 64 links, or a touched node whose lists an earlier mn_hnsw_delete edited — the reference never
+// persisted those edits, so only a whole rewrite of that node matches it): the persist set (mn_hnsw_take_dirty) is then
+// still complete.  With a valid log the persist set is emptied — the caller has everything.  Same graph, same return
+// convention as mn_hnsw_insert.
+extern "C" int mn_hnsw_insert_logged(mn_index *x, int64_t id, const float *vector, mn_edge_change *log, int cap, int *n_log) {
+    *n_log = -1;
+    if (use_device(x))
+        return -1;
+    const int was_slots = x->n_slots;
+    x->want_chlog = true;
+    x->h_chlog.clear();
+    const int rc = insert_impl(x, &id, vector, 1, MN_BUILD_SEQUENTIAL);
+    x->want_chlog = false;
+    if (rc != 0)
+        return rc;
+    if (x->n_slots == was_slots + 1 && x->h_chlog.empty()) { // first node of an empty index: no search, no edges
+        *n_log = 0;
+    } else if (!x->h_chlog.empty() && x->h_chlog[0] >= 0 && x->h_chlog[0] <= cap) {
+        const int n = x->h_chlog[0];
+        bool stale = false; // touched = the new node's selected neighbours = dst of its own "added" entries
+        for (int i = 0; i < n && x->n_stale > 0 && !stale; i++) {
+            const int *e = x->h_chlog.data() + 1 + (size_t)i * MN_CHLOG_INTS;
+            stale = e[0] == 1 && (size_t)e[3] < x->h_stale.size() && x->h_stale[e[3]];
+        }
+        for (int i = 0; i < n && !stale; i++) {
+            const int *e = x->h_chlog.data() + 1 + (size_t)i * MN_CHLOG_INTS;
+            log[i].op = e[0];
+            log[i].src = x->ids[e[1]];
+            log[i].level = e[2];
+            log[i].dst = x->ids[e[3]];
+            memcpy(&log[i].distance, &e[4], sizeof(float));
+        }
+        if (!stale)
+            *n_log = n;
+    }
+    if (*n_log >= 0 && x->d_dirty.p && x->n_slots > 0) // (the log replaces the persist set for this insert)
+        HIPCHK(hipMemsetAsync(x->d_dirty.p, 0, std::min((size_t)x->n_slots, x->d_dirty.cap), x->stream));
+    return 0;
+}
+
+// The caller's edge-by-edge copy of the graph no longer matches the index — for the n given nodes, or (ids == NULL) for every
+// node present now (its transaction rolled back): logged inserts report -1 for every insert that touches such a node, until
+// the node has gone through the persist set (a whole rewrite).  Unknown ids are ignored.
+static void mark_stale(mn_index *x, int slot) {
+    if (x->h_stale.size() < (size_t)x->n_slots)
+        x->h_stale.resize((size_t)x->n_slots, 0);
+    if (!x->h_stale[slot]) {
+        x->h_stale[slot] = 1;
+        x->n_stale++;
+    }
+}
+extern "C" int mn_hnsw_log_invalidate(mn_index *x, const int64_t *ids, int64_t n) {
+    if (!x)
+        return -1;
+    if (!ids) {
+        x->h_stale.assign((size_t)x->n_slots, 1);
+        x->n_stale = x->n_slots;
+        return 0;
+    }
+    for (int64_t i = 0; i < n; i++) {
+        const int s = ht_find(x, ids[i]);
+        if (s >= 0)
+            mark_stale(x, s);
+    }
+    return 0;
 }
 
 static int build_impl(mn_index *x, const int64_t *ids, const float *vectors, int64_t n, int grow_div, int max_batch,
@@ -1597,6 +1689,7 @@ extern "C" int mn_hnsw_delete(mn_index *x, int64_t id) { // src/hnsw_algo.c:717-
         const int slot = (int)(k & 0xffffffffu), level = (int)(k >> 32);
         const std::vector<int> &list = ed.rows[k];
         const int W = level == 0 ? x->W0 : x->WU;
+        mark_stale(x, slot);
         std::vector<int> padded((size_t)W, -1);
         std::copy(list.begin(), list.end(), padded.begin());
         if (x->host_links_valid) {
@@ -1720,8 +1813,10 @@ extern "C" int mn_hnsw_load_neighbors(mn_index *x, int64_t id, int level, const 
         return -1;
     for (int i = 0; i < n; i++) {
         int t = ht_find(x, nbrs[i]);
-        if (t < 0)
+        if (t < 0) { // (a row the caller holds and the index does not: a whole rewrite of s is what removes it)
+            mark_stale(x, s);
             continue;
+        }
         int W;
         int *row = h_row(x, s, level, &W);
         int cnt = h_row_count(row, W);

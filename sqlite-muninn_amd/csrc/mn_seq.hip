@@ -26,12 +26,52 @@ struct MnSeqArgs {
     unsigned long long *counters;
     int SB; // LDS entries of the selected-list buffer (>= M0)
     int LW; // LDS entries of each prune array (>= longest list + 1, multiple of 64)
+    // change log of ONE insert (n == 1; null otherwise): which edges it added and removed, so that a host that persists the
+    // graph edge by edge ("{t}_edges" of the SQLite extension) rewrites only those rows.  chlog[0] = entries (or -1: the log
+    // cannot describe this insert — a row wider than 64 links — and the host uses the persist set instead), then entries of
+    // MN_CH_INTS ints {op (1 add, 2 delete), source slot, level, target slot, distance bits}
+    int *chlog;
+    int chcap;
 };
+#define MN_CH_INTS 5
+
+DEVI void seq_log(const MnSeqArgs &a, int &nlog, int op, int src, int level, int dst, unsigned dist_bits) { // lane 0 only
+    if (nlog < 0)
+        return;
+    if (nlog >= a.chcap) {
+        nlog = -1;
+        return;
+    }
+    int *e = a.chlog + 1 + (size_t)nlog * MN_CH_INTS;
+    e[0] = op;
+    e[1] = src;
+    e[2] = level;
+    e[3] = dst;
+    e[4] = (int)dist_bits;
+    nlog++;
+}
 
 DEVI int *seq_row(const MnDevIndex &ix, int node, int level) {
     if (level == 0)
         return ix.links0 + (size_t)node * ix.W0;
     return ix.links_up + ((size_t)ix.up_off[node] + (level - 1)) * ix.WU;
+}
+
+// Does any list of node t hold a soft-deleted node?  persist_node writes such a link with distance 0 (hnsw_get_node is NULL
+// for it, src/hnsw_vtab.c:272-273) whenever it rewrites t, so an insert that touches t changes a row no edge of the insert
+// names: the change log gives up and the host rewrites t whole.
+DEVI bool seq_links_deleted(const MnDevIndex &ix, int t, int lane) {
+    bool bad = false;
+    const int top = ix.levels[t];
+    for (int lv = 0; lv <= top; lv++) {
+        const int *row = seq_row(ix, t, lv);
+        const int W = lv == 0 ? ix.W0 : ix.WU;
+        for (int c0 = 0; c0 < W; c0 += 64) {
+            const int v = c0 + lane < W ? ld_link<true>(row + c0 + lane) : -1;
+            bad |= v >= 0 && ix.deleted[v] != 0;
+        }
+    }
+    return __ballot(bad) != 0;
 }
 
 template <int ORDER, int NCH, bool WIDE = false>
@@ -42,7 +82,8 @@ __global__ void __launch_bounds__(64) k_insert_seq(MnDevIndex ix, MnSeqArgs a) {
     uint2 *res_l = cand_l + MN_CAND_LDS;
     int *scratch = reinterpret_cast<int *>(res_l + MN_RES_LDS); // [64]
     int *selbuf = scratch + 64;                                 // [SB]
-    int *list = selbuf + a.SB;                                  // [LW]
+    unsigned *seldist = reinterpret_cast<unsigned *>(selbuf + a.SB); // [SB] distance bits of the selected neighbours
+    int *list = reinterpret_cast<int *>(seldist + a.SB);        // [LW]
     float *nd = reinterpret_cast<float *>(list + a.LW);         // [LW]
     int *mn = reinterpret_cast<int *>(nd + a.LW);               // [LW]
     float *q = reinterpret_cast<float *>(mn + a.LW);            // [ld]
@@ -69,6 +110,7 @@ __global__ void __launch_bounds__(64) k_insert_seq(MnDevIndex ix, MnSeqArgs a) {
 
     int entry = a.state[0];
     int maxl = a.state[1];
+    int nlog = a.chlog ? 0 : -1; // (lane 0's count is the one written out)
 
     for (int it = 0; it < a.n; it++) {
         const int s = a.slots[it];
@@ -102,8 +144,10 @@ __global__ void __launch_bounds__(64) k_insert_seq(MnDevIndex ix, MnSeqArgs a) {
             int first = cur;
             for (int i = count - 1; i >= 0; i--) {
                 uint2 itx = heap_pop(res, lane);
-                if (i < nsel && lane == 0)
+                if (i < nsel && lane == 0) {
                     selbuf[i] = (int)itx.y;
+                    seldist[i] = itx.x ^ 0x80000000u; // (the result heap holds negated distances: flip the sign back)
+                }
                 if (i == 0)
                     first = (int)itx.y;
             }
@@ -114,12 +158,16 @@ __global__ void __launch_bounds__(64) k_insert_seq(MnDevIndex ix, MnSeqArgs a) {
                 if (lane == 0) {
                     st_link(srow + i, t); // node_add_neighbor(new_node, l, selected[i])
                     ix.dirty[t] = 1;      // every neighbour of the new node is re-persisted (src/hnsw_vtab.c:761-768)
+                    if (a.chlog)
+                        seq_log(a, nlog, 1, s, l, t, seldist[i]);
                 }
+                if (a.chlog && ix.has_deleted && seq_links_deleted(ix, t, lane))
+                    nlog = -1;
                 if (ix.levels[t] < l)      // :590
                     continue;
                 int *trow = seq_row(ix, t, l);
                 // the row, 64 links per pass (two passes when M > 32), staged in LDS in case it has to be pruned
-                int cnt = 0;
+                int cnt = 0, vold = -1;
                 bool already = false;
                 __builtin_amdgcn_wave_barrier();
                 for (int c0 = 0; c0 < W; c0 += 64) {
@@ -128,12 +176,16 @@ __global__ void __launch_bounds__(64) k_insert_seq(MnDevIndex ix, MnSeqArgs a) {
                     already |= __ballot(v == s) != 0;
                     if (c0 + lane < W)
                         list[c0 + lane] = v;
+                    vold = v; // (the log below is only kept for rows of at most 64 links: one pass)
                 }
                 if (already) // already a neighbour (:147-150)
                     continue;
                 if (cnt < M_max) {
-                    if (lane == 0)
+                    if (lane == 0) {
                         st_link(trow + cnt, s);
+                        if (a.chlog) // d(t, s) = d(s, t) bit for bit in all three metrics (src/vec_math.c:78-143)
+                            seq_log(a, nlog, 1, t, l, s, seldist[i]);
+                    }
                     continue;
                 }
                 // ── over-full: MN-RU prune of t's list (:601-646).  A list that a delete's reconnection (or a loaded
@@ -149,8 +201,32 @@ __global__ void __launch_bounds__(64) k_insert_seq(MnDevIndex ix, MnSeqArgs a) {
                 const float tnorm = ix.metric == 1 ? ix.norms[t] : 0.0f;
                 prune_any<ORDER, NCH, true>(ix, tv, tnorm, list, nd, mn, nc, M_max, l, lane);
                 w.n_dist += nc;
-                for (int i = lane; i < cnt; i += 64)
-                    st_link(trow + i, i < M_max ? list[i] : -1);
+                if (a.chlog) {
+                    // what the prune changed: every old link that is not among the M_max kept ones was removed; the new
+                    // node was added iff it is among them
+                    if (W > 64) {
+                        nlog = -1;
+                    } else {
+                        bool kept = false, s_kept = false;
+                        for (int j = 0; j < M_max; j++) {
+                            const int lj = list[j];
+                            kept |= lj == vold;
+                            s_kept |= lj == s;
+                        }
+                        unsigned long long gone = __ballot(vold >= 0 && !kept);
+                        while (gone) { // (one link, unless the row had outgrown M_max)
+                            const int gl = __ffsll((long long)gone) - 1;
+                            gone &= gone - 1;
+                            const int u = __shfl(vold, gl);
+                            if (lane == 0)
+                                seq_log(a, nlog, 2, t, l, u, 0u);
+                        }
+                        if (s_kept && lane == 0)
+                            seq_log(a, nlog, 1, t, l, s, seldist[i]);
+                    }
+                }
+                for (int i2 = lane; i2 < cnt; i2 += 64)
+                    st_link(trow + i2, i2 < M_max ? list[i2] : -1);
                 __builtin_amdgcn_wave_barrier();
             }
             if (count > 0) // :651-652
@@ -162,6 +238,8 @@ __global__ void __launch_bounds__(64) k_insert_seq(MnDevIndex ix, MnSeqArgs a) {
         }
     }
     if (lane == 0) {
+        if (a.chlog)
+            a.chlog[0] = nlog;
         a.state[0] = entry;
         a.state[1] = maxl;
         atomicAdd(&a.counters[0], w.n_dist);
@@ -175,7 +253,7 @@ size_t mn_insert_seq_lds_bytes(const MnDevIndex &ix) {
     int SB = (ix.M0 + 63) & ~63, LW = (ix.WX + 1 + 63) & ~63;
     if (LW < 192)
         LW = 192;
-    return (size_t)(MN_CAND_LDS + MN_RES_LDS) * sizeof(uint2) + (size_t)(64 + SB + 3 * LW) * sizeof(int) +
+    return (size_t)(MN_CAND_LDS + MN_RES_LDS) * sizeof(uint2) + (size_t)(64 + 2 * SB + 3 * LW) * sizeof(int) +
            2 * (size_t)ix.ld * sizeof(float);
 }
 
@@ -192,8 +270,10 @@ static int pick_nch_s(int ld) {
 
 void mn_launch_insert_seq(const MnDevIndex &ix, const int *d_slots, int n, int ef, int *d_state, unsigned *bitmap0,
                           long long bm0_words, unsigned *bitmap_up, long long bmu_words, uint2 *cand_ovf, int cand_gcap,
-                          uint2 *res_ovf, int res_gcap, unsigned long long *counters, hipStream_t st) {
+                          uint2 *res_ovf, int res_gcap, unsigned long long *counters, hipStream_t st, int *chlog, int chcap) {
     MnSeqArgs a;
+    a.chlog = n == 1 ? chlog : nullptr;
+    a.chcap = chcap;
     a.slots = d_slots;
     a.n = n;
     a.ef = ef;

@@ -29,6 +29,7 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 typedef struct {
     sqlite3_vtab base;
@@ -44,7 +45,16 @@ typedef struct {
     unsigned char *pset_used;
     int pset_cap;
     int mode; /* MUNINN_HNSW_MODE */
+    /* exact mode, one row at a time: the device says which edges the insert added and removed, and only those rows of
+     * "{t}_edges" are written (insert_one_delta) — valid for nodes whose shadow rows equal the index.  A ROLLBACK takes rows
+     * away that the index (like the reference's in-memory one) keeps, and a DELETE edits lists the reference never persists:
+     * the index then reports "no log" for inserts touching such nodes (mn_hnsw_log_invalidate / mn_hnsw_delete) and they
+     * get the reference's whole-node rewrite, which heals them */
+    int delta_ok;
+    mn_edge_change *chlog;
+    sqlite3_stmt *st_node, *st_edge_put, *st_edge_del, *st_cfg;
 } VtabHnsw;
+#define MN_DELTA_CAP 1024
 
 enum { MODE_EXACT = 0, MODE_DEFERRED = 1, MODE_FAST = 2 };
 #define MN_PEND_MAX_BYTES ((size_t)256 << 20) /* queue is applied when its vectors reach this size ... */
@@ -192,6 +202,16 @@ static int make_shadow_tables(sqlite3 *db, const char *t) {
 
 /* src/hnsw_vtab.c:183-199 */
 static int write_config(VtabHnsw *v) {
+    if (v->st_cfg) { /* (the same six upserts, prepared once: persist_delta runs this per row) */
+        char ep[24], ml[16];
+        snprintf(ep, sizeof(ep), "%lld", (long long)mn_hnsw_entry_point(v->index));
+        snprintf(ml, sizeof(ml), "%d", mn_hnsw_max_level(v->index));
+        sqlite3_bind_text(v->st_cfg, 1, ep, -1, SQLITE_STATIC);
+        sqlite3_bind_text(v->st_cfg, 2, ml, -1, SQLITE_STATIC);
+        int rc = sqlite3_step(v->st_cfg) == SQLITE_DONE ? SQLITE_OK : SQLITE_ERROR;
+        sqlite3_reset(v->st_cfg);
+        return rc;
+    }
     return run_sql(v->db, sqlite3_mprintf("INSERT OR REPLACE INTO \"%w_config\" (key, value) VALUES ('dimensions', '%d'),"
                                           " ('metric', '%d'), ('m', '%d'), ('ef_construction', '%d'),"
                                           " ('entry_point', '%lld'), ('max_level', '%d')",
@@ -450,10 +470,123 @@ static int persist_marked(VtabHnsw *v, const sqlite3_int64 *new_ids, const float
     return rc;
 }
 
+/* MUNINN_PROFILE=1: where a flush's time goes (device insert vs shadow-table SQL), printed when the table disconnects */
+static double g_prof_dev_s = 0.0, g_prof_sql_s = 0.0;
+static long long g_prof_rows = 0;
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void delta_release(VtabHnsw *v) {
+    sqlite3_finalize(v->st_node);
+    sqlite3_finalize(v->st_edge_put);
+    sqlite3_finalize(v->st_edge_del);
+    sqlite3_finalize(v->st_cfg);
+    v->st_node = v->st_edge_put = v->st_edge_del = v->st_cfg = 0;
+    free(v->chlog);
+    v->chlog = 0;
+}
+static void delta_off(VtabHnsw *v) {
+    v->delta_ok = 0;
+    delta_release(v);
+}
+static int delta_prepare(VtabHnsw *v) {
+    if (v->st_node)
+        return SQLITE_OK;
+    v->chlog = (mn_edge_change *)malloc((size_t)MN_DELTA_CAP * sizeof(mn_edge_change));
+    if (!v->chlog)
+        return SQLITE_NOMEM;
+    static const char *const Q[4] = {
+        "INSERT OR REPLACE INTO \"%w_nodes\" (id, vector, level, deleted) VALUES (?, ?, ?, 0)",
+        "INSERT OR REPLACE INTO \"%w_edges\" (source_id, target_id, level, distance) VALUES (?, ?, ?, ?)",
+        "DELETE FROM \"%w_edges\" WHERE source_id = ? AND level = ? AND target_id = ?",
+        0};
+    sqlite3_stmt **dst[3] = {&v->st_node, &v->st_edge_put, &v->st_edge_del};
+    int rc = SQLITE_OK;
+    for (int i = 0; i < 3 && rc == SQLITE_OK; i++) {
+        char *sql = sqlite3_mprintf(Q[i], v->name);
+        rc = sql ? sqlite3_prepare_v2(v->db, sql, -1, dst[i], 0) : SQLITE_NOMEM;
+        sqlite3_free(sql);
+    }
+    if (rc == SQLITE_OK) {
+        char *sql = sqlite3_mprintf("INSERT OR REPLACE INTO \"%w_config\" (key, value) VALUES ('dimensions', '%d'),"
+                                    " ('metric', '%d'), ('m', '%d'), ('ef_construction', '%d'), ('entry_point', ?1), ('max_level', ?2)",
+                                    v->name, v->dim, v->metric, v->m, v->efc);
+        rc = sql ? sqlite3_prepare_v2(v->db, sql, -1, &v->st_cfg, 0) : SQLITE_NOMEM;
+        sqlite3_free(sql);
+    }
+    if (rc != SQLITE_OK)
+        delta_release(v);
+    return rc;
+}
+
+/* One exact insert and its shadow rows.  The reference re-persists the new node and every neighbour whole (persist_node,
+ * src/hnsw_vtab.c:237-283, called at :755-776: ≈ 1 100 "{t}_edges" rows deleted and re-inserted per row at M = 16); the
+ * device reports the edges this insert added and removed (mn_hnsw_insert_logged) and those ≈ 100 rows are written instead —
+ * the same table contents, because every other row of the touched nodes is already what persist_node would write back.
+ * When the log cannot describe the insert (*logged = 0) the caller does the whole-node rewrite. */
+static int insert_one_delta(VtabHnsw *v, sqlite3_int64 id, const float *vec, int *logged, int *dev_rc, double *t_dev) {
+    *logged = 0;
+    int rc = delta_prepare(v);
+    if (rc != SQLITE_OK)
+        return rc;
+    int n_log = -1;
+    *dev_rc = mn_hnsw_insert_logged(v->index, id, vec, v->chlog, MN_DELTA_CAP, &n_log);
+    *t_dev = now_s();
+    if (*dev_rc != 0 || n_log < 0)
+        return SQLITE_OK;
+    *logged = 1;
+    sqlite3_bind_int64(v->st_node, 1, id);
+    sqlite3_bind_blob(v->st_node, 2, vec, v->dim * (int)sizeof(float), SQLITE_STATIC);
+    sqlite3_bind_int(v->st_node, 3, mn_hnsw_node_level(v->index, id));
+    rc = sqlite3_step(v->st_node) == SQLITE_DONE ? SQLITE_OK : SQLITE_ERROR;
+    sqlite3_reset(v->st_node);
+    for (int i = 0; i < n_log && rc == SQLITE_OK; i++) {
+        const mn_edge_change *e = &v->chlog[i];
+        sqlite3_stmt *st = e->op == 1 ? v->st_edge_put : v->st_edge_del;
+        sqlite3_bind_int64(st, 1, e->src);
+        if (e->op == 1) {
+            sqlite3_bind_int64(st, 2, e->dst);
+            sqlite3_bind_int(st, 3, e->level);
+            sqlite3_bind_double(st, 4, (double)e->distance);
+        } else {
+            sqlite3_bind_int(st, 2, e->level);
+            sqlite3_bind_int64(st, 3, e->dst);
+        }
+        rc = sqlite3_step(st) == SQLITE_DONE ? SQLITE_OK : SQLITE_ERROR;
+        sqlite3_reset(st);
+    }
+    if (rc == SQLITE_OK)
+        rc = write_config(v);
+    if (rc != SQLITE_OK)
+        delta_off(v); /* rows may be half written: whole-node rewrites from here on */
+    return rc;
+}
+
 /* apply the queue to the device index (arrival order) and write the shadow tables */
 static int flush_pending(VtabHnsw *v) {
     if (v->n_pend == 0)
         return SQLITE_OK;
+    const double t0 = now_s();
+    if (v->mode == MODE_EXACT && v->n_pend == 1 && v->delta_ok) {
+        int logged = 0, dev_rc = 0;
+        double t1 = t0;
+        int rc = insert_one_delta(v, v->pend_ids[0], v->pend_vecs, &logged, &dev_rc, &t1);
+        if (rc == SQLITE_OK && dev_rc != 0) {
+            sqlite3_free(v->base.zErrMsg);
+            v->base.zErrMsg = sqlite3_mprintf("hnsw_index: insert failed (%s)", mn_last_error());
+            rc = SQLITE_ERROR;
+        } else if (rc == SQLITE_OK && !logged) {
+            rc = persist_marked(v, v->pend_ids, v->pend_vecs, 1);
+        }
+        g_prof_dev_s += t1 - t0;
+        g_prof_sql_s += now_s() - t1;
+        g_prof_rows += 1;
+        pend_clear(v);
+        return rc;
+    }
     int r = v->mode == MODE_FAST ? mn_hnsw_build(v->index, (const int64_t *)v->pend_ids, v->pend_vecs, v->n_pend, 0, 0)
                           : mn_hnsw_insert_batch(v->index, (const int64_t *)v->pend_ids, v->pend_vecs, v->n_pend, MN_BUILD_SEQUENTIAL);
     if (r != 0) {
@@ -462,7 +595,11 @@ static int flush_pending(VtabHnsw *v) {
         pend_clear(v);
         return SQLITE_ERROR;
     }
+    const double t1 = now_s();
     int rc = persist_marked(v, v->pend_ids, v->pend_vecs, v->n_pend);
+    g_prof_dev_s += t1 - t0;
+    g_prof_sql_s += now_s() - t1;
+    g_prof_rows += v->n_pend;
     pend_clear(v);
     return rc;
 }
@@ -494,8 +631,11 @@ static int load_from_shadow(VtabHnsw *v) {
         int64_t dst = sqlite3_column_int64(st, 1);
         int64_t src = sqlite3_column_int64(st, 0);
         int lv = sqlite3_column_int(st, 2);
-        if (mn_hnsw_node_level(v->index, src) >= lv && /* :333-336 */
-            mn_hnsw_load_neighbors(v->index, src, lv, &dst, 1) != 0) { /* never drop an edge silently */
+        if (mn_hnsw_node_level(v->index, src) < lv) { /* :333-336; the row stays until src is rewritten whole */
+            mn_hnsw_log_invalidate(v->index, &src, 1);
+            continue;
+        }
+        if (mn_hnsw_load_neighbors(v->index, src, lv, &dst, 1) != 0) { /* never drop an edge silently */
             sqlite3_finalize(st);
             return SQLITE_ERROR;
         }
@@ -518,6 +658,8 @@ static VtabHnsw *new_vtab(sqlite3 *db, const char *name, const Params *p, mn_ind
     v->efc = p->efc;
     const char *mode = getenv("MUNINN_HNSW_MODE");
     v->mode = mode && !strcmp(mode, "fast") ? MODE_FAST : mode && !strcmp(mode, "deferred") ? MODE_DEFERRED : MODE_EXACT;
+    const char *delta = getenv("MUNINN_HNSW_DELTA"); /* =0: whole-node rewrites always, as the reference does them */
+    v->delta_ok = !(delta && !strcmp(delta, "0"));
     live_add(v);
     return v;
 }
@@ -599,8 +741,11 @@ static int x_connect(sqlite3 *db, void *aux, int argc, const char *const *argv, 
 
 static int x_disconnect(sqlite3_vtab *vt) {
     VtabHnsw *v = (VtabHnsw *)vt;
+    if (getenv("MUNINN_PROFILE") && g_prof_rows)
+        fprintf(stderr, "[muninn] %lld rows flushed: device %.3f s, shadow tables %.3f s\n", g_prof_rows, g_prof_dev_s, g_prof_sql_s);
     live_remove(v);
     pend_free(v);
+    delta_release(v);
     mn_hnsw_destroy(v->index);
     sqlite3_free(v->name);
     sqlite3_free(v);
@@ -609,6 +754,7 @@ static int x_disconnect(sqlite3_vtab *vt) {
 
 static int x_destroy(sqlite3_vtab *vt) { /* src/hnsw_vtab.c:471-494 */
     VtabHnsw *v = (VtabHnsw *)vt;
+    delta_release(v);
     run_sql(v->db, sqlite3_mprintf("DROP TABLE IF EXISTS \"%w_config\"", v->name));
     run_sql(v->db, sqlite3_mprintf("DROP TABLE IF EXISTS \"%w_nodes\"", v->name));
     run_sql(v->db, sqlite3_mprintf("DROP INDEX IF EXISTS \"%w_edges_rev\"", v->name));
@@ -835,11 +981,29 @@ static int x_commit(sqlite3_vtab *vt) {
 }
 static int x_rollback(sqlite3_vtab *vt) {
     pend_clear((VtabHnsw *)vt);
+    mn_hnsw_log_invalidate(((VtabHnsw *)vt)->index, 0, 0); /* shadow rows are gone that the index still holds */
+    return SQLITE_OK;
+}
+/* statement and savepoint rollbacks take shadow rows away just the same (a multi-row INSERT that fails half way inside a
+ * transaction): the module is version 2 only to hear about them */
+static int x_savepoint(sqlite3_vtab *vt, int n) {
+    (void)vt;
+    (void)n;
+    return SQLITE_OK;
+}
+static int x_release(sqlite3_vtab *vt, int n) {
+    (void)vt;
+    (void)n;
+    return SQLITE_OK;
+}
+static int x_rollback_to(sqlite3_vtab *vt, int n) {
+    (void)n;
+    mn_hnsw_log_invalidate(((VtabHnsw *)vt)->index, 0, 0);
     return SQLITE_OK;
 }
 
 static sqlite3_module hnsw_module = {
-    .iVersion = 0,
+    .iVersion = 2,
     .xCreate = x_create,
     .xConnect = x_connect,
     .xBestIndex = x_best_index,
@@ -857,6 +1021,9 @@ static sqlite3_module hnsw_module = {
     .xSync = x_sync,
     .xCommit = x_commit,
     .xRollback = x_rollback,
+    .xSavepoint = x_savepoint,
+    .xRelease = x_release,
+    .xRollbackTo = x_rollback_to,
 };
 
 /* ───────────────────────── hnsw_search_batch: many queries, one launch ─────────────────────────

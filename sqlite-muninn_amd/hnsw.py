@@ -55,6 +55,8 @@ SYMBOLS = [
     ("mn_hnsw_set_order", C.c_int, [C.c_void_p, C.c_int]),
     ("mn_hnsw_insert", C.c_int, [C.c_void_p, C.c_int64, _f32p]),
     ("mn_hnsw_insert_batch", C.c_int, [C.c_void_p, _i64p, _f32p, C.c_int64, C.c_int]),
+    ("mn_hnsw_insert_logged", C.c_int, [C.c_void_p, C.c_int64, _f32p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    ("mn_hnsw_log_invalidate", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     ("mn_hnsw_build", C.c_int, [C.c_void_p, _i64p, _f32p, C.c_int64, C.c_int, C.c_int]),
     ("mn_hnsw_build_dev", C.c_int, [C.c_void_p, _i64p, C.c_void_p, C.c_int64, C.c_int, C.c_int]),
     ("mn_hnsw_device", C.c_int, [C.c_void_p]),
@@ -216,6 +218,10 @@ class ShardedIndex:
         return ids, ds, cnt
 
 
+class _EdgeChange(C.Structure):  # mn_edge_change
+    _fields_ = [("op", C.c_int), ("level", C.c_int), ("src", C.c_int64), ("dst", C.c_int64), ("distance", C.c_float)]
+
+
 class HnswIndex:
     """Device-resident HNSW index; mirrors HnswIndex + hnsw_* of src/hnsw_algo.h."""
 
@@ -246,6 +252,22 @@ class HnswIndex:
 
     def insert(self, id, vec) -> int:
         return self.L.mn_hnsw_insert(self.h, int(id), np.ascontiguousarray(vec, np.float32))
+
+    def insert_logged(self, id, vec, cap=1024):
+        """mn_hnsw_insert_logged → (rc, changes): changes = list of (op, level, src, dst, distance) — op 1 edge added, 2 removed
+        — or None when the log could not describe the insert (the persist set is then complete instead)."""
+        log = (_EdgeChange * cap)()
+        n = C.c_int(-1)
+        rc = self.L.mn_hnsw_insert_logged(self.h, int(id), np.ascontiguousarray(vec, np.float32), log, cap, C.byref(n))
+        if rc != 0 or n.value < 0:
+            return rc, None
+        return rc, [(log[i].op, log[i].level, log[i].src, log[i].dst, log[i].distance) for i in range(n.value)]
+
+    def log_invalidate(self, ids=None) -> int:
+        if ids is None:
+            return self.L.mn_hnsw_log_invalidate(self.h, None, 0)
+        ids = np.ascontiguousarray(ids, np.int64)
+        return self.L.mn_hnsw_log_invalidate(self.h, ids.ctypes.data, len(ids))
 
     def insert_batch(self, ids, vecs, mode=BUILD_BATCHED) -> int:
         ids = np.ascontiguousarray(ids, np.int64)

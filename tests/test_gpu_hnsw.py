@@ -638,3 +638,75 @@ def test_bench_streamed_build_path(gpu):
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert j["config"]["n"] == 150000 and j["recall_queries"] == 500 and j["recall_at_10"] > 0.8
     assert j["build_roofline"]["batches"] > 10 and j["cpu_baseline"] is None
+
+
+def _bits(x):
+    return int(np.float32(x).view(np.int32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric,dim,m,deletes", [("cosine", 24, 4, False), ("l2", 7, 2, True), ("inner_product", 16, 8, True)])
+def test_logged_insert_reports_exactly_the_edges_that_changed(gpu, metric, dim, m, deletes):
+    """mn_hnsw_insert_logged: the same insert as mn_hnsw_insert plus the list of edges it added and removed (so that the
+    extension rewrites ~100 "{t}_edges" rows per INSERT instead of ~1 100).  Two copies of one session: A persists edge by
+    edge from the log and falls back to the persist set when there is none, B persists as the reference does — every node of
+    the persist set rewritten whole (src/hnsw_vtab.c:755-776), deletes persisting nothing (:702-706).  After EVERY operation
+    the two persisted edge sets (ids, levels, f32 distance bits) must be equal; and without deletes A's equals a full export.
+    Small M: lists overflow and are pruned from the first few dozen rows; deletes leave edited lists un-persisted and dangling
+    links whose distance a whole rewrite stores as 0 — the cases in which the log has to say "no log"."""
+    n = 700
+    rng = np.random.default_rng(12)
+    X = rng.standard_normal((n, dim)).astype(np.float32)
+    X[50] = X[10]  # duplicates: distance ties in the prunes (MN-RU looks at other rows)
+    X[51] = X[10]
+    ids = np.arange(100, 100 + n, dtype=np.int64)
+    a = gpu.HnswIndex(dim, metric, m, 40)
+    b = gpu.HnswIndex(dim, metric, m, 40)
+    ea, eb = {}, {}
+
+    def rewrite_whole(ix, store, nodes):
+        nodes = set(int(x) for x in nodes)
+        for k in [k for k in store if k[0] in nodes]:
+            del store[k]
+        if nodes:
+            src, dst, lvl, dist = ix.edges_of(np.array(sorted(nodes), np.int64))
+            for s_, d_, l_, x in zip(src, dst, lvl, dist):
+                store[(int(s_), int(l_), int(d_))] = _bits(x)
+
+    n_logged = n_unlogged = 0
+    live = []
+    for i in range(n):
+        rc, log = a.insert_logged(ids[i], X[i])
+        assert rc == 0 and b.insert(ids[i], X[i]) == 0
+        rewrite_whole(b, eb, b.take_dirty())
+        if log is None:
+            n_unlogged += 1
+            rewrite_whole(a, ea, a.take_dirty())
+        else:
+            n_logged += 1
+            assert a.take_dirty().size == 0  # the log replaces the persist set
+            for op, level, s_, d_, dist_ in log:
+                if op == 1:
+                    ea[(s_, level, d_)] = _bits(dist_)
+                else:
+                    assert (s_, level, d_) in ea, (i, s_, level, d_)
+                    del ea[(s_, level, d_)]
+        assert ea == eb, i
+        live.append(int(ids[i]))
+        if deletes and i > 30 and rng.random() < 0.15:
+            d = live.pop(int(rng.integers(0, len(live))))
+            assert a.delete(d) == 0 and b.delete(d) == 0
+        if not deletes and (i % 97 == 0 or i == n - 1 or i < 40):
+            full = {}
+            rewrite_whole(a, full, ids[:i + 1])
+            assert ea == full, i
+    assert n_logged > n // 5, (n_logged, n_unlogged)
+    assert (n_unlogged > 0) == deletes
+    assert a.graph(ids) == b.graph(ids)
+    # a rolled-back transaction: everything present is unknown until rewritten; new rows are logged again once they stop
+    # touching unknown nodes
+    a.log_invalidate()
+    rc, log = a.insert_logged(10_000, X[0] * 0.5)
+    assert rc == 0 and log is None and a.take_dirty().size > 0
+    a.close()
+    b.close()

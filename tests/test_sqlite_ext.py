@@ -761,3 +761,77 @@ def test_muninn_device_env_selects_the_ordinal_and_fails_loudly_on_a_bad_one(ext
         else:
             assert "SQLERR" in r.stdout and "SQLERR2" in r.stdout and "CREATED" not in r.stdout and "PR 3" not in r.stdout, r.stdout
             assert "MUNINN_DEVICE=" in r.stdout, r.stdout  # the message names the variable
+
+
+def _delta_session(ext_built, path, delta):
+    """a session that exercises everything the edge-by-edge persistence has to survive; returns the tables after each phase"""
+    env = dict(os.environ, MUNINN_HNSW_MODE="exact", MUNINN_HNSW_DELTA="1" if delta else "0", MN_ROOT=ROOT, MN_DB=path)
+    code = r"""
+import os, sqlite3, numpy as np
+def connect():
+    c = sqlite3.connect(os.environ["MN_DB"], isolation_level=None); c.enable_load_extension(True)
+    c.load_extension(os.path.join(os.environ["MN_ROOT"], "sqlite-muninn_amd", "ext", "muninn"))
+    return c
+def dump(tag):
+    for t, order in (("v_config", "key"), ("v_nodes", "id"), ("v_edges", "1,3,2")):
+        cols = "rowid, *" if t == "v_config" else "id, level, deleted, hex(vector)" if t == "v_nodes" else "*"
+        for r in c.execute(f"SELECT {cols} FROM {t} ORDER BY {order}"):
+            print(tag, t, r)
+c = connect()
+X = np.random.default_rng(77).standard_normal((1400, 10), dtype=np.float32)
+c.execute("CREATE VIRTUAL TABLE v USING hnsw_index(dimensions=10, metric='l2', m=3, ef_construction=24)")
+ins = lambda i: c.execute("INSERT INTO v (rowid, vector) VALUES (?, ?)", (i + 1, X[i].tobytes()))
+c.execute("BEGIN")
+for i in range(0, 300): ins(i)
+c.execute("COMMIT")
+for i in range(300, 320): ins(i)                      # autocommit rows
+dump("plain")
+c.execute("BEGIN")
+for i in range(320, 360): ins(i)
+c.execute("ROLLBACK")                                 # 40 nodes stay in the index without shadow rows
+c.execute("BEGIN")
+for i in range(360, 450): ins(i)
+dump("after-rollback")
+for d in (3, 17, 250, 361, 400): c.execute("DELETE FROM v WHERE rowid = ?", (d,))
+for i in range(450, 600): ins(i)
+dump("after-deletes")
+try:                                                  # a statement that fails half way inside a transaction: its rows roll back
+    c.execute("INSERT INTO v (rowid, vector) SELECT 6000 + value, CASE WHEN value < 4 THEN zeroblob(40) ELSE x'00' END "
+              "FROM (SELECT 1 AS value UNION ALL SELECT 2 UNION ALL SELECT 3 UNION ALL SELECT 4)")
+except sqlite3.Error as e:
+    print("failed:", e)
+for i in range(600, 700): ins(i)
+dump("after-failed-statement")
+c.execute("SAVEPOINT a")
+for i in range(700, 730): ins(i)
+c.execute("ROLLBACK TO a")
+c.execute("RELEASE a")
+for i in range(730, 850): ins(i)
+c.execute("COMMIT")
+dump("after-savepoint")
+c.close()
+c = connect()                                         # reopen: lists in primary-key order, rolled-back nodes gone
+for i in range(850, 1100): ins(i)
+dump("after-reopen")
+print(c.execute("SELECT rowid, distance FROM v WHERE vector MATCH ? AND k = 8 AND ef_search = 50", (X[7].tobytes(),)).fetchall())
+"""
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stdout.splitlines()
+
+
+@pytest.mark.gpu
+def test_edge_by_edge_persistence_leaves_the_tables_whole_node_rewrites_leave(ext_built, gpu, tmp_path):
+    """Exact mode writes only the "{t}_edges" rows an insert changed (mn_hnsw_insert_logged) where the reference rewrites
+    the new node and all its neighbours whole (src/hnsw_vtab.c:755-776).  MUNINN_HNSW_DELTA=0 is that whole-node rewrite
+    (the path every reference-recorded golden was green on before the log existed): a session with m = 3 (prunes from the
+    first rows on), autocommit rows, a ROLLBACK, DELETEs, statements failing half way inside a transaction, a SAVEPOINT
+    rolled back and a reopen must leave the same _config (rowids included), _nodes and _edges, and answer alike."""
+    a = _delta_session(ext_built, str(tmp_path / "a.db"), True)
+    b = _delta_session(ext_built, str(tmp_path / "b.db"), False)
+    assert len(a) > 20_000
+    sa, sb = set(a), set(b)
+    assert a == b, f"edge by edge only: {sorted(sa - sb)[:12]}; whole-node only: {sorted(sb - sa)[:12]}"
