@@ -119,7 +119,29 @@ DEVI float sse_row(const float *__restrict__ row, const float *q_lds, int dim, i
 #ifndef MN_SSE_UNROLL
 #define MN_SSE_UNROLL 16
 #endif
-#pragma unroll MN_SSE_UNROLL
+    // Whole batches first, with every load of a batch issued before its first use: the sums are one dependent chain, so the
+    // loads are the only parallelism there is, and left to the scheduler about half of the inlined copies of this loop came
+    // out as load-use-load-use (one row element in flight; a single search's distance step 3x slower, MN_PHASE_TIMING).
+    for (; c + MN_SSE_UNROLL <= steps; c += MN_SSE_UNROLL) {
+        float b[MN_SSE_UNROLL];
+#pragma unroll
+        for (int u = 0; u < MN_SSE_UNROLL; u++)
+            b[u] = row[4 * (c + u) + j];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < MN_SSE_UNROLL; u++) {
+            const float a = q_lds[4 * (c + u) + j];
+            float p;
+            if (L2) {
+                float d = __fsub_rn(a, b[u]);
+                p = __fmul_rn(d, d);
+            } else {
+                p = __fmul_rn(a, b[u]);
+            }
+            s = __fadd_rn(s, p);
+        }
+    }
+#pragma unroll 4
     for (; c < steps; c++) {
         float b = row[4 * c + j];
         float a = q_lds[4 * c + j];

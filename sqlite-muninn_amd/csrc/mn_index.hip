@@ -133,6 +133,10 @@ struct mn_index {
     // insert re-persists the node WHOLE, so an insert that touches one cannot be described by a change log
     std::vector<unsigned char> h_stale;
     int n_stale = 0;
+    // pinned host block the kernels of a small search read the queries from and write the answers to (one query per call is
+    // the SQL surface's shape: five pageable copies and two synchronisations cost more than the search)
+    unsigned char *pin = nullptr;
+    size_t pin_cap = 0;
     DevBuf<unsigned long long> sh_ovf; // [world] heap-workspace overflow counts of the last sharded search, all-gathered
     int sh_ovf_pending = 0;             // entries of sh_ovf not yet looked at by the host (0: none)
     DevBuf<long long> sh_gids, sh_lids;
@@ -593,6 +597,7 @@ extern "C" void mn_hnsw_destroy(mn_index *x) {
     x->er_slot.release(); x->er_level.release(); x->er_nbr.release(); x->er_dist.release();
     x->d_staged.release();
     x->sh_sel.release(); x->sh_nsel.release(); x->sh_gcnt.release(); x->sh_lcnt.release(); x->sh_ovf.release(); x->ws_chlog.release(); x->sh_gids.release();
+    if (x->pin) { (void)hipHostFree(x->pin); x->pin = nullptr; x->pin_cap = 0; }
     x->sh_lids.release(); x->sh_gd.release(); x->sh_ld.release();
     x->ws_readlog.release(); x->ws_nread.release(); x->ws_ncommit.release(); x->d_stamp0.release(); x->d_stampU.release();
     if (x->ev0) (void)hipEventDestroy(x->ev0);
@@ -768,12 +773,64 @@ extern "C" int mn_hnsw_sync(mn_index *x) {
     return check_sharded_overflow(x);
 }
 
+static int counters_from(mn_index *x, const unsigned long long *c) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, x->ev0, x->ev1) == hipSuccess)
+        x->last.last_kernel_ms = ms;
+    x->last.last_n_dist = (int64_t)c[0];
+    x->last.last_n_expanded = (int64_t)c[1];
+    x->last.last_n_overflow = (int64_t)c[2];
+    return 0;
+}
+
+// A handful of queries from host memory: the kernel reads them from, and writes ids / distances / counts to, one pinned host
+// block; the counters follow in the same block; ONE synchronisation.
+static int search_small(mn_index *x, const float *queries, int64_t nq, int k, int ef, int64_t *out_ids, float *out_dists,
+                        int *out_counts) {
+    hipStream_t st = x->stream;
+    const size_t qb = (size_t)nq * x->dim * sizeof(float), ib = (size_t)nq * k * sizeof(int64_t), db = (size_t)nq * k * sizeof(float);
+    const size_t cb = ((size_t)nq * sizeof(int) + 7) & ~(size_t)7;
+    const size_t o_ids = (qb + 15) & ~(size_t)15, o_d = o_ids + ib, o_c = (o_d + db + 7) & ~(size_t)7, o_cnt = o_c + cb;
+    const size_t need = o_cnt + 4 * sizeof(unsigned long long);
+    if (need > x->pin_cap) {
+        if (x->pin)
+            (void)hipHostFree(x->pin);
+        x->pin = nullptr;
+        x->pin_cap = 0;
+        void *p = nullptr;
+        HIPCHK(hipHostMalloc(&p, need * 2, hipHostMallocDefault));
+        x->pin = (unsigned char *)p;
+        x->pin_cap = need * 2;
+    }
+    memcpy(x->pin, queries, qb);
+    if (mn_hnsw_search_batch_dev(x, (const float *)x->pin, nq, k, ef, (int64_t *)(x->pin + o_ids), (float *)(x->pin + o_d),
+                                 (int *)(x->pin + o_c)))
+        return -1;
+    const bool launched = x->entry_id != -1 && x->node_count > 0;
+    if (launched)
+        HIPCHK(hipMemcpyAsync(x->pin + o_cnt, x->ws_counters.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    memcpy(out_ids, x->pin + o_ids, ib);
+    memcpy(out_dists, x->pin + o_d, db);
+    memcpy(out_counts, x->pin + o_c, (size_t)nq * sizeof(int));
+    if (launched) {
+        counters_from(x, (const unsigned long long *)(x->pin + o_cnt));
+        if (x->last.last_n_overflow) {
+            set_err("mn_hnsw_search: %lld queries exceeded heap workspace", (long long)x->last.last_n_overflow);
+            return -1;
+        }
+    }
+    return 0;
+}
+
 extern "C" int mn_hnsw_search_batch(mn_index *x, const float *queries, int64_t nq, int k, int ef, int64_t *out_ids,
                                     float *out_dists, int *out_counts) {
     if (use_device(x))
         return -1;
     if (nq <= 0)
         return 0;
+    if (k > 0 && (size_t)nq * ((size_t)x->dim * 4 + (size_t)k * 12 + 4) <= ((size_t)1 << 20))
+        return search_small(x, queries, nq, k, ef, out_ids, out_dists, out_counts);
     hipStream_t st = x->stream;
     if (x->ws_q.reserve((size_t)nq * x->dim, false, st)) return -1;
     if (x->ws_outi.reserve((size_t)nq * k, false, st)) return -1;

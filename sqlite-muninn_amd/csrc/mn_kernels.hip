@@ -144,7 +144,8 @@ void mn_launch_dist_batch(int metric, int order, const float *d_query, const flo
 #include "mn_beam.hpp"
 
 // one query, one (leading) wavefront; `coop` = the group's shared area when helpers stand by (k_beam_coop)
-template <int ORDER, int NCH, bool BUILD, bool WIDE>
+// LAT: a latency-bound launch (few queries, one workgroup each): the layer searches keep their queues in registers (beam_layer_auto)
+template <int ORDER, int NCH, bool BUILD, bool WIDE, bool LAT = false>
 DEVI void beam_query(const MnDevIndex &ix, const MnSearchArgs &a, const long long qi, const int lane, unsigned char *smem,
                      CoopCtx *coop, unsigned *lds_bitmap = nullptr) {
     // LDS carve: cand heap | result heap | scratch | query
@@ -207,11 +208,14 @@ DEVI void beam_query(const MnDevIndex &ix, const MnSearchArgs &a, const long lon
         // hnsw_search, src/hnsw_algo.c:676-703
         for (int l = a.max_level; l > 0; l--)
             cur = greedy_layer<ORDER, NCH, false, WIDE>(ix, w, cur, l, lane);
-        beam_layer<ORDER, NCH, false, WIDE>(ix, w, cand, res, bm0, cur, 0, a.ef, lane);
+        if (LAT)
+            beam_layer_auto<ORDER, NCH, false, WIDE>(ix, w, cand, res, bm0, a.bm0_words, cur, 0, a.ef, lane);
+        else
+            beam_layer<ORDER, NCH, false, WIDE>(ix, w, cand, res, bm0, cur, 0, a.ef, lane);
         int count = res.size;
         int outn = count < a.k ? count : a.k;
         for (int i = count - 1; i >= 0; i--) { // :436-441
-            uint2 it = heap_pop(res, lane);
+            uint2 it = res_take(res, i, count, lane);
             if (i < a.k && lane == 0) {
                 a.out_ids[qi * a.k + i] = ix.ids[it.y];
                 a.out_dists[qi * a.k + i] = -u2f(it.x);
@@ -234,14 +238,17 @@ DEVI void beam_query(const MnDevIndex &ix, const MnSearchArgs &a, const long lon
             unsigned *bm = bm0;
             if (l > 0)
                 bm = a.bitmap_up + ((size_t)a.up_bm_index[qi] * a.max_level + (l - 1)) * a.bmu_words;
-            beam_layer<ORDER, NCH, false, WIDE>(ix, w, cand, res, bm, cur, l, a.ef, lane);
+            if (LAT)
+                beam_layer_auto<ORDER, NCH, false, WIDE>(ix, w, cand, res, bm, l > 0 ? a.bmu_words : a.bm0_words, cur, l, a.ef, lane);
+            else
+                beam_layer<ORDER, NCH, false, WIDE>(ix, w, cand, res, bm, cur, l, a.ef, lane);
             const int M_max = (l == 0) ? ix.M0 : ix.MU;
             int count = res.size;
             int keep = count < M_max ? count : M_max;
             int *sel = a.sel + ((size_t)qi * a.nlev + l) * ix.M0;
             int first = cur;
             for (int i = count - 1; i >= 0; i--) {
-                uint2 it = heap_pop(res, lane);
+                uint2 it = res_take(res, i, count, lane);
                 if (i < keep && lane == 0)
                     sel[i] = (int)it.y;
                 if (i == 0)
@@ -294,7 +301,7 @@ __global__ void __launch_bounds__(MN_COOP_WAVES * 64) k_beam_coop(MnDevIndex ix,
         __syncthreads();
     }
     if (c.wv == 0) {
-        beam_query<ORDER, NCH, BUILD, WIDE>(ix, a, blockIdx.x, lane, smem, &c, lbm);
+        beam_query<ORDER, NCH, BUILD, WIDE, true>(ix, a, blockIdx.x, lane, smem, &c, lbm);
         if (lane == 0)
             *c.n = -1;
         __syncthreads(); // releases the helpers
@@ -471,3 +478,16 @@ void mn_launch_merge_topk(const long long *g_ids, const float *g_dists, const in
     hipLaunchKernelGGL(k_merge_topk, dim3((unsigned)((nq + 127) / 128)), dim3(128), 0, st, g_ids, g_dists, g_counts, world, nq, k,
                        out_ids, out_dists, out_counts);
 }
+
+#ifdef MN_PHASE_TIMING
+extern "C" int mn_debug_phase_kernels(unsigned long long *out, int reset) { // probe builds only (scripts/probe_phases.sh)
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mn_phase), 8 * sizeof(unsigned long long)) != hipSuccess)
+        return -1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(mn_phase), z, sizeof(z)) != hipSuccess)
+            return -1;
+    }
+    return 0;
+}
+#endif

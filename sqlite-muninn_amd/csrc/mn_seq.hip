@@ -74,10 +74,22 @@ DEVI bool seq_links_deleted(const MnDevIndex &ix, int t, int lane) {
     return __ballot(bad) != 0;
 }
 
+// The inserts are one wavefront's work (the reference's loop, in its order); the other wavefronts of the workgroup only
+// stand by for the distance step of its searches (CoopCtx, mn_beam.hpp: a 32-row step is eight round trips to memory for one
+// wavefront and one for eight) and leave when it is done.
+#define MN_SEQ_WAVES 8
+#define MN_SEQ_COOP_BYTES ((4 + 64 + 64) * sizeof(int))
 template <int ORDER, int NCH, bool WIDE = false>
-__global__ void __launch_bounds__(64) k_insert_seq(MnDevIndex ix, MnSeqArgs a) {
+__global__ void __launch_bounds__(MN_SEQ_WAVES * 64) k_insert_seq(MnDevIndex ix, MnSeqArgs a, size_t base_lds) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    CoopCtx coop;
+    coop.n = reinterpret_cast<int *>(smem + base_lds);
+    coop.qnorm = reinterpret_cast<float *>(coop.n + 1);
+    coop.list = coop.n + 4;
+    coop.dist = reinterpret_cast<float *>(coop.list + 64);
+    coop.nw = blockDim.x >> 6;
+    coop.wv = threadIdx.x >> 6;
     uint2 *cand_l = reinterpret_cast<uint2 *>(smem);
     uint2 *res_l = cand_l + MN_CAND_LDS;
     int *scratch = reinterpret_cast<int *>(res_l + MN_RES_LDS); // [64]
@@ -88,8 +100,13 @@ __global__ void __launch_bounds__(64) k_insert_seq(MnDevIndex ix, MnSeqArgs a) {
     int *mn = reinterpret_cast<int *>(nd + a.LW);               // [LW]
     float *q = reinterpret_cast<float *>(mn + a.LW);            // [ld]
     float *tv = q + ix.ld;                                      // [ld]
+    if (coop.wv != 0) {
+        coop_helper<ORDER, NCH>(ix, q, coop, lane);
+        return;
+    }
 
     WaveCtx w;
+    w.coop = &coop; // (works alone too: with one wavefront a request is simply its own share)
     w.q = q;
     w.scratch = scratch;
     w.n_dist = 0;
@@ -122,6 +139,8 @@ __global__ void __launch_bounds__(64) k_insert_seq(MnDevIndex ix, MnSeqArgs a) {
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
         w.qnorm = ix.metric == 1 ? ix.norms[s] : 0.0f;
+        if (lane == 0)
+            *coop.qnorm = w.qnorm; // (the helpers read it, and the new query, behind the first barrier of a request)
 
         int cur = entry;
         for (int l = maxl; l > level; l--) // :553-555
@@ -138,12 +157,15 @@ __global__ void __launch_bounds__(64) k_insert_seq(MnDevIndex ix, MnSeqArgs a) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __builtin_amdgcn_s_waitcnt(0);
 
-            beam_layer<ORDER, NCH, true, WIDE>(ix, w, cand, res, bm, cur, l, a.ef, lane);
+            beam_layer_auto<ORDER, NCH, true, WIDE>(ix, w, cand, res, bm, words, cur, l, a.ef, lane);
+#ifdef MN_PHASE_TIMING
+            const unsigned long long ph_link0 = __builtin_amdgcn_s_memrealtime();
+#endif
             const int count = res.size;
             const int nsel = count < M_max ? count : M_max; // :511
             int first = cur;
             for (int i = count - 1; i >= 0; i--) {
-                uint2 itx = heap_pop(res, lane);
+                uint2 itx = res_take(res, i, count, lane);
                 if (i < nsel && lane == 0) {
                     selbuf[i] = (int)itx.y;
                     seldist[i] = itx.x ^ 0x80000000u; // (the result heap holds negated distances: flip the sign back)
@@ -231,12 +253,19 @@ __global__ void __launch_bounds__(64) k_insert_seq(MnDevIndex ix, MnSeqArgs a) {
             }
             if (count > 0) // :651-652
                 cur = first;
+#ifdef MN_PHASE_TIMING
+            if (lane == 0)
+                atomicAdd(&mn_phase[6], __builtin_amdgcn_s_memrealtime() - ph_link0);
+#endif
         }
         if (level > maxl) { // :660-663
             entry = s;
             maxl = level;
         }
     }
+    if (lane == 0)
+        *coop.n = -1;
+    __syncthreads(); // releases the helpers
     if (lane == 0) {
         if (a.chlog)
             a.chlog[0] = nlog;
@@ -253,8 +282,9 @@ size_t mn_insert_seq_lds_bytes(const MnDevIndex &ix) {
     int SB = (ix.M0 + 63) & ~63, LW = (ix.WX + 1 + 63) & ~63;
     if (LW < 192)
         LW = 192;
-    return (size_t)(MN_CAND_LDS + MN_RES_LDS) * sizeof(uint2) + (size_t)(64 + 2 * SB + 3 * LW) * sizeof(int) +
-           2 * (size_t)ix.ld * sizeof(float);
+    const size_t own = (size_t)(MN_CAND_LDS + MN_RES_LDS) * sizeof(uint2) + (size_t)(64 + 2 * SB + 3 * LW) * sizeof(int) +
+                       2 * (size_t)ix.ld * sizeof(float);
+    return ((own + 15) & ~(size_t)15) + MN_SEQ_COOP_BYTES; // + the request area the helper wavefronts watch
 }
 
 static int pick_nch_s(int ld) {
@@ -292,12 +322,15 @@ void mn_launch_insert_seq(const MnDevIndex &ix, const int *d_slots, int n, int e
     if (a.LW < 192)
         a.LW = 192;
     const size_t lds = mn_insert_seq_lds_bytes(ix);
-#define MN_SQ(O, N)                                                                            \
-    do {                                                                                       \
-        if (ix.WX > 64)                                                                        \
-            hipLaunchKernelGGL((k_insert_seq<O, N, true>), dim3(1), dim3(64), lds, st, ix, a); \
-        else                                                                                   \
-            hipLaunchKernelGGL((k_insert_seq<O, N>), dim3(1), dim3(64), lds, st, ix, a);       \
+    const size_t base = lds - MN_SEQ_COOP_BYTES;
+    const char *co = getenv("MN_COOP"); // MN_COOP=0: the inserting wavefront alone
+    const dim3 blk(co && atoi(co) == 0 ? 64 : MN_SEQ_WAVES * 64);
+#define MN_SQ(O, N)                                                                                \
+    do {                                                                                           \
+        if (ix.WX > 64)                                                                            \
+            hipLaunchKernelGGL((k_insert_seq<O, N, true>), dim3(1), blk, lds, st, ix, a, base);    \
+        else                                                                                       \
+            hipLaunchKernelGGL((k_insert_seq<O, N>), dim3(1), blk, lds, st, ix, a, base);          \
     } while (0)
     if (ix.order == MN_ORDER_SSE_V) {
         MN_SQ(MN_ORDER_SSE_V, 0);
@@ -314,3 +347,16 @@ void mn_launch_insert_seq(const MnDevIndex &ix, const int *d_slots, int n, int e
     }
 #undef MN_SQ
 }
+
+#ifdef MN_PHASE_TIMING
+extern "C" int mn_debug_phase_seq(unsigned long long *out, int reset) { // probe builds only (scripts/probe_phases.sh)
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mn_phase), 8 * sizeof(unsigned long long)) != hipSuccess)
+        return -1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(mn_phase), z, sizeof(z)) != hipSuccess)
+            return -1;
+    }
+    return 0;
+}
+#endif
