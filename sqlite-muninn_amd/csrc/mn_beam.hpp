@@ -184,7 +184,7 @@ DEVI void coop_share(const MnDevIndex &ix, const float *q, const CoopCtx &c, int
     if (cnt == 0)
         return;
     const int myslot = lane < cnt ? c.list[c.wv + lane * c.nw] : 0;
-    const float d = rows_distance<ORDER, NCH>(ix, q, *c.qnorm, myslot, cnt, lane);
+    const float d = rows_distance<ORDER, NCH, true>(ix, q, *c.qnorm, myslot, cnt, lane);
     if (lane < cnt)
         c.dist[c.wv + lane * c.nw] = d;
 }

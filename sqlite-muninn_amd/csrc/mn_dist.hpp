@@ -60,7 +60,35 @@ DEVI float quad_xor2(float v) { // lanes (0,2) and (1,3) of each quad exchange
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
 }
 
-template <bool L2>
+#ifndef MN_SSE_UNROLL
+#define MN_SSE_UNROLL 16
+#endif
+// chain positions c .. in whole batches of U: all U loads first (the scheduler may not move anything across the barrier — left
+// to itself about half of the inlined copies of this loop came out as load-use-load-use), then the sums in order
+template <bool L2, int U>
+DEVI void sse_chunks(const float *__restrict__ row, const float *q_lds, int j, int steps, int &c, float &s) {
+    for (; c + U <= steps; c += U) {
+        float b[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            b[u] = row[4 * (c + u) + j];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const float a = q_lds[4 * (c + u) + j];
+            float p;
+            if (L2) {
+                float d = __fsub_rn(a, b[u]);
+                p = __fmul_rn(d, d);
+            } else {
+                p = __fmul_rn(a, b[u]);
+            }
+            s = __fadd_rn(s, p);
+        }
+    }
+}
+
+template <bool L2, bool LAT = false>
 DEVI float sse_row(const float *__restrict__ row, const float *q_lds, int dim, int lane) {
     const int j = lane & 3;
     const int steps = dim >> 2; // chain positions (one per group of 4 elements)
@@ -116,31 +144,14 @@ DEVI float sse_row(const float *__restrict__ row, const float *q_lds, int dim, i
     }
     c = blocks << 2;
 #endif
-#ifndef MN_SSE_UNROLL
-#define MN_SSE_UNROLL 16
-#endif
     // Whole batches first, with every load of a batch issued before its first use: the sums are one dependent chain, so the
-    // loads are the only parallelism there is, and left to the scheduler about half of the inlined copies of this loop came
-    // out as load-use-load-use (one row element in flight; a single search's distance step 3x slower, MN_PHASE_TIMING).
-    for (; c + MN_SSE_UNROLL <= steps; c += MN_SSE_UNROLL) {
-        float b[MN_SSE_UNROLL];
-#pragma unroll
-        for (int u = 0; u < MN_SSE_UNROLL; u++)
-            b[u] = row[4 * (c + u) + j];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < MN_SSE_UNROLL; u++) {
-            const float a = q_lds[4 * (c + u) + j];
-            float p;
-            if (L2) {
-                float d = __fsub_rn(a, b[u]);
-                p = __fmul_rn(d, d);
-            } else {
-                p = __fmul_rn(a, b[u]);
-            }
-            s = __fadd_rn(s, p);
-        }
+    // loads are the only parallelism there is.  LAT (a lone search: nothing else hides the round trips to memory): batches of
+    // 64 and 32 chain positions before the 16s — a 768-d row is 3 round trips instead of 12.
+    if (LAT) {
+        sse_chunks<L2, 64>(row, q_lds, j, steps, c, s);
+        sse_chunks<L2, 32>(row, q_lds, j, steps, c, s);
     }
+    sse_chunks<L2, MN_SSE_UNROLL>(row, q_lds, j, steps, c, s);
 #pragma unroll 4
     for (; c < steps; c++) {
         float b = row[4 * c + j];
@@ -260,7 +271,7 @@ DEVI float sse_rows_tiled(const MnDevIndex &ix, const float *q_lds, float *tile,
 
 // Raw accumulation (dot or Σd²) of `n` rows (slot per lane, lanes < n valid) against q_lds.
 // Returns, in lane i < n, the value for row i.
-template <int ORDER, int NCH, bool L2>
+template <int ORDER, int NCH, bool L2, bool LAT = false>
 DEVI float rows_accumulate(const MnDevIndex &ix, const float *q_lds, int myslot, int n, int lane, float *tile = nullptr) {
     float mine = 0.0f;
     if (ORDER == MN_ORDER_SSE_V) {
@@ -271,7 +282,7 @@ DEVI float rows_accumulate(const MnDevIndex &ix, const float *q_lds, int myslot,
         for (int t = 0; t < n; t += 16) {
             int r = t + (lane >> 2);
             int s = __shfl(myslot, r < n ? r : n - 1);
-            float v = sse_row<L2>(ix.vectors + (size_t)s * ix.ld, q_lds, ix.dim, lane);
+            float v = sse_row<L2, LAT>(ix.vectors + (size_t)s * ix.ld, q_lds, ix.dim, lane);
             // lane i in [t, t+16) fetches the sum from group (i - t)
             float got = __shfl(v, ((lane - t) & 15) << 2);
             if (lane >= t && lane < t + 16)
@@ -336,13 +347,13 @@ DEVI float rows_accumulate(const MnDevIndex &ix, const float *q_lds, int myslot,
 }
 
 // distances of rows myslot[0..n) to the query in q_lds (qnorm = |q|² for cosine)
-template <int ORDER, int NCH>
+template <int ORDER, int NCH, bool LAT = false>
 DEVI float rows_distance(const MnDevIndex &ix, const float *q_lds, float qnorm, int myslot, int n, int lane,
                          float *tile = nullptr) {
     if (ix.metric == 0) {
-        return rows_accumulate<ORDER, NCH, true>(ix, q_lds, myslot, n, lane, tile);
+        return rows_accumulate<ORDER, NCH, true, LAT>(ix, q_lds, myslot, n, lane, tile);
     }
-    float dot = rows_accumulate<ORDER, NCH, false>(ix, q_lds, myslot, n, lane, tile);
+    float dot = rows_accumulate<ORDER, NCH, false, LAT>(ix, q_lds, myslot, n, lane, tile);
     if (ix.metric == 2)
         return -dot; // src/vec_math.c:142
     float nb = (lane < n) ? ix.norms[myslot] : 1.0f;
