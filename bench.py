@@ -369,7 +369,7 @@ def main():
     ap.add_argument("--quality-datasets", default="lowrank", help="comma list of datasets for that comparison")
     ap.add_argument("--stream-above", type=int, default=2_000_000,
                     help="N above this is built from the chunk stream without holding the matrix on the host (single rank)")
-    ap.add_argument("--exact-inserts", type=int, default=200,
+    ap.add_argument("--exact-inserts", type=int, default=600,
                     help="N=1: vectors inserted one at a time (reference semantics) into the full-size index, by the GPU and by "
                          "the compiled reference on the same graph: build CPU baseline + full-size insert parity (0 = skip)")
     ap.add_argument("--cpu-queries", type=int, default=4000)
