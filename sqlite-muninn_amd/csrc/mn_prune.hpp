@@ -58,9 +58,12 @@ DEVI void prune_ties(const MnDevIndex &ix, int *list, float *nd, int *mn, int nc
 // sequential kernel edits them in the same launch).
 // TIES = false: a distance tie (where the outcome depends on neighbours' rows) is not resolved; the list is left
 // untouched and 1 is returned, so that the caller can redo the step where those rows are stable.  Returns 0 otherwise.
+// last_known: the distance of the LAST candidate (the node being inserted) to the row's owner is already known — the search
+// that selected the owner computed it, and every metric gives d(t, s) = d(s, t) bit for bit (src/vec_math.c:78-143; checked by
+// the edge-log tests) — so it is not computed again: a 33-candidate list is two passes of 16 rows instead of three.
 template <int ORDER, int NCH, bool COH, bool TIES = true>
 DEVI int prune_row(const MnDevIndex &ix, const float *tq, float tnorm, int *list, float *nd, int *mn, int nc, int keep,
-                   int level, int lane) {
+                   int level, int lane, bool last_known = false, float last_d = 0.0f) {
     constexpr int NS = 3;
     bool has[NS];
     int sl[NS];
@@ -74,8 +77,12 @@ DEVI int prune_row(const MnDevIndex &ix, const float *tq, float tnorm, int *list
 #pragma unroll
     for (int k = 0; k < NS; k++) {
         const int nk = nc - 64 * k < 64 ? nc - 64 * k : 64;
-        if (nk > 0) // uniform
-            dd[k] = rows_distance<ORDER, NCH>(ix, tq, tnorm, sl[k], nk, lane);
+        const bool holds_last = last_known && nc - 1 >= 64 * k && nc - 1 < 64 * (k + 1); // uniform
+        const int ncomp = holds_last ? nk - 1 : nk;
+        if (ncomp > 0) // uniform
+            dd[k] = rows_distance<ORDER, NCH>(ix, tq, tnorm, sl[k], ncomp, lane);
+        if (holds_last && lane + 64 * k == nc - 1)
+            dd[k] = last_d;
         if (has[k] && ix.deleted[sl[k]])
             dd[k] = 1e30f; // :610-612
     }
@@ -194,8 +201,8 @@ DEVI int prune_row_long(const MnDevIndex &ix, const float *tq, float tnorm, int 
 
 template <int ORDER, int NCH, bool COH, bool TIES = true>
 DEVI int prune_any(const MnDevIndex &ix, const float *tq, float tnorm, int *list, float *nd, int *mn, int nc, int keep,
-                   int level, int lane) {
+                   int level, int lane, bool last_known = false, float last_d = 0.0f) {
     if (nc <= 192) // uniform
-        return prune_row<ORDER, NCH, COH, TIES>(ix, tq, tnorm, list, nd, mn, nc, keep, level, lane);
+        return prune_row<ORDER, NCH, COH, TIES>(ix, tq, tnorm, list, nd, mn, nc, keep, level, lane, last_known, last_d);
     return prune_row_long<ORDER, NCH, COH, TIES>(ix, tq, tnorm, list, nd, mn, nc, keep, level, lane);
 }

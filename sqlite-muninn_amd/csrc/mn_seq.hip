@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(MN_SEQ_WAVES * 64) k_insert_seq(MnDevIndex ix,
                 __builtin_amdgcn_s_waitcnt(0);
                 __builtin_amdgcn_wave_barrier();
                 const float tnorm = ix.metric == 1 ? ix.norms[t] : 0.0f;
-                prune_any<ORDER, NCH, true>(ix, tv, tnorm, list, nd, mn, nc, M_max, l, lane);
+                prune_any<ORDER, NCH, true>(ix, tv, tnorm, list, nd, mn, nc, M_max, l, lane, true, __uint_as_float(seldist[i]));
                 w.n_dist += nc;
                 if (a.chlog) {
                     // what the prune changed: every old link that is not among the M_max kept ones was removed; the new
