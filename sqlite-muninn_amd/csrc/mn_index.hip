@@ -344,6 +344,33 @@ static int host_add_node(mn_index *x, int64_t id, int level, int deleted) {
 // upload n vectors (host [n][dim]) into slots [first, first+n), zero padded to ld, and their norms
 static int upload_vectors(mn_index *x, int first, const float *vecs, int n, bool src_on_device = false);
 
+// the index's pinned host block (staging of one insert, mailbox of a small search), at least `need` bytes; nullptr on failure
+static unsigned char *pin_reserve(mn_index *x, size_t need) {
+    if (need <= x->pin_cap)
+        return x->pin;
+    if (hipStreamSynchronize(x->stream) != hipSuccess) // (copies out of the old block may still be queued)
+        return nullptr;
+    if (x->pin)
+        (void)hipHostFree(x->pin);
+    x->pin = nullptr;
+    x->pin_cap = 0;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, need * 2, hipHostMallocDefault) != hipSuccess)
+        return nullptr;
+    x->pin = (unsigned char *)p;
+    x->pin_cap = need * 2;
+    return x->pin;
+}
+// layout of the block during ONE insert (every piece is consumed before the insert's single synchronisation returns)
+#define MN_PIN_META 0      /* up_off, level, deleted, id of the new slot */
+#define MN_PIN_IN 64       /* slot, entry slot, max level */
+#define MN_PIN_OUT 96      /* state back (2 ints), counters (4 u64) */
+#define MN_PIN_VEC 256     /* the vector, zero padded to ld */
+static size_t pin_log_off(const mn_index *x) { return (MN_PIN_VEC + (size_t)x->ld * sizeof(float) + 63) & ~(size_t)63; }
+static size_t pin_insert_bytes(const mn_index *x) {
+    return pin_log_off(x) + ((size_t)1 + (size_t)MN_CHLOG_CAP * MN_CHLOG_INTS) * sizeof(int);
+}
+
 // make device buffers large enough for the host tables and upload metadata of new slots
 static int sync_meta(mn_index *x) {
     hipStream_t st = x->stream;
@@ -358,7 +385,20 @@ static int sync_meta(mn_index *x) {
     if (x->d_dirty.reserve(ns, true, st, 0)) return -1;
     if (x->d_ids.reserve(ns, true, st)) return -1;
     int a = x->meta_uploaded, n = x->n_slots - a;
-    if (n > 0) {
+    unsigned char *pin = n == 1 ? pin_reserve(x, pin_insert_bytes(x)) : nullptr;
+    if (n == 1 && pin) { // one insert: staged in the pinned block — four truly asynchronous copies, nothing to wait for
+        HIPCHK(hipStreamSynchronize(st)); // (whoever starts writing into the block waits for its previous user; idle as a rule)
+        int *pi = reinterpret_cast<int *>(pin + MN_PIN_META);
+        pi[0] = x->up_off[a];
+        reinterpret_cast<unsigned char *>(pi + 1)[0] = (unsigned char)x->levels[a];
+        reinterpret_cast<unsigned char *>(pi + 2)[0] = x->deleted[a];
+        memcpy(pi + 4, &x->ids[a], sizeof(long long));
+        HIPCHK(hipMemcpyAsync(x->d_up_off.p + a, pi, sizeof(int), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(x->d_levels.p + a, pi + 1, 1, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(x->d_deleted.p + a, pi + 2, 1, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(x->d_ids.p + a, pi + 4, sizeof(long long), hipMemcpyHostToDevice, st));
+        x->meta_uploaded = x->n_slots;
+    } else if (n > 0) {
         HIPCHK(hipMemcpyAsync(x->d_up_off.p + a, x->up_off.data() + a, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(x->d_levels.p + a, x->levels.data() + a, (size_t)n, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(x->d_deleted.p + a, x->deleted.data() + a, (size_t)n, hipMemcpyHostToDevice, st));
@@ -381,6 +421,16 @@ static int upload_vectors(mn_index *x, int first, const float *vecs, int n, bool
     hipStream_t st = x->stream;
     // (src_on_device: the rows are already in HBM — mn_hnsw_build_dev — and never visit the host)
     const hipMemcpyKind kind = src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (n == 1 && !src_on_device && x->pin && x->pin_cap >= pin_insert_bytes(x)) { // (sync_meta has just sized the block)
+        float *pv = reinterpret_cast<float *>(x->pin + MN_PIN_VEC);
+        memcpy(pv, vecs, (size_t)x->dim * sizeof(float));
+        for (int i = x->dim; i < x->ld; i++)
+            pv[i] = 0.0f;
+        HIPCHK(hipMemcpyAsync(x->d_vectors.p + (size_t)first * x->ld, pv, (size_t)x->ld * sizeof(float), hipMemcpyHostToDevice, st));
+        if (x->metric == MN_METRIC_COSINE)
+            mn_launch_norms(dev_view(x), first, 1, x->d_norms.p, st);
+        return 0; // the insert's own synchronisation covers the copy
+    }
     if (x->ld == x->dim) {
         HIPCHK(hipMemcpyAsync(x->d_vectors.p + (size_t)first * x->ld, vecs, (size_t)n * x->dim * sizeof(float), kind, st));
     } else {
@@ -792,16 +842,13 @@ static int search_small(mn_index *x, const float *queries, int64_t nq, int k, in
     const size_t cb = ((size_t)nq * sizeof(int) + 7) & ~(size_t)7;
     const size_t o_ids = (qb + 15) & ~(size_t)15, o_d = o_ids + ib, o_c = (o_d + db + 7) & ~(size_t)7, o_cnt = o_c + cb;
     const size_t need = o_cnt + 4 * sizeof(unsigned long long);
-    if (need > x->pin_cap) {
-        if (x->pin)
-            (void)hipHostFree(x->pin);
-        x->pin = nullptr;
-        x->pin_cap = 0;
-        void *p = nullptr;
-        HIPCHK(hipHostMalloc(&p, need * 2, hipHostMallocDefault));
-        x->pin = (unsigned char *)p;
-        x->pin_cap = need * 2;
+    if (push_links(x) || sync_meta(x)) // (before the block is written: a pending single-slot upload stages through it too)
+        return -1;
+    if (!pin_reserve(x, need)) {
+        set_err("mn_hnsw_search: cannot allocate %zu bytes of pinned host memory", need);
+        return -1;
     }
+    HIPCHK(hipStreamSynchronize(st));
     memcpy(x->pin, queries, qb);
     if (mn_hnsw_search_batch_dev(x, (const float *)x->pin, nq, k, ef, (int64_t *)(x->pin + o_ids), (float *)(x->pin + o_d),
                                  (int *)(x->pin + o_c)))
@@ -1026,8 +1073,19 @@ static int run_sequential(mn_index *x, const std::vector<int> &slots) {
     if (x->ws_qslots.reserve((size_t)n, false, st)) return -1;
     if (x->ws_state.reserve(2, false, st)) return -1;
     int state[2] = {ht_find(x, x->entry_id), x->max_level};
-    HIPCHK(hipMemcpyAsync(x->ws_qslots.p, slots.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(x->ws_state.p, state, sizeof(state), hipMemcpyHostToDevice, st));
+    // one insert: inputs and outputs go through the pinned block (sized by sync_meta for this insert) and there is ONE wait
+    unsigned char *pin = n == 1 && x->pin && x->pin_cap >= pin_insert_bytes(x) ? x->pin : nullptr;
+    if (pin) {
+        int *in = reinterpret_cast<int *>(pin + MN_PIN_IN);
+        in[0] = slots[0];
+        in[1] = state[0];
+        in[2] = state[1];
+        HIPCHK(hipMemcpyAsync(x->ws_qslots.p, in, sizeof(int), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(x->ws_state.p, in + 1, 2 * sizeof(int), hipMemcpyHostToDevice, st));
+    } else {
+        HIPCHK(hipMemcpyAsync(x->ws_qslots.p, slots.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(x->ws_state.p, state, sizeof(state), hipMemcpyHostToDevice, st));
+    }
     MnDevIndex v = dev_view(x);
     const bool logged = x->want_chlog && n == 1;
     x->want_chlog = false;
@@ -1043,13 +1101,33 @@ static int run_sequential(mn_index *x, const std::vector<int> &slots) {
     }
     HIPCHK(hipEventRecord(x->ev1, st));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(state, x->ws_state.p, sizeof(state), hipMemcpyDeviceToHost, st));
-    if (logged) {
-        x->h_chlog.assign((size_t)1 + (size_t)MN_CHLOG_CAP * MN_CHLOG_INTS, 0);
-        HIPCHK(hipMemcpyAsync(x->h_chlog.data(), x->ws_chlog.p, x->h_chlog.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+    if (pin) {
+        int *out = reinterpret_cast<int *>(pin + MN_PIN_OUT);
+        const size_t log_ints = (size_t)1 + (size_t)MN_CHLOG_CAP * MN_CHLOG_INTS;
+        HIPCHK(hipMemcpyAsync(out, x->ws_state.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(out + 2, x->ws_counters.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        if (logged)
+            HIPCHK(hipMemcpyAsync(pin + pin_log_off(x), x->ws_chlog.p, log_ints * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        state[0] = out[0];
+        state[1] = out[1];
+        unsigned long long c[4];
+        memcpy(c, out + 2, sizeof(c));
+        counters_from(x, c);
+        if (logged) {
+            const int *lg = reinterpret_cast<const int *>(pin + pin_log_off(x));
+            const int cnt = lg[0];
+            x->h_chlog.assign(lg, lg + 1 + (size_t)(cnt > 0 && cnt <= MN_CHLOG_CAP ? cnt : 0) * MN_CHLOG_INTS);
+        }
+    } else {
+        HIPCHK(hipMemcpyAsync(state, x->ws_state.p, sizeof(state), hipMemcpyDeviceToHost, st));
+        if (logged) {
+            x->h_chlog.assign((size_t)1 + (size_t)MN_CHLOG_CAP * MN_CHLOG_INTS, 0);
+            HIPCHK(hipMemcpyAsync(x->h_chlog.data(), x->ws_chlog.p, x->h_chlog.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+        }
+        if (fetch_counters(x))
+            return -1;
     }
-    if (fetch_counters(x))
-        return -1;
     if (x->last.last_n_overflow) {
         set_err("mn_hnsw_insert: heap workspace exceeded");
         return -1;
