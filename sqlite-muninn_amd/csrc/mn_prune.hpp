@@ -61,9 +61,10 @@ DEVI void prune_ties(const MnDevIndex &ix, int *list, float *nd, int *mn, int nc
 // last_known: the distance of the LAST candidate (the node being inserted) to the row's owner is already known — the search
 // that selected the owner computed it, and every metric gives d(t, s) = d(s, t) bit for bit (src/vec_math.c:78-143; checked by
 // the edge-log tests) — so it is not computed again: a 33-candidate list is two passes of 16 rows instead of three.
+// pre: all distances but the last were computed ahead (k_insert_seq's helper wavefronts, mn_seq.hip).
 template <int ORDER, int NCH, bool COH, bool TIES = true>
 DEVI int prune_row(const MnDevIndex &ix, const float *tq, float tnorm, int *list, float *nd, int *mn, int nc, int keep,
-                   int level, int lane, bool last_known = false, float last_d = 0.0f) {
+                   int level, int lane, bool last_known = false, float last_d = 0.0f, const float *pre = nullptr) {
     constexpr int NS = 3;
     bool has[NS];
     int sl[NS];
@@ -79,8 +80,12 @@ DEVI int prune_row(const MnDevIndex &ix, const float *tq, float tnorm, int *list
         const int nk = nc - 64 * k < 64 ? nc - 64 * k : 64;
         const bool holds_last = last_known && nc - 1 >= 64 * k && nc - 1 < 64 * (k + 1); // uniform
         const int ncomp = holds_last ? nk - 1 : nk;
-        if (ncomp > 0) // uniform
+        if (pre) { // (LDS) the distances were computed ahead, by the same code, against the same row
+            if (has[k])
+                dd[k] = pre[lane + 64 * k];
+        } else if (ncomp > 0) { // uniform
             dd[k] = rows_distance<ORDER, NCH>(ix, tq, tnorm, sl[k], ncomp, lane);
+        }
         if (holds_last && lane + 64 * k == nc - 1)
             dd[k] = last_d;
         if (has[k] && ix.deleted[sl[k]])
@@ -201,8 +206,8 @@ DEVI int prune_row_long(const MnDevIndex &ix, const float *tq, float tnorm, int 
 
 template <int ORDER, int NCH, bool COH, bool TIES = true>
 DEVI int prune_any(const MnDevIndex &ix, const float *tq, float tnorm, int *list, float *nd, int *mn, int nc, int keep,
-                   int level, int lane, bool last_known = false, float last_d = 0.0f) {
+                   int level, int lane, bool last_known = false, float last_d = 0.0f, const float *pre = nullptr) {
     if (nc <= 192) // uniform
-        return prune_row<ORDER, NCH, COH, TIES>(ix, tq, tnorm, list, nd, mn, nc, keep, level, lane, last_known, last_d);
+        return prune_row<ORDER, NCH, COH, TIES>(ix, tq, tnorm, list, nd, mn, nc, keep, level, lane, last_known, last_d, pre);
     return prune_row_long<ORDER, NCH, COH, TIES>(ix, tq, tnorm, list, nd, mn, nc, keep, level, lane);
 }

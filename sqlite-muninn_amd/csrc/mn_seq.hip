@@ -32,6 +32,11 @@ struct MnSeqArgs {
     // MN_CH_INTS ints {op (1 add, 2 delete), source slot, level, target slot, distance bits}
     int *chlog;
     int chcap;
+    // link phase: the distances the prunes of one (insert, layer) need — every full target row against its owner — are
+    // computed ahead by all wavefronts side by side (targets are distinct rows and a row changes only at its own step), so
+    // that the steps themselves, which stay in list order, only rank and write.  pre_rows = targets covered (0: off),
+    // pre_w = floats per target.
+    int pre_rows, pre_w;
 };
 #define MN_CH_INTS 5
 
@@ -74,6 +79,55 @@ DEVI bool seq_links_deleted(const MnDevIndex &ix, int t, int lane) {
     return __ballot(bad) != 0;
 }
 
+// this wavefront's share of the link phase's distances (see MnSeqArgs::pre_rows): targets wv, wv + nw, ...
+template <int ORDER, int NCH>
+DEVI void seq_pre_share(const MnDevIndex &ix, const MnSeqArgs &a, const CoopCtx &c, const int *selbuf, float *pre_nd,
+                        int *pre_cnt, float *tvw, int lane) {
+    const int l = c.n[2], nsel = c.n[3];
+    const int W = l == 0 ? ix.W0 : ix.WU, M_max = l == 0 ? ix.M0 : ix.MU;
+    for (int i = c.wv; i < nsel; i += c.nw) {
+        int ok = 0;
+        const int t = selbuf[i];
+        if (i < a.pre_rows && W <= 64 && ix.levels[t] >= l) {
+            const int *trow = seq_row(ix, t, l);
+            const int v = lane < W ? ld_link<true>(trow + lane) : -1;
+            const int cnt = __popcll(__ballot(v >= 0));
+            if (cnt >= M_max && cnt + 1 <= a.pre_w) { // a row that will be pruned (if the new node is not in it already)
+                const float *tsrc = ix.vectors + (size_t)t * ix.ld;
+                __builtin_amdgcn_wave_barrier();
+                for (int e = lane; e < ix.ld; e += 64)
+                    tvw[e] = tsrc[e];
+                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_wave_barrier();
+                const float tnorm = ix.metric == 1 ? ix.norms[t] : 0.0f;
+                const float d = rows_distance<ORDER, NCH>(ix, tvw, tnorm, lane < cnt ? v : 0, cnt, lane);
+                if (lane < cnt)
+                    pre_nd[i * a.pre_w + lane] = d;
+                ok = cnt;
+            }
+        }
+        if (lane == 0)
+            pre_cnt[i] = ok;
+    }
+}
+
+// the helpers' life in k_insert_seq: distance requests of the searches (n >= 0), link-phase requests (-2), the end (-1)
+template <int ORDER, int NCH>
+DEVI void seq_helper(const MnDevIndex &ix, const MnSeqArgs &a, const float *q, const CoopCtx &c, const int *selbuf,
+                     float *pre_nd, int *pre_cnt, float *tvw, int lane) {
+    for (;;) {
+        __syncthreads();
+        const int n = *c.n;
+        if (n == -1)
+            break;
+        if (n == -2)
+            seq_pre_share<ORDER, NCH>(ix, a, c, selbuf, pre_nd, pre_cnt, tvw, lane);
+        else
+            coop_share<ORDER, NCH>(ix, q, c, n, lane);
+        __syncthreads();
+    }
+}
+
 // The inserts are one wavefront's work (the reference's loop, in its order); the other wavefronts of the workgroup only
 // stand by for the distance step of its searches (CoopCtx, mn_beam.hpp: a 32-row step is eight round trips to memory for one
 // wavefront and one for eight) and leave when it is done.
@@ -100,8 +154,12 @@ __global__ void __launch_bounds__(MN_SEQ_WAVES * 64) k_insert_seq(MnDevIndex ix,
     int *mn = reinterpret_cast<int *>(nd + a.LW);               // [LW]
     float *q = reinterpret_cast<float *>(mn + a.LW);            // [ld]
     float *tv = q + ix.ld;                                      // [ld]
+    // behind the request area: the precomputed prune distances, their row counts, one owner vector per wavefront
+    float *pre_nd = reinterpret_cast<float *>(smem + base_lds + MN_SEQ_COOP_BYTES);
+    int *pre_cnt = reinterpret_cast<int *>(pre_nd + (size_t)a.pre_rows * a.pre_w);
+    float *tvw = reinterpret_cast<float *>(pre_cnt + ((a.pre_rows + 3) & ~3)) + (size_t)coop.wv * ix.ld;
     if (coop.wv != 0) {
-        coop_helper<ORDER, NCH>(ix, q, coop, lane);
+        seq_helper<ORDER, NCH>(ix, a, q, coop, selbuf, pre_nd, pre_cnt, tvw, lane);
         return;
     }
 
@@ -174,6 +232,17 @@ __global__ void __launch_bounds__(MN_SEQ_WAVES * 64) k_insert_seq(MnDevIndex ix,
                     first = (int)itx.y;
             }
             __builtin_amdgcn_wave_barrier();
+            const bool pre_on = a.pre_rows > 0 && nsel >= 4 && W <= 64; // uniform
+            if (pre_on) {
+                if (lane == 0) {
+                    coop.n[2] = l;
+                    coop.n[3] = nsel;
+                    *coop.n = -2;
+                }
+                __syncthreads();
+                seq_pre_share<ORDER, NCH>(ix, a, coop, selbuf, pre_nd, pre_cnt, tvw, lane);
+                __syncthreads();
+            }
             int *srow = seq_row(ix, s, l);
             for (int i = 0; i < nsel; i++) { // :582-648
                 const int t = selbuf[i];
@@ -215,13 +284,19 @@ __global__ void __launch_bounds__(MN_SEQ_WAVES * 64) k_insert_seq(MnDevIndex ix,
                 const int nc = cnt + 1;
                 if (lane == 0)
                     list[cnt] = s;
-                const float *tsrc = ix.vectors + (size_t)t * ix.ld;
-                for (int e = lane; e < ix.ld; e += 64)
-                    tv[e] = tsrc[e];
-                __builtin_amdgcn_s_waitcnt(0);
-                __builtin_amdgcn_wave_barrier();
                 const float tnorm = ix.metric == 1 ? ix.norms[t] : 0.0f;
-                prune_any<ORDER, NCH, true>(ix, tv, tnorm, list, nd, mn, nc, M_max, l, lane, true, __uint_as_float(seldist[i]));
+                if (pre_on && i < a.pre_rows && pre_cnt[i] == cnt) { // the distances are there (the row is as it was: its count)
+                    __builtin_amdgcn_wave_barrier();
+                    prune_any<ORDER, NCH, true>(ix, tv, tnorm, list, nd, mn, nc, M_max, l, lane, true,
+                                                __uint_as_float(seldist[i]), pre_nd + (size_t)i * a.pre_w);
+                } else {
+                    const float *tsrc = ix.vectors + (size_t)t * ix.ld;
+                    for (int e = lane; e < ix.ld; e += 64)
+                        tv[e] = tsrc[e];
+                    __builtin_amdgcn_s_waitcnt(0);
+                    __builtin_amdgcn_wave_barrier();
+                    prune_any<ORDER, NCH, true>(ix, tv, tnorm, list, nd, mn, nc, M_max, l, lane, true, __uint_as_float(seldist[i]));
+                }
                 w.n_dist += nc;
                 if (a.chlog) {
                     // what the prune changed: every old link that is not among the M_max kept ones was removed; the new
@@ -286,6 +361,15 @@ size_t mn_insert_seq_lds_bytes(const MnDevIndex &ix) {
                        2 * (size_t)ix.ld * sizeof(float);
     return ((own + 15) & ~(size_t)15) + MN_SEQ_COOP_BYTES; // + the request area the helper wavefronts watch
 }
+// + the link phase's precomputed distances, when they fit (64 KB): rows x (row width + 1) floats, a count per row, one owner
+// vector per wavefront.  0 = they do not fit: every prune computes its own distances.
+static size_t seq_pre_bytes(const MnDevIndex &ix, int *rows, int *w) {
+    *rows = ix.M0;
+    *w = (std::max(ix.W0, ix.WU) + 1 + 3) & ~3;
+    if (std::max(ix.W0, ix.WU) > 64)
+        return 0;
+    return (size_t)*rows * *w * sizeof(float) + (size_t)((*rows + 3) & ~3) * sizeof(int) + (size_t)MN_SEQ_WAVES * ix.ld * sizeof(float);
+}
 
 static int pick_nch_s(int ld) {
     int need = (ld + 255) / 256;
@@ -321,8 +405,18 @@ void mn_launch_insert_seq(const MnDevIndex &ix, const int *d_slots, int n, int e
     a.LW = (ix.WX + 1 + 63) & ~63;
     if (a.LW < 192)
         a.LW = 192;
-    const size_t lds = mn_insert_seq_lds_bytes(ix);
+    size_t lds = mn_insert_seq_lds_bytes(ix);
     const size_t base = lds - MN_SEQ_COOP_BYTES;
+    int pre_rows = 0, pre_w = 0;
+    const size_t pre = seq_pre_bytes(ix, &pre_rows, &pre_w);
+    const char *pe = getenv("MN_SEQ_PRE"); // MN_SEQ_PRE=0: every prune computes its own distances
+    if (pre && lds + pre <= MN_LDS_LIMIT && !(pe && atoi(pe) == 0)) {
+        lds += pre;
+        a.pre_rows = pre_rows;
+        a.pre_w = pre_w;
+    } else {
+        a.pre_rows = a.pre_w = 0;
+    }
     const char *co = getenv("MN_COOP"); // MN_COOP=0: the inserting wavefront alone
     const dim3 blk(co && atoi(co) == 0 ? 64 : MN_SEQ_WAVES * 64);
 #define MN_SQ(O, N)                                                                                \
