@@ -132,6 +132,8 @@ struct CoopCtx {
     float *dist;  // LDS [64] their distances
     float *qnorm; // LDS [1]
     int nw, wv;   // wavefronts in the group, this wavefront's index
+    float *tile = nullptr; // LDS, this wavefront's own: tile_rows x (ld + 4) floats for sse_rows_lat_tiled, or null
+    int tile_rows = 0;
 };
 
 // -DMN_PHASE_TIMING (scripts/probe_phases.sh builds a separate library with it; never the product): where one search's
@@ -184,7 +186,7 @@ DEVI void coop_share(const MnDevIndex &ix, const float *q, const CoopCtx &c, int
     if (cnt == 0)
         return;
     const int myslot = lane < cnt ? c.list[c.wv + lane * c.nw] : 0;
-    const float d = rows_distance<ORDER, NCH, true>(ix, q, *c.qnorm, myslot, cnt, lane);
+    const float d = rows_distance<ORDER, NCH, true>(ix, q, *c.qnorm, myslot, cnt, lane, c.tile, c.tile_rows);
     if (lane < cnt)
         c.dist[c.wv + lane * c.nw] = d;
 }

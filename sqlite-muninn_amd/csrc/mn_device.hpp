@@ -73,7 +73,13 @@ struct MnSearchArgs {
     int *readlog; // [nq][readcap] or null
     int readcap;
     int *nread;   // [nq] rows read (may exceed readcap)
+    // k_beam_coop, SSE order: every wavefront of the group has an LDS tile of lat_tile_rows x (ld + 4) floats at byte offset
+    // lat_tile_off for its share of a distance request (sse_rows_lat_tiled, mn_dist.hpp); 0 rows = none
+    int lat_tile_rows;
+    unsigned lat_tile_off;
 };
+// dynamic LDS a workgroup of this process may ask for: 64 KB, or what the device grants on request (mn_kernels.hip)
+size_t mn_lds_optin_limit();
 
 // LDS budget per wavefront (items are 8 B: f32 distance bits, int32 slot)
 #ifndef MN_CAND_LDS

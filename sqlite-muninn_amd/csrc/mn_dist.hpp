@@ -145,12 +145,9 @@ DEVI float sse_row(const float *__restrict__ row, const float *q_lds, int dim, i
     c = blocks << 2;
 #endif
     // Whole batches first, with every load of a batch issued before its first use: the sums are one dependent chain, so the
-    // loads are the only parallelism there is.  LAT (a lone search: nothing else hides the round trips to memory): batches of
-    // 64 and 32 chain positions before the 16s — a 768-d row is 3 round trips instead of 12.
-    if (LAT) {
-        sse_chunks<L2, 64>(row, q_lds, j, steps, c, s);
-        sse_chunks<L2, 32>(row, q_lds, j, steps, c, s);
-    }
+    // loads are the only parallelism there is.  (Batches of 64 and 32 positions for the lone-search kernels were tried: 768-d
+    // distances 7.7 -> 6.5 us, but the code they add slows every other step of those kernels by 5-8 % — they run one
+    // wavefront against the instruction cache; the LDS tile of sse_rows_lat_tiled does the same job better.)
     sse_chunks<L2, MN_SSE_UNROLL>(row, q_lds, j, steps, c, s);
 #pragma unroll 4
     for (; c < steps; c++) {
@@ -269,12 +266,95 @@ DEVI float sse_rows_tiled(const MnDevIndex &ix, const float *q_lds, float *tile,
     return mine;
 }
 
+// A lone search's distance step, SSE order, with a per-wavefront LDS tile of R rows (row stride ld + 4 floats): the
+// wavefront's few rows (a request is shared out over eight wavefronts, so 4 or so each) are fetched by ALL 64 lanes as
+// coalesced float4s — every load of a pass in flight at once, one round trip to memory instead of three dependent batches of
+// dword gathers by four lanes per row — and then quad g walks row g's chain out of LDS exactly as sse_row walks it out of
+// memory (same operations, same order, same bits).
+template <bool L2, int R>
+DEVI float sse_rows_lat_tiled(const MnDevIndex &ix, const float *q_lds, float *tile, int myslot, int n, int lane) {
+    float mine = 0.0f;
+    const int stride = ix.ld + 4;
+    const int nf4 = ix.ld >> 2;
+    const int j = lane & 3, g = lane >> 2;
+    const int steps = ix.dim >> 2;
+    for (int t = 0; t < n; t += R) {
+        const int nr = n - t < R ? n - t : R;
+        __builtin_amdgcn_wave_barrier(); // (the previous pass's chains are done with the tile)
+        for (int cb = 0; cb < nf4; cb += 256) {
+            float4 v[R][4];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int s = __builtin_amdgcn_readlane(myslot, t + (r < nr ? r : 0));
+                const float4 *row = reinterpret_cast<const float4 *>(ix.vectors + (size_t)s * ix.ld);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int e4 = cb + lane + 64 * k;
+                    v[r][k] = (r < nr && e4 < nf4) ? row[e4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < R; r++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int e4 = cb + lane + 64 * k;
+                    if (r < nr && e4 < nf4)
+                        *reinterpret_cast<float4 *>(tile + r * stride + e4 * 4) = v[r][k];
+                }
+        }
+        __builtin_amdgcn_wave_barrier();
+        float s = 0.0f;
+        const bool mine_row = g < nr;
+        const float *trow = tile + (mine_row ? g : 0) * stride + j;
+        const float *qrow = q_lds + j;
+#pragma unroll 8
+        for (int c = 0; c < steps; c++) {
+            const float b = trow[4 * c];
+            const float a = qrow[4 * c];
+            float p;
+            if (L2) {
+                const float d = __fsub_rn(a, b);
+                p = __fmul_rn(d, d);
+            } else {
+                p = __fmul_rn(a, b);
+            }
+            s = __fadd_rn(s, p);
+        }
+        const int gb = lane & ~3;
+        const float s0 = __shfl(s, gb), s1 = __shfl(s, gb + 1), s2 = __shfl(s, gb + 2), s3 = __shfl(s, gb + 3);
+        float sum = __fadd_rn(__fadd_rn(__fadd_rn(s0, s1), s2), s3);
+        for (int i = steps * 4; i < ix.dim; i++) { // scalar tail (src/vec_math.c:91-94)
+            const float a = q_lds[i], b = tile[(mine_row ? g : 0) * stride + i];
+            float p;
+            if (L2) {
+                const float d = __fsub_rn(a, b);
+                p = __fmul_rn(d, d);
+            } else {
+                p = __fmul_rn(a, b);
+            }
+            sum = __fadd_rn(sum, p);
+        }
+        const float got = __shfl(sum, ((lane - t) & 15) << 2);
+        if (lane >= t && lane < t + nr)
+            mine = got;
+    }
+    return mine;
+}
+
 // Raw accumulation (dot or Σd²) of `n` rows (slot per lane, lanes < n valid) against q_lds.
 // Returns, in lane i < n, the value for row i.
 template <int ORDER, int NCH, bool L2, bool LAT = false>
-DEVI float rows_accumulate(const MnDevIndex &ix, const float *q_lds, int myslot, int n, int lane, float *tile = nullptr) {
+DEVI float rows_accumulate(const MnDevIndex &ix, const float *q_lds, int myslot, int n, int lane, float *tile = nullptr,
+                           int tile_rows = 0) {
     float mine = 0.0f;
     if (ORDER == MN_ORDER_SSE_V) {
+        if (LAT && tile) { // (uniform)
+            if (tile_rows >= 4)
+                return sse_rows_lat_tiled<L2, 4>(ix, q_lds, tile, myslot, n, lane);
+            if (tile_rows >= 2)
+                return sse_rows_lat_tiled<L2, 2>(ix, q_lds, tile, myslot, n, lane);
+        }
 #ifdef MN_SSE_TILE_PATH // opt-in: same bits, same speed as the strided walk on gfx950 (both sit at the gather ceiling)
         if (tile)
             return sse_rows_tiled<L2>(ix, q_lds, tile, myslot, n, lane);
@@ -349,11 +429,11 @@ DEVI float rows_accumulate(const MnDevIndex &ix, const float *q_lds, int myslot,
 // distances of rows myslot[0..n) to the query in q_lds (qnorm = |q|² for cosine)
 template <int ORDER, int NCH, bool LAT = false>
 DEVI float rows_distance(const MnDevIndex &ix, const float *q_lds, float qnorm, int myslot, int n, int lane,
-                         float *tile = nullptr) {
+                         float *tile = nullptr, int tile_rows = 0) {
     if (ix.metric == 0) {
-        return rows_accumulate<ORDER, NCH, true, LAT>(ix, q_lds, myslot, n, lane, tile);
+        return rows_accumulate<ORDER, NCH, true, LAT>(ix, q_lds, myslot, n, lane, tile, tile_rows);
     }
-    float dot = rows_accumulate<ORDER, NCH, false, LAT>(ix, q_lds, myslot, n, lane, tile);
+    float dot = rows_accumulate<ORDER, NCH, false, LAT>(ix, q_lds, myslot, n, lane, tile, tile_rows);
     if (ix.metric == 2)
         return -dot; // src/vec_math.c:142
     float nb = (lane < n) ? ix.norms[myslot] : 1.0f;

@@ -18,6 +18,7 @@
 //                  exact order (separate mul/add, ((t0+t1)+t2)+t3, scalar tail)
 // Build with -ffp-contract=off; the WAVE path uses explicit fmaf, the SSE path explicit *_rn ops.
 #include "mn_device.hpp"
+#include <cstdio>
 #include <cstdlib>
 
 #include "mn_dist.hpp"
@@ -293,6 +294,10 @@ __global__ void __launch_bounds__(MN_COOP_WAVES * 64) k_beam_coop(MnDevIndex ix,
     c.dist = reinterpret_cast<float *>(c.list + 64);
     c.nw = blockDim.x >> 6;
     c.wv = threadIdx.x >> 6;
+    if (a.lat_tile_rows > 0) {
+        c.tile = reinterpret_cast<float *>(smem + a.lat_tile_off) + (size_t)c.wv * a.lat_tile_rows * (ix.ld + 4);
+        c.tile_rows = a.lat_tile_rows;
+    }
     unsigned *lbm = nullptr;
     if (!BUILD && a.lds_bitmap) { // (uniform) one query's visited bitmap in LDS, cleared by the whole workgroup
         lbm = reinterpret_cast<unsigned *>(smem + base_lds) + 4 + 64 + 64;
@@ -321,6 +326,51 @@ size_t mn_search_lds_bytes(int ld, bool tile) {
     return b;
 }
 
+// Dynamic LDS beyond 64 KB has to be asked for per kernel (hipFuncAttributeMaxDynamicSharedMemorySize); what the device would
+// grant is asked once.  Anything that fails leaves the 64 KB every kernel gets.
+size_t mn_lds_optin_limit() {
+    static size_t lim = 0;
+    if (lim)
+        return lim;
+    lim = 64 * 1024;
+    const char *e = getenv("MN_LDS_OPTIN"); // MN_LDS_OPTIN=0: never ask
+    int dev = 0, v = 0;
+    if (!(e && atoi(e) == 0) && hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeSharedMemPerBlockOptin, dev) == hipSuccess && v > 64 * 1024)
+        lim = (size_t)v;
+    (void)hipGetLastError();
+    return lim;
+}
+template <typename K> static bool lds_grant(K kern, size_t bytes) {
+    if (bytes <= 64 * 1024)
+        return true;
+    const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+    if (!ok)
+        (void)hipGetLastError();
+    return ok;
+}
+
+template <int ORDER, int NCH, bool BUILD, bool WIDE>
+static void launch_coop(const MnDevIndex &ix, MnSearchArgs a, size_t base, size_t tot, hipStream_t st) {
+    // SSE order: an LDS tile per wavefront for the distance step (4 rows, else 2, else none — by what fits)
+    const char *te = getenv("MN_LAT_TILE"); // MN_LAT_TILE=0: no distance tiles
+    if (ORDER == MN_ORDER_SSE_V && ix.ld >= 256 && !(te && atoi(te) == 0)) { // (short rows: the plain walk is as fast)
+        const size_t off = (tot + 15) & ~(size_t)15;
+        for (int rows = 4; rows >= 2; rows >>= 1) {
+            const size_t need = off + (size_t)MN_COOP_WAVES * rows * (ix.ld + 4) * sizeof(float);
+            if (need <= mn_lds_optin_limit() && lds_grant(k_beam_coop<ORDER, NCH, BUILD, WIDE>, need)) {
+                a.lat_tile_rows = rows;
+                a.lat_tile_off = (unsigned)off;
+                tot = need;
+                if (getenv("MN_LAT_DEBUG"))
+                    fprintf(stderr, "[mn] k_beam_coop: distance tile of %d rows per wavefront, %zu bytes of LDS\n", rows, need);
+                break;
+            }
+        }
+    }
+    hipLaunchKernelGGL((k_beam_coop<ORDER, NCH, BUILD, WIDE>), dim3((unsigned)a.nq), dim3(MN_COOP_WAVES * 64), tot, st, ix, a, base);
+}
+
 template <int ORDER, int NCH>
 static void launch_beam(const MnDevIndex &ix, const MnSearchArgs &a, bool build, hipStream_t st) {
     dim3 grid((unsigned)a.nq), block(64);
@@ -330,16 +380,15 @@ static void launch_beam(const MnDevIndex &ix, const MnSearchArgs &a, bool build,
     if (a.nq <= 128 && !(co && atoi(co) == 0)) {
         const size_t base = (lds + 15) & ~(size_t)15;
         const size_t tot = base + (4 + 64 + 64) * sizeof(int) + (!build && a.lds_bitmap ? (size_t)a.bm0_words * sizeof(unsigned) : 0);
-        dim3 cblock(MN_COOP_WAVES * 64);
         if (wide) {
             if (build)
-                hipLaunchKernelGGL((k_beam_coop<ORDER, NCH, true, true>), grid, cblock, tot, st, ix, a, base);
+                launch_coop<ORDER, NCH, true, true>(ix, a, base, tot, st);
             else
-                hipLaunchKernelGGL((k_beam_coop<ORDER, NCH, false, true>), grid, cblock, tot, st, ix, a, base);
+                launch_coop<ORDER, NCH, false, true>(ix, a, base, tot, st);
         } else if (build)
-            hipLaunchKernelGGL((k_beam_coop<ORDER, NCH, true>), grid, cblock, tot, st, ix, a, base);
+            launch_coop<ORDER, NCH, true, false>(ix, a, base, tot, st);
         else
-            hipLaunchKernelGGL((k_beam_coop<ORDER, NCH, false>), grid, cblock, tot, st, ix, a, base);
+            launch_coop<ORDER, NCH, false, false>(ix, a, base, tot, st);
         return;
     }
     if (wide) {

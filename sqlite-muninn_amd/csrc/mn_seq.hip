@@ -37,6 +37,9 @@ struct MnSeqArgs {
     // that the steps themselves, which stay in list order, only rank and write.  pre_rows = targets covered (0: off),
     // pre_w = floats per target.
     int pre_rows, pre_w;
+    // every wavefront's own LDS scratch, wave_floats each: the owner vector of a precomputed prune, and (SSE order) the
+    // lat_tile_rows x (ld + 4) tile of its share of a search's distance request (sse_rows_lat_tiled) — never both at once
+    int wave_floats, lat_tile_rows;
 };
 #define MN_CH_INTS 5
 
@@ -157,7 +160,11 @@ __global__ void __launch_bounds__(MN_SEQ_WAVES * 64) k_insert_seq(MnDevIndex ix,
     // behind the request area: the precomputed prune distances, their row counts, one owner vector per wavefront
     float *pre_nd = reinterpret_cast<float *>(smem + base_lds + MN_SEQ_COOP_BYTES);
     int *pre_cnt = reinterpret_cast<int *>(pre_nd + (size_t)a.pre_rows * a.pre_w);
-    float *tvw = reinterpret_cast<float *>(pre_cnt + ((a.pre_rows + 3) & ~3)) + (size_t)coop.wv * ix.ld;
+    float *tvw = reinterpret_cast<float *>(pre_cnt + ((a.pre_rows + 3) & ~3)) + (size_t)coop.wv * a.wave_floats;
+    if (a.lat_tile_rows > 0) {
+        coop.tile = tvw;
+        coop.tile_rows = a.lat_tile_rows;
+    }
     if (coop.wv != 0) {
         seq_helper<ORDER, NCH>(ix, a, q, coop, selbuf, pre_nd, pre_cnt, tvw, lane);
         return;
@@ -361,14 +368,13 @@ size_t mn_insert_seq_lds_bytes(const MnDevIndex &ix) {
                        2 * (size_t)ix.ld * sizeof(float);
     return ((own + 15) & ~(size_t)15) + MN_SEQ_COOP_BYTES; // + the request area the helper wavefronts watch
 }
-// + the link phase's precomputed distances, when they fit (64 KB): rows x (row width + 1) floats, a count per row, one owner
-// vector per wavefront.  0 = they do not fit: every prune computes its own distances.
+// + the link phase's precomputed distances (rows x (row width + 1) floats and a count per row) and every wavefront's scratch
 static size_t seq_pre_bytes(const MnDevIndex &ix, int *rows, int *w) {
     *rows = ix.M0;
     *w = (std::max(ix.W0, ix.WU) + 1 + 3) & ~3;
     if (std::max(ix.W0, ix.WU) > 64)
         return 0;
-    return (size_t)*rows * *w * sizeof(float) + (size_t)((*rows + 3) & ~3) * sizeof(int) + (size_t)MN_SEQ_WAVES * ix.ld * sizeof(float);
+    return (size_t)*rows * *w * sizeof(float) + (size_t)((*rows + 3) & ~3) * sizeof(int);
 }
 
 static int pick_nch_s(int ld) {
@@ -407,24 +413,54 @@ void mn_launch_insert_seq(const MnDevIndex &ix, const int *d_slots, int n, int e
         a.LW = 192;
     size_t lds = mn_insert_seq_lds_bytes(ix);
     const size_t base = lds - MN_SEQ_COOP_BYTES;
+    // optional LDS behind the request area, by what fits (64 KB, or what the device grants on request): the link phase's
+    // precomputed distances, and per wavefront an owner vector for them / a distance tile of 4 or 2 rows (SSE order)
     int pre_rows = 0, pre_w = 0;
-    const size_t pre = seq_pre_bytes(ix, &pre_rows, &pre_w);
+    size_t pre = seq_pre_bytes(ix, &pre_rows, &pre_w);
     const char *pe = getenv("MN_SEQ_PRE"); // MN_SEQ_PRE=0: every prune computes its own distances
-    if (pre && lds + pre <= MN_LDS_LIMIT && !(pe && atoi(pe) == 0)) {
-        lds += pre;
-        a.pre_rows = pre_rows;
-        a.pre_w = pre_w;
-    } else {
-        a.pre_rows = a.pre_w = 0;
+    if (pe && atoi(pe) == 0)
+        pre = 0;
+    a.pre_rows = a.pre_w = a.wave_floats = a.lat_tile_rows = 0;
+    const size_t lds0 = lds;
+    const char *te = getenv("MN_LAT_TILE"); // MN_LAT_TILE=0: no distance tiles
+    for (int rows = ix.order == MN_ORDER_SSE_V && ix.ld >= 256 && !(te && atoi(te) == 0) ? 4 : 0; rows >= 0; rows = rows == 4 ? 2 : rows == 2 ? 0 : -1) {
+        const int wf = std::max(pre ? ix.ld : 0, rows * (ix.ld + 4));
+        const size_t need = lds0 + pre + (size_t)MN_SEQ_WAVES * wf * sizeof(float);
+        if (rows == 0 && !pre)
+            break;
+        if (need <= (rows ? mn_lds_optin_limit() : (size_t)MN_LDS_LIMIT)) {
+            lds = need;
+            a.wave_floats = wf;
+            a.lat_tile_rows = rows;
+            if (pre) {
+                a.pre_rows = pre_rows;
+                a.pre_w = pre_w;
+            }
+            break;
+        }
     }
     const char *co = getenv("MN_COOP"); // MN_COOP=0: the inserting wavefront alone
     const dim3 blk(co && atoi(co) == 0 ? 64 : MN_SEQ_WAVES * 64);
-#define MN_SQ(O, N)                                                                                \
-    do {                                                                                           \
-        if (ix.WX > 64)                                                                            \
-            hipLaunchKernelGGL((k_insert_seq<O, N, true>), dim3(1), blk, lds, st, ix, a, base);    \
-        else                                                                                       \
-            hipLaunchKernelGGL((k_insert_seq<O, N>), dim3(1), blk, lds, st, ix, a, base);          \
+#define MN_SQ(O, N)                                                                                                          \
+    do {                                                                                                                     \
+        if (lds > 64 * 1024) {                                                                                               \
+            const void *kp = ix.WX > 64 ? reinterpret_cast<const void *>(k_insert_seq<O, N, true>)                           \
+                                        : reinterpret_cast<const void *>(k_insert_seq<O, N, false>);                         \
+            if (hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {               \
+                (void)hipGetLastError(); /* not granted: without the tile (and, if that is still too much, without the rest) */ \
+                a.lat_tile_rows = 0;                                                                                         \
+                a.wave_floats = a.pre_rows ? ix.ld : 0;                                                                      \
+                lds = lds0 + pre + (size_t)MN_SEQ_WAVES * a.wave_floats * sizeof(float);                                     \
+                if (lds > 64 * 1024) {                                                                                       \
+                    a.pre_rows = a.pre_w = a.wave_floats = 0;                                                                \
+                    lds = lds0;                                                                                              \
+                }                                                                                                            \
+            }                                                                                                                \
+        }                                                                                                                    \
+        if (ix.WX > 64)                                                                                                      \
+            hipLaunchKernelGGL((k_insert_seq<O, N, true>), dim3(1), blk, lds, st, ix, a, base);                              \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((k_insert_seq<O, N>), dim3(1), blk, lds, st, ix, a, base);                                    \
     } while (0)
     if (ix.order == MN_ORDER_SSE_V) {
         MN_SQ(MN_ORDER_SSE_V, 0);
