@@ -73,7 +73,7 @@ struct MnSearchArgs {
     int *readlog; // [nq][readcap] or null
     int readcap;
     int *nread;   // [nq] rows read (may exceed readcap)
-    // k_beam_coop, SSE order: every wavefront of the group has an LDS tile of lat_tile_rows x (ld + 4) floats at byte offset
+    // k_beam_coop, SSE order: every wavefront of the group has an LDS tile of mn_lat_tile_floats(ld, lat_tile_rows) floats at byte offset
     // lat_tile_off for its share of a distance request (sse_rows_lat_tiled, mn_dist.hpp); 0 rows = none
     int lat_tile_rows;
     unsigned lat_tile_off;

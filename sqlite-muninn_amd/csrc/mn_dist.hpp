@@ -266,18 +266,32 @@ DEVI float sse_rows_tiled(const MnDevIndex &ix, const float *q_lds, float *tile,
     return mine;
 }
 
-// A lone search's distance step, SSE order, with a per-wavefront LDS tile of R rows (row stride ld + 4 floats): the
-// wavefront's few rows (a request is shared out over eight wavefronts, so 4 or so each) are fetched by ALL 64 lanes as
-// coalesced float4s — every load of a pass in flight at once, one round trip to memory instead of three dependent batches of
-// dword gathers by four lanes per row — and then quad g walks row g's chain out of LDS exactly as sse_row walks it out of
-// memory (same operations, same order, same bits).
+// A lone search's distance step, SSE order, with a per-wavefront LDS tile of R rows: the wavefront's few rows (a request
+// is shared out over eight wavefronts, so 4 or so each) are fetched by ALL 64 lanes as coalesced float4s — every load of a
+// pass in flight at once, one round trip to memory instead of dependent batches of dword gathers by four lanes per row — and
+// stored TRANSPOSED: plane j of a row holds its elements 4c + j, c = 0, 1, ...  Quad g then walks row g's four chains exactly
+// as sse_row walks them out of memory (same operations, same order, same bits), lane j reading plane j — and the query's
+// plane j, transposed once per request — four chain positions per ds_read_b128.
+__host__ __device__ inline int mn_lat_plane(int ld) { return (((ld >> 2) + 3) & ~3) + 4; }          // floats per plane
+__host__ __device__ inline int mn_lat_row(int ld) { return 4 * mn_lat_plane(ld) + 8; }              // floats per tile row
+__host__ __device__ inline int mn_lat_tile_floats(int ld, int rows) { return rows * mn_lat_row(ld) + 4 * mn_lat_plane(ld); }
+
 template <bool L2, int R>
 DEVI float sse_rows_lat_tiled(const MnDevIndex &ix, const float *q_lds, float *tile, int myslot, int n, int lane) {
     float mine = 0.0f;
-    const int stride = ix.ld + 4;
+    const int P = mn_lat_plane(ix.ld), RS = mn_lat_row(ix.ld);
     const int nf4 = ix.ld >> 2;
     const int j = lane & 3, g = lane >> 2;
     const int steps = ix.dim >> 2;
+    float *qT = tile + R * RS;
+    __builtin_amdgcn_wave_barrier();
+    for (int e4 = lane; e4 < nf4; e4 += 64) { // the query's planes (q_lds is zero padded to ld)
+        const float4 qv = *reinterpret_cast<const float4 *>(q_lds + e4 * 4);
+        qT[e4] = qv.x;
+        qT[P + e4] = qv.y;
+        qT[2 * P + e4] = qv.z;
+        qT[3 * P + e4] = qv.w;
+    }
     for (int t = 0; t < n; t += R) {
         const int nr = n - t < R ? n - t : R;
         __builtin_amdgcn_wave_barrier(); // (the previous pass's chains are done with the tile)
@@ -299,19 +313,40 @@ DEVI float sse_rows_lat_tiled(const MnDevIndex &ix, const float *q_lds, float *t
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int e4 = cb + lane + 64 * k;
-                    if (r < nr && e4 < nf4)
-                        *reinterpret_cast<float4 *>(tile + r * stride + e4 * 4) = v[r][k];
+                    if (r < nr && e4 < nf4) {
+                        float *tr = tile + r * RS + e4;
+                        tr[0] = v[r][k].x;
+                        tr[P] = v[r][k].y;
+                        tr[2 * P] = v[r][k].z;
+                        tr[3 * P] = v[r][k].w;
+                    }
                 }
         }
         __builtin_amdgcn_wave_barrier();
         float s = 0.0f;
-        const bool mine_row = g < nr;
-        const float *trow = tile + (mine_row ? g : 0) * stride + j;
-        const float *qrow = q_lds + j;
-#pragma unroll 8
-        for (int c = 0; c < steps; c++) {
-            const float b = trow[4 * c];
-            const float a = qrow[4 * c];
+        const int gr = g < nr ? g : 0;
+        const float *tp = tile + gr * RS + j * P; // row gr, plane j
+        const float *qp = qT + j * P;
+        int c = 0;
+#pragma unroll 4
+        for (; c + 4 <= steps; c += 4) {
+            const float4 b = *reinterpret_cast<const float4 *>(tp + c);
+            const float4 a = *reinterpret_cast<const float4 *>(qp + c);
+            if (L2) {
+                const float d0 = __fsub_rn(a.x, b.x), d1 = __fsub_rn(a.y, b.y), d2 = __fsub_rn(a.z, b.z), d3 = __fsub_rn(a.w, b.w);
+                s = __fadd_rn(s, __fmul_rn(d0, d0));
+                s = __fadd_rn(s, __fmul_rn(d1, d1));
+                s = __fadd_rn(s, __fmul_rn(d2, d2));
+                s = __fadd_rn(s, __fmul_rn(d3, d3));
+            } else {
+                s = __fadd_rn(s, __fmul_rn(a.x, b.x));
+                s = __fadd_rn(s, __fmul_rn(a.y, b.y));
+                s = __fadd_rn(s, __fmul_rn(a.z, b.z));
+                s = __fadd_rn(s, __fmul_rn(a.w, b.w));
+            }
+        }
+        for (; c < steps; c++) {
+            const float b = tp[c], a = qp[c];
             float p;
             if (L2) {
                 const float d = __fsub_rn(a, b);
@@ -324,8 +359,8 @@ DEVI float sse_rows_lat_tiled(const MnDevIndex &ix, const float *q_lds, float *t
         const int gb = lane & ~3;
         const float s0 = __shfl(s, gb), s1 = __shfl(s, gb + 1), s2 = __shfl(s, gb + 2), s3 = __shfl(s, gb + 3);
         float sum = __fadd_rn(__fadd_rn(__fadd_rn(s0, s1), s2), s3);
-        for (int i = steps * 4; i < ix.dim; i++) { // scalar tail (src/vec_math.c:91-94)
-            const float a = q_lds[i], b = tile[(mine_row ? g : 0) * stride + i];
+        for (int i = steps * 4; i < ix.dim; i++) { // scalar tail (src/vec_math.c:91-94): element i is plane i & 3, place steps
+            const float a = qT[(i & 3) * P + steps], b = tile[gr * RS + (i & 3) * P + steps];
             float p;
             if (L2) {
                 const float d = __fsub_rn(a, b);

@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(MN_COOP_WAVES * 64) k_beam_coop(MnDevIndex ix,
     c.nw = blockDim.x >> 6;
     c.wv = threadIdx.x >> 6;
     if (a.lat_tile_rows > 0) {
-        c.tile = reinterpret_cast<float *>(smem + a.lat_tile_off) + (size_t)c.wv * a.lat_tile_rows * (ix.ld + 4);
+        c.tile = reinterpret_cast<float *>(smem + a.lat_tile_off) + (size_t)c.wv * mn_lat_tile_floats(ix.ld, a.lat_tile_rows);
         c.tile_rows = a.lat_tile_rows;
     }
     unsigned *lbm = nullptr;
@@ -357,7 +357,7 @@ static void launch_coop(const MnDevIndex &ix, MnSearchArgs a, size_t base, size_
     if (ORDER == MN_ORDER_SSE_V && ix.ld >= 256 && !(te && atoi(te) == 0)) { // (short rows: the plain walk is as fast)
         const size_t off = (tot + 15) & ~(size_t)15;
         for (int rows = 4; rows >= 2; rows >>= 1) {
-            const size_t need = off + (size_t)MN_COOP_WAVES * rows * (ix.ld + 4) * sizeof(float);
+            const size_t need = off + (size_t)MN_COOP_WAVES * mn_lat_tile_floats(ix.ld, rows) * sizeof(float);
             if (need <= mn_lds_optin_limit() && lds_grant(k_beam_coop<ORDER, NCH, BUILD, WIDE>, need)) {
                 a.lat_tile_rows = rows;
                 a.lat_tile_off = (unsigned)off;

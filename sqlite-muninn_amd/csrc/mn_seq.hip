@@ -38,7 +38,7 @@ struct MnSeqArgs {
     // pre_w = floats per target.
     int pre_rows, pre_w;
     // every wavefront's own LDS scratch, wave_floats each: the owner vector of a precomputed prune, and (SSE order) the
-    // lat_tile_rows x (ld + 4) tile of its share of a search's distance request (sse_rows_lat_tiled) — never both at once
+    // mn_lat_tile_floats(ld, lat_tile_rows) tile of its share of a search's distance request (sse_rows_lat_tiled) — never both at once
     int wave_floats, lat_tile_rows;
 };
 #define MN_CH_INTS 5
@@ -424,7 +424,7 @@ void mn_launch_insert_seq(const MnDevIndex &ix, const int *d_slots, int n, int e
     const size_t lds0 = lds;
     const char *te = getenv("MN_LAT_TILE"); // MN_LAT_TILE=0: no distance tiles
     for (int rows = ix.order == MN_ORDER_SSE_V && ix.ld >= 256 && !(te && atoi(te) == 0) ? 4 : 0; rows >= 0; rows = rows == 4 ? 2 : rows == 2 ? 0 : -1) {
-        const int wf = std::max(pre ? ix.ld : 0, rows * (ix.ld + 4));
+        const int wf = std::max(pre ? ix.ld : 0, rows ? mn_lat_tile_floats(ix.ld, rows) : 0);
         const size_t need = lds0 + pre + (size_t)MN_SEQ_WAVES * wf * sizeof(float);
         if (rows == 0 && !pre)
             break;
