@@ -576,6 +576,22 @@ def main():
         sweep.append({"ef": ef2, "queries_per_s": NQ / (np.mean(k2) * 1e-3), "recall_at_k": r2, "n_dist_per_query": nd2 / NQ,
                       "kernel_ms": float(np.mean(k2)), "roofline_frac": ab2 / (np.mean(k2) * 1e-3) / 1e9 / HBM_PEAK_GBS})
 
+    # ---- one query per call (the SQL surface's shape: mn_hnsw_search from host memory, answer back in host memory): the
+    #      latency-bound kernel (k_beam_coop, queues in registers), not the throughput one ----
+    lone = None
+    if rank == 0 and world == 1 and not sharded and not streamed:
+        nl = min(200, NQ)
+        for i in range(20):
+            g.search(Q[i], K, EF)
+        tl = []
+        for i in range(nl):
+            t1 = time.perf_counter()
+            li, ld_ = g.search(Q[i], K, EF)
+            tl.append((time.perf_counter() - t1) * 1e3)
+        lone = {"queries": nl, "ms_per_query_median": float(np.median(tl)), "ms_per_query_p90": float(np.percentile(tl, 90)),
+                "same_ids_as_the_batch_kernel": bool(np.array_equal(li, out_ids[nl - 1][:len(li)])),
+                "what": "mn_hnsw_search, one query per call, host memory in and out (k_beam_coop; the batch above is k_beam)"}
+
     # ---- CPU baseline: the oracle (single-threaded port of the reference algorithm) on the SAME
     #      graph and the SAME queries; also a full-size parity check of the returned ids ----
     cpu = None
@@ -746,6 +762,7 @@ def main():
                            "one shard per GPU" if sharded else "single GPU"),
             "parity_vs_oracle": parity,
             "ef_sweep": sweep,
+            "one_query_per_call": lone,
             "at_recall_target": at_target,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note, "kernel": "k_beam",

@@ -710,3 +710,28 @@ def test_logged_insert_reports_exactly_the_edges_that_changed(gpu, metric, dim, 
     assert rc == 0 and log is None and a.take_dirty().size > 0
     a.close()
     b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,dim,metric", [(6000, 96, "l2"), (3000, 768, "cosine"), (2500, 300, "inner_product")])
+def test_lone_search_kernel_equals_the_batch_kernel(gpu, n, dim, metric):
+    """One query per launch runs in k_beam_coop with both queues in registers (unsorted arrays, cached nearest / worst, a tie or
+    NaN sends the layer back to the binary heaps; rows of 256+ floats go through the per-wavefront LDS tile); a batch of more than
+    128 queries runs in k_beam with the LDS heaps.  Same index, same queries: ids, distance bits and counts must be equal at
+    every ef — below and above the 256 the registers hold, on data with exact duplicates (ties in both queues) as well."""
+    rng = np.random.default_rng(77)
+    X = rng.standard_normal((n, dim)).astype(np.float32)
+    X[n // 2:n // 2 + 200] = X[:200]  # exact duplicates
+    X[n - 50:] = 0.0                  # and a block of zero vectors (cosine: distance 1 for all of them)
+    ids = np.arange(1, n + 1, dtype=np.int64)
+    g = gpu.HnswIndex(dim, metric, 16, 100)
+    assert g.build(ids, X) == 0
+    Q = np.concatenate([rng.standard_normal((150, dim)).astype(np.float32), X[:30], np.zeros((2, dim), np.float32)])
+    for ef in (10, 64, 200, 256, 300):
+        bi, bd, bc = g.search_batch(Q, 10, ef)  # 182 queries: k_beam
+        for qi in range(len(Q)):
+            si, sd = g.search(Q[qi], 10, ef)    # one query: k_beam_coop
+            assert len(si) == bc[qi], (ef, qi)
+            assert np.array_equal(si, bi[qi, :bc[qi]]), (ef, qi)
+            assert same_bits(sd, bd[qi, :bc[qi]]), (ef, qi)
+    g.close()
