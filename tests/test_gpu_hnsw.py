@@ -735,3 +735,50 @@ def test_lone_search_kernel_equals_the_batch_kernel(gpu, n, dim, metric):
             assert np.array_equal(si, bi[qi, :bc[qi]]), (ef, qi)
             assert same_bits(sd, bd[qi, :bc[qi]]), (ef, qi)
     g.close()
+
+
+_KNOB_SCRIPT = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["MN_ROOT"])
+import muninn_amd
+from oracle import orc
+pkg = muninn_amd.pkg
+rng = np.random.default_rng(5)
+for dim, metric, n in ((768, "cosine", 420), (512, "l2", 400), (300, "l2", 500), (24, "inner_product", 700)):
+    X = rng.standard_normal((n, dim)).astype(np.float32)
+    X[100:110] = X[:10]  # ties
+    ids = np.arange(1, n + 1, dtype=np.int64)
+    o = orc.Oracle(dim, metric, 8, 60)
+    o.insert_many(ids, X)
+    g = pkg.HnswIndex(dim, metric, 8, 60)
+    for i in range(n):  # one at a time: k_insert_seq
+        assert g.insert(int(ids[i]), X[i]) == 0
+    assert g.graph(ids) == o.graph(ids), (dim, metric)
+    Q = rng.standard_normal((40, dim)).astype(np.float32)
+    for q in Q:
+        gi, gd = g.search(q, 10, 64)  # one at a time: k_beam_coop
+        oi, od = o.search(q, 10, 64)
+        assert np.array_equal(gi, oi) and np.array_equal(gd.view(np.int32), od.view(np.int32)), (dim, metric)
+    g.close()
+print("OK")
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("knob", ["MN_LDS_OPTIN", "MN_LAT_TILE", "MN_SEQ_PRE", "MN_COOP", "MN_SPECULATE"])
+def test_latency_kernel_fallbacks_give_the_same_graph_and_answers(gpu, knob):
+    """The lone-search / lone-insert kernels pick their LDS geometry at launch: a 4-row distance tile per wavefront when the device
+    grants more than 64 KB (else 2 rows, else none), precomputed prune distances when they fit, helper wavefronts.  Every knob
+    that switches one of these off (MN_LDS_OPTIN=0 is the only way the 2-row tile is reached on this part: 512-d) must leave the
+    graph of one-at-a-time inserts and the answers of one-at-a-time queries equal to the oracle's, bit for bit (ids, distance
+    bits), at dimensions that use the tile (768, 512, 300) and one that does not (24)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MN_ROOT=root)
+    env[knob] = "0"
+    r = subprocess.run([sys.executable, "-c", _KNOB_SCRIPT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-1500:]
