@@ -80,6 +80,7 @@ struct MnSearchArgs {
 };
 // dynamic LDS a workgroup of this process may ask for: 64 KB, or what the device grants on request (mn_kernels.hip)
 size_t mn_lds_optin_limit();
+bool mn_lds_grant(const void *kernel, size_t bytes); // asks once per kernel and size; false = stay within 64 KB
 
 // LDS budget per wavefront (items are 8 B: f32 distance bits, int32 slot)
 #ifndef MN_CAND_LDS

@@ -20,6 +20,8 @@
 #include "mn_device.hpp"
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
+#include <unordered_map>
 
 #include "mn_dist.hpp"
 
@@ -341,14 +343,26 @@ size_t mn_lds_optin_limit() {
     (void)hipGetLastError();
     return lim;
 }
-template <typename K> static bool lds_grant(K kern, size_t bytes) {
+// one request per kernel and size (the call is not free, and these kernels are launched once per query / insert)
+bool mn_lds_grant(const void *kern, size_t bytes) {
     if (bytes <= 64 * 1024)
         return true;
-    const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+    static std::mutex mu;
+    static std::unordered_map<unsigned long long, size_t> granted; // (kernel, device) -> largest size granted (0: refused)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long key = (unsigned long long)reinterpret_cast<uintptr_t>(kern) * 64ull + (unsigned)(dev & 63);
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = granted.find(key);
+    if (it != granted.end() && (it->second >= bytes || it->second == 0))
+        return it->second >= bytes;
+    const bool ok = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
     if (!ok)
         (void)hipGetLastError();
+    granted[key] = ok ? bytes : 0;
     return ok;
 }
+template <typename K> static bool lds_grant(K kern, size_t bytes) { return mn_lds_grant(reinterpret_cast<const void *>(kern), bytes); }
 
 template <int ORDER, int NCH, bool BUILD, bool WIDE>
 static void launch_coop(const MnDevIndex &ix, MnSearchArgs a, size_t base, size_t tot, hipStream_t st) {

@@ -446,8 +446,7 @@ void mn_launch_insert_seq(const MnDevIndex &ix, const int *d_slots, int n, int e
         if (lds > 64 * 1024) {                                                                                               \
             const void *kp = ix.WX > 64 ? reinterpret_cast<const void *>(k_insert_seq<O, N, true>)                           \
                                         : reinterpret_cast<const void *>(k_insert_seq<O, N, false>);                         \
-            if (hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {               \
-                (void)hipGetLastError(); /* not granted: without the tile (and, if that is still too much, without the rest) */ \
+            if (!mn_lds_grant(kp, lds)) { /* not granted: without the tile (and, if that is still too much, without the rest) */ \
                 a.lat_tile_rows = 0;                                                                                         \
                 a.wave_floats = a.pre_rows ? ix.ld : 0;                                                                      \
                 lds = lds0 + pre + (size_t)MN_SEQ_WAVES * a.wave_floats * sizeof(float);                                     \
