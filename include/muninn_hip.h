@@ -240,7 +240,7 @@ const char *mn_graph_last_error(void);
 
 typedef enum {
     MN_LEIDEN_SEQUENTIAL = 0, /* the reference's in-order sweep with immediate moves: community[] and Q bit-identical */
-    MN_LEIDEN_BATCHED = 1     /* batch-synchronous parallel rounds */
+    MN_LEIDEN_BATCHED = 1     /* parallel schedules: whole-graph synchronous sweeps, or rounds of `batch` nodes */
 } mn_leiden_mode;
 typedef struct {
     int64_t iterations, moves, move_sweeps, refine_sweeps;
@@ -248,9 +248,10 @@ typedef struct {
     double device_ms;
 } mn_leiden_stats;
 /* run_leiden (src/graph_community.c:336-429).  use_both = (direction == "both").  community_out[n_nodes] is
- * renumbered 0..K-1 in first-seen order; *modularity_out = Q.  batch: nodes per parallel round (BATCHED; <=1 → N/16
- * clamped to [256, 32768]).
- * Returns 0 / -1. */
+ * renumbered 0..K-1 in first-seen order; *modularity_out = Q.  batch (BATCHED only): 0 or 1 → the default schedule, whole-graph
+ * synchronous sweeps in which every positive-gain mover applies and every 3rd sweep is "pick-less" (moves to a smaller
+ * community id only), finished by the round schedule if 48 sweeps do not settle; < 0 → the same with a pick-less sweep every
+ * -batch sweeps; > 1 → rounds of `batch` nodes with the safe-winner commit rule.  Returns 0 / -1. */
 int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int mode, int batch, int *community_out,
                     double *modularity_out);
 int mn_graph_leiden_stats(mn_graph *g, mn_leiden_stats *out);

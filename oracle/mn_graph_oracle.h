@@ -23,8 +23,9 @@ typedef struct {
     int64_t iterations, moves, move_sweeps, refine_sweeps;
 } orc_leiden_stats;
 
-/* run_leiden (src/graph_community.c:336-429).  batch <= 1: the reference's sequential sweeps;
- * batch > 1: the batch-synchronous schedule of the HIP fast mode.  Returns modularity Q. */
+/* run_leiden (src/graph_community.c:336-429).  batch 0 or 1: the reference's sequential sweeps; batch > 1: the round
+ * schedule of the HIP fast mode (rounds of `batch` nodes, safe winners); batch < 0: its whole-graph synchronous sweeps with a
+ * pick-less sweep every -batch sweeps (the device's default is -3).  Returns modularity Q. */
 double orc_leiden(const orc_graph *g, int *community, double resolution, int use_both, int batch, orc_leiden_stats *st);
 /* compute_modularity (src/graph_community.c:109-142) */
 double orc_modularity(const orc_graph *g, const int *community, double resolution, double m, int use_both);

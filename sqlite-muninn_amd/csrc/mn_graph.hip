@@ -75,7 +75,7 @@ template <bool COH> DEVI double ld_d(const double *p) {
 template <bool COH>
 DEVI int best_move(const DevGraph &g, int v, const int *label, const double *sum_tot, const double *kdeg, double m,
                    double resolution, int use_both, const int *elig_part, int *ec, double *ew, unsigned char *el, int lane,
-                   double *dk_out = nullptr) {
+                   double *dk_out = nullptr, int pickless = 0) {
     const int o0 = g.off_out[v], d_out = g.off_out[v + 1] - o0;
     const int i0 = use_both ? g.off_in[v] : 0, d_in = use_both ? g.off_in[v + 1] - i0 : 0;
     const int d = d_out + d_in;
@@ -124,7 +124,7 @@ DEVI int best_move(const DevGraph &g, int v, const int *label, const double *sum
     for (int base = 0; base < d; base += 64) {
         const int e = base + lane;
         const int c = e < d ? ec[e] : -3;
-        bool cand = e < d && el[e] && c != old;
+        bool cand = e < d && el[e] && c != old && !(pickless && c > old);
         // one pass over the list: the in-order weight sum of community c (weight_to_community, :206) and
         // "an eligible earlier edge already carries c" (the dedup scan of :173-199)
         double sacc = 0.0;
@@ -177,7 +177,7 @@ DEVI int best_move(const DevGraph &g, int v, const int *label, const double *sum
 template <int SG>
 DEVI int best_move_sg(const DevGraph &g, int v, const int *label, const double *sum_tot, const double *kdeg, double m,
                       double resolution, int use_both, const int *elig_part, int *ec, double *ew, unsigned char *el, int lane,
-                      int sl, double *dk_out) {
+                      int sl, double *dk_out, int pickless) {
     const int o0 = g.off_out[v], d_out = g.off_out[v + 1] - o0;
     const int i0 = use_both ? g.off_in[v] : 0, d_in = use_both ? g.off_in[v + 1] - i0 : 0;
     const int d = d_out + d_in;
@@ -225,7 +225,7 @@ DEVI int best_move_sg(const DevGraph &g, int v, const int *label, const double *
     for (int base = 0; base < d; base += SG) {
         const int e = base + sl;
         const int c = e < d ? ec[e] : -3;
-        bool cand = e < d && el[e] && c != old;
+        bool cand = e < d && el[e] && c != old && !(pickless && c > old);
         double sacc = 0.0;
         bool dup = false;
         for (int q = 0; q < (d4 >> 2); q++) {
@@ -301,7 +301,7 @@ DEVI LeiHead lei_head(const DevGraph &g, int v, const int *label, const double *
 template <int SG>
 DEVI int best_move_hash(const DevGraph &g, const LeiHead &hd, const int *label, const double *sum_tot, double m,
                         double resolution, const int *elig_part, int *tk, int *tc, int *tp, int *cl, int log2h, int lane,
-                        int sl, double *dk_out) {
+                        int sl, double *dk_out, int pickless) {
     const int H = 1 << log2h;
     const int o0 = hd.o0, d_out = hd.d_out, i0 = hd.i0, d_in = hd.d_in;
     const int d = d_out + d_in;
@@ -388,7 +388,7 @@ DEVI int best_move_hash(const DevGraph &g, const LeiHead &hd, const int *label, 
     for (int i = sl; i < ncand; i += SG) {
         const int slot = clist[i];
         const int c = tk[slot], pos = tp[slot];
-        if (c == old || pos == 0x7fffffff)
+        if (c == old || pos == 0x7fffffff || (pickless && c > old))
             continue;
         const double sacc = (double)tc[slot];
         const double st_c = sum_tot[c];
@@ -447,6 +447,8 @@ struct LeiArgs {
     int big0, big1;              // the slice of biglist inside [b0, b1)
     int parity;                  // round parity: out[1 + parity] counts this round's safe winners
     int big_log2h;               // hash table size of a wide node (unweighted): 2^big_log2h >= 2 * lds_cap
+    int sync;                    // 1: whole-graph synchronous sweep — every positive-gain mover applies, no tallies (k_leiden_apply_sync)
+    int pickless;                // this sweep only allows moves to a community with a smaller id
 };
 
 #define LEI_FX 1048576.0
@@ -501,6 +503,8 @@ __global__ void __launch_bounds__(64) k_leiden_seq(LeiArgs a) {
 // a mover's tallies: smallest mover index per touched community, and the movers' degrees leaving / joining it
 DEVI void lei_tally(const LeiArgs &a, int v, int old, int best, double dk) {
     a.dec[v - a.b0] = best;
+    if (a.sync) // synchronous sweep: the decision is all k_leiden_apply_sync needs
+        return;
     a.dk[v - a.b0] = dk;
     a.mv[v - a.b0] = best != old;
     if (best == old)
@@ -538,7 +542,7 @@ __global__ void __launch_bounds__(64 * LEI_WPB) k_leiden_eval(LeiArgs a, int nsm
             old = hd.old;
             int *tk = reinterpret_cast<int *>(lei_smem) + grp * LEI_SG_AREA; // H = 2 * LEI_SG_CAP entries
             best = best_move_hash<SG>(a.g, hd, a.label, a.sum_tot, a.m, a.resolution, a.elig_part, tk, tk + 2 * LEI_SG_CAP,
-                                      tk + 4 * LEI_SG_CAP, tk + 6 * LEI_SG_CAP, LEI_SG_LOG2H, lane, sl, &dk);
+                                      tk + 4 * LEI_SG_CAP, tk + 6 * LEI_SG_CAP, LEI_SG_LOG2H, lane, sl, &dk, a.pickless);
         } else {
             if (node_degree(a, v) > LEI_SG_CAP)
                 return;
@@ -547,7 +551,8 @@ __global__ void __launch_bounds__(64 * LEI_WPB) k_leiden_eval(LeiArgs a, int nsm
             int *lds_c = reinterpret_cast<int *>(lds_w + NG * LEI_SG_CAP);
             unsigned char *lds_e = reinterpret_cast<unsigned char *>(lds_c + NG * LEI_SG_CAP);
             best = best_move_sg<SG>(a.g, v, a.label, a.sum_tot, a.kdeg, a.m, a.resolution, a.use_both, a.elig_part,
-                                    lds_c + grp * LEI_SG_CAP, lds_w + grp * LEI_SG_CAP, lds_e + grp * LEI_SG_CAP, lane, sl, &dk);
+                                    lds_c + grp * LEI_SG_CAP, lds_w + grp * LEI_SG_CAP, lds_e + grp * LEI_SG_CAP, lane, sl, &dk,
+                                    a.pickless);
         }
         if (sl == 0)
             lei_tally(a, v, old, best, dk);
@@ -568,17 +573,17 @@ __global__ void __launch_bounds__(64 * LEI_WPB) k_leiden_eval(LeiArgs a, int nsm
         while ((1 << lg) < 2 * deg)
             lg++;
         best = best_move_hash<64>(a.g, hd, a.label, a.sum_tot, a.m, a.resolution, a.elig_part, tk, tk + H, tk + 2 * H, tk + 3 * H,
-                                  lg, lane, lane, &dk);
+                                  lg, lane, lane, &dk, a.pickless);
     } else if (deg <= a.lds_cap) {
         double *lds_w = reinterpret_cast<double *>(lei_smem);
         int *lds_c = reinterpret_cast<int *>(lds_w + a.lds_cap);
         unsigned char *lds_e = reinterpret_cast<unsigned char *>(lds_c + a.lds_cap);
         best = best_move<false>(a.g, v, a.label, a.sum_tot, a.kdeg, a.m, a.resolution, a.use_both, a.elig_part, lds_c, lds_w,
-                                lds_e, lane, &dk);
+                                lds_e, lane, &dk, a.pickless);
     } else { // more edges than fit in LDS: global scratch, list-order sums
         const size_t o = (size_t)a.bigoff[a.big0 + bi]; // this node's own region (only nodes past LEI_CAP have one)
         best = best_move<false>(a.g, v, a.label, a.sum_tot, a.kdeg, a.m, a.resolution, a.use_both, a.elig_part, a.scratch_c + o,
-                                a.scratch_w + o, a.scratch_e + o, lane, &dk);
+                                a.scratch_w + o, a.scratch_e + o, lane, &dk, a.pickless);
     }
     if (lane == 0)
         lei_tally(a, v, a.label[v], best, dk);
@@ -690,6 +695,35 @@ __global__ void __launch_bounds__(256) k_leiden_apply(LeiArgs a) {
         atomicAdd(a.out, blk_moves);
 }
 
+// Synchronous sweep: every mover applies.  Unweighted graphs: degrees are integers, the f64 atomic adds are exact and
+// order-free.  Weighted graphs: sum_tot was brought up to date in node order by k_leiden_apply_ops, only labels move here.
+__global__ void __launch_bounds__(256) k_leiden_apply_sync(LeiArgs a) {
+    __shared__ int blk_moves;
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (threadIdx.x == 0)
+        blk_moves = 0;
+    __syncthreads();
+    int applied = 0;
+    if (v < a.b1) {
+        const int old = a.label[v], best = a.dec[v];
+        if (best != old) {
+            if (a.apply_on_device) {
+                const double k_v = a.kdeg[v];
+                atomicAdd(a.sum_tot + old, -k_v);
+                atomicAdd(a.sum_tot + best, k_v);
+            }
+            a.label[v] = best;
+            applied = 1;
+        }
+    }
+    const unsigned long long ba = __ballot(applied);
+    if (ba && (threadIdx.x & 63) == __ffsll((long long)ba) - 1)
+        atomicAdd(&blk_moves, __popcll(ba));
+    __syncthreads();
+    if (threadIdx.x == 0 && blk_moves)
+        atomicAdd(a.out, blk_moves);
+}
+
 // Weighted graphs: a round's winners applied on the device in the reference's order.  f64 addition is not associative, so
 // sum_tot[c] must receive its additions exactly as the sequential loop makes them: winners in node order, each first
 // "sum_tot[old] -= k" then "sum_tot[new] += k" (:220-223).  Operation 2·slot is the subtraction, 2·slot + 1 the addition;
@@ -701,8 +735,11 @@ __global__ void __launch_bounds__(256) k_leiden_ops(LeiArgs a, int n_nodes, int 
         return;
     const int v = a.b0 + slot;
     const int old = a.label[v], best = a.dec[slot]; // (labels are written by k_leiden_apply, after this)
-    const int use_bit = a.out[1 + a.parity] > 0 ? 1 : 2;
-    const bool winner = best != old && (a.win[slot] & use_bit);
+    bool winner = best != old; // synchronous sweep: every mover
+    if (!a.sync) {
+        const int use_bit = a.out[1 + a.parity] > 0 ? 1 : 2;
+        winner = winner && (a.win[slot] & use_bit);
+    }
     keys[2 * slot] = winner ? old : n_nodes;
     keys[2 * slot + 1] = winner ? best : n_nodes;
 }
@@ -1215,6 +1252,31 @@ static void lei_grow_setting(int *grow, int *grow_div) {
     *grow_div = std::max(*grow_div, 1);
 }
 
+// evaluation of the nodes [a.b0, a.b1) (+ the wide nodes a.big0..a.big1 of that range) against the frozen state
+static void lei_launch_eval(const LeiArgs &a, int nb, int sg, bool hashed, hipStream_t st) {
+    const int nsmall = (nb + (64 / sg) - 1) / (64 / sg);
+    const unsigned wlds = (unsigned)((lei_eval_lds(sg, hashed, a.lds_cap, a.big_log2h) + 15) & ~(size_t)15);
+    int wpb = LEI_WPB; // (wide nodes with large tables: fewer wavefronts per workgroup, 64 KB of dynamic LDS at most)
+    while (wpb > 1 && (size_t)wlds * wpb > 60 * 1024)
+        wpb >>= 1;
+    const dim3 grid((unsigned)((nsmall + a.big1 - a.big0 + wpb - 1) / wpb)), blk(64 * wpb);
+    const size_t lds = (size_t)wlds * wpb;
+    if (sg == 32 && hashed)
+        hipLaunchKernelGGL((k_leiden_eval<32, true>), grid, blk, lds, st, a, nsmall, wlds);
+    else if (sg == 32)
+        hipLaunchKernelGGL((k_leiden_eval<32, false>), grid, blk, lds, st, a, nsmall, wlds);
+    else if (hashed)
+        hipLaunchKernelGGL((k_leiden_eval<16, true>), grid, blk, lds, st, a, nsmall, wlds);
+    else
+        hipLaunchKernelGGL((k_leiden_eval<16, false>), grid, blk, lds, st, a, nsmall, wlds);
+}
+static int lei_sub_group(const mn_graph *g, int use_both) {
+    int sg = (double)(use_both ? g->e_out + g->e_in : g->e_out) / std::max(1, g->n) > 48.0 ? 32 : 16;
+    if (const char *e = getenv("MN_LEIDEN_SG")) // tuning knob: 16 or 32 lanes per node
+        sg = atoi(e) == 16 ? 16 : 32;
+    return sg;
+}
+
 // one phase (local moving when elig_part == nullptr, refinement otherwise); returns moves, -1 on error
 static long long run_phase(mn_graph *g, LeiArgs a, int mode, int batch, int64_t *sweeps_out) {
     hipStream_t st = g->stream;
@@ -1236,9 +1298,7 @@ static long long run_phase(mn_graph *g, LeiArgs a, int mode, int batch, int64_t 
     long long total = 0;
     int improved = 1, sweeps = 0, parity = 0;
     const bool hashed = !g->weighted; // every weight 1.0 → counts (best_move_hash)
-    int sg = (double)(a.use_both ? g->e_out + g->e_in : g->e_out) / std::max(1, g->n) > 48.0 ? 32 : 16;
-    if (const char *e = getenv("MN_LEIDEN_SG")) // tuning knob: 16 or 32 lanes per node
-        sg = atoi(e) == 16 ? 16 : 32;
+    const int sg = lei_sub_group(g, a.use_both);
     int *const out_base = a.out; // two counter blocks of 8 ints ([0] moves, [1..2] "has a safe winner" by round parity): sweep s uses block s & 1
     int pending = -1;            // sweep whose move count is still on its way to the host (device-applied moves only)
     // Tail rule (part of the schedule, restated in oracle/mn_graph_oracle.c batched_phase): once the sweep before the
@@ -1269,23 +1329,7 @@ static long long run_phase(mn_graph *g, LeiArgs a, int mode, int batch, int64_t 
             while (bigpos < big.size() && big[bigpos] < a.b1)
                 bigpos++;
             a.big1 = (int)bigpos;
-            {
-                const int nsmall = (nb + (64 / sg) - 1) / (64 / sg);
-                const unsigned wlds = (unsigned)((lei_eval_lds(sg, hashed, a.lds_cap, a.big_log2h) + 15) & ~(size_t)15);
-                int wpb = LEI_WPB; // (wide nodes with large tables: fewer wavefronts per workgroup, 64 KB of dynamic LDS at most)
-                while (wpb > 1 && (size_t)wlds * wpb > 60 * 1024)
-                    wpb >>= 1;
-                const dim3 grid((unsigned)((nsmall + a.big1 - a.big0 + wpb - 1) / wpb)), blk(64 * wpb);
-                const size_t lds = (size_t)wlds * wpb;
-                if (sg == 32 && hashed)
-                    hipLaunchKernelGGL((k_leiden_eval<32, true>), grid, blk, lds, st, a, nsmall, wlds);
-                else if (sg == 32)
-                    hipLaunchKernelGGL((k_leiden_eval<32, false>), grid, blk, lds, st, a, nsmall, wlds);
-                else if (hashed)
-                    hipLaunchKernelGGL((k_leiden_eval<16, true>), grid, blk, lds, st, a, nsmall, wlds);
-                else
-                    hipLaunchKernelGGL((k_leiden_eval<16, false>), grid, blk, lds, st, a, nsmall, wlds);
-            }
+            lei_launch_eval(a, nb, sg, hashed, st);
             hipLaunchKernelGGL(k_leiden_win, dim3((nb * 8 + 255) / 256), dim3(256), 0, st, a);
             if (!a.apply_on_device) {
                 // weighted graph: several winners may share a community and f64 addition is not associative → the round's
@@ -1337,6 +1381,74 @@ static long long run_phase(mn_graph *g, LeiArgs a, int mode, int batch, int64_t 
     return total;
 }
 
+// Default schedule of MN_LEIDEN_BATCHED since round 4: WHOLE-GRAPH synchronous sweeps (oracle/mn_graph_oracle.c sync_phase is
+// the restatement, bit for bit).  A sweep = k_leiden_eval over every node against the state frozen at its start +
+// k_leiden_apply_sync applying EVERY positive-gain mover (weighted graphs: sum_tot in node order through the stable sort of
+// k_leiden_ops).  Simultaneous moves can swap two nodes for ever, so every `period`-th sweep is "pick-less" (Naim et al., GPU
+// Louvain): a node may only move to a community with a smaller id.  The phase ends with the first ordinary sweep that moves
+// nothing (= the sequential loop's fixed point); Q is not monotone under simultaneous moves, so after LEI_SYNC_CAP sweeps the
+// round schedule (run_phase: safe winners, Q strictly increasing) finishes the phase.  Config 5's graph: 16 + 16 sweeps of two
+// launches instead of 856 rounds of three.
+#define LEI_PICKLESS 3
+#define LEI_SYNC_CAP 48
+static int lei_round_default(int N) { return (int)std::min<long long>(16384, std::max<long long>(256, N / 32)); }
+static long long run_phase_sync(mn_graph *g, LeiArgs a, int period, int64_t *sweeps_out) {
+    hipStream_t st = g->stream;
+    LeiWork &w = *g->work;
+    const int N = g->n, nbN = (N + 255) / 256;
+    const bool hashed = !g->weighted;
+    const int sg = lei_sub_group(g, a.use_both);
+    int cap = LEI_SYNC_CAP;
+    if (const char *e = getenv("MN_LEIDEN_SYNC_CAP")) // tuning knob (the oracle reads ORC_LEI_SYNC_CAP the same way)
+        cap = atoi(e);
+    a.sync = 1;
+    a.b0 = 0;
+    a.b1 = N;
+    a.big0 = 0;
+    a.big1 = (int)w.h_big.size();
+    a.parity = 0;
+    long long total = 0;
+    int sweeps = 0;
+    bool converged = false;
+    while (sweeps < cap && sweeps < a.max_sweeps) {
+        sweeps++;
+        a.pickless = period > 0 && sweeps % period == 0;
+        GCHK(hipMemsetAsync(a.out, 0, sizeof(int), st));
+        lei_launch_eval(a, N, sg, hashed, st);
+        if (!a.apply_on_device) {
+            const int n_ops = 2 * N;
+            hipLaunchKernelGGL(k_leiden_ops, dim3(nbN), dim3(256), 0, st, a, N, w.okeys);
+            size_t bytes = w.osort_bytes;
+            if (rocprim::radix_sort_pairs(w.osort_tmp, bytes, w.okeys, w.okeys_s, w.oiota, w.oops_s, (size_t)n_ops, 0, w.osort_bits, st) !=
+                hipSuccess) {
+                gset_err("rocprim::radix_sort_pairs failed");
+                return -1;
+            }
+            hipLaunchKernelGGL(k_leiden_apply_ops, dim3((n_ops + 255) / 256), dim3(256), 0, st, a, N, w.okeys_s, w.oops_s, n_ops);
+        }
+        hipLaunchKernelGGL(k_leiden_apply_sync, dim3(nbN), dim3(256), 0, st, a);
+        GCHK(hipGetLastError());
+        GCHK(hipMemcpyAsync(w.h_out, a.out, sizeof(int), hipMemcpyDeviceToHost, st));
+        GCHK(hipStreamSynchronize(st));
+        const int mv = w.h_out[0];
+        total += mv;
+        if (mv == 0 && !a.pickless) {
+            converged = true;
+            break;
+        }
+    }
+    *sweeps_out += sweeps;
+    if (!converged) {
+        a.sync = 0;
+        a.pickless = 0;
+        const long long more = run_phase(g, a, MN_LEIDEN_BATCHED, lei_round_default(N), sweeps_out);
+        if (more < 0)
+            return -1;
+        total += more;
+    }
+    return total;
+}
+
 extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int mode, int batch, int *community_out,
                                double *modularity_out) {
     GCHK(hipSetDevice(g->device));
@@ -1346,14 +1458,20 @@ extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int
         *modularity_out = 0.0;
     if (N == 0)
         return 0;
+    // MN_LEIDEN_BATCHED: batch 0 / 1 = the default schedule, whole-graph synchronous sweeps with a pick-less sweep every
+    // LEI_PICKLESS (run_phase_sync); batch < 0 = the same with period -batch; batch > 1 = rounds of `batch` nodes with the
+    // safe-winner commit rule (run_phase) — also what finishes a synchronous phase that does not settle.
+    int period = 0;
     if (mode == MN_LEIDEN_BATCHED && batch <= 1) {
-        // A round costs about the same wall time up to a few full waves of the chip, and larger rounds need more sweeps.
-        // Measured on the cfg5 graph (N = 500k, <k> = 37): modularity 0.668–0.674 for round sizes 6 250 … 100 000.
-        // (round 2: a round is now three launches of ≈ 10 µs whatever its size; measured on the same graph, ms per run_leiden
-        //  for rounds of 15 625 / 31 250 / 62 500 / 125 000 nodes: 32.9 / 34.1 / 42.6 / 93.4 — smaller rounds need fewer sweeps)
-        batch = (int)std::min<long long>(16384, std::max<long long>(256, N / 32));
-        if (const char *e = getenv("MN_LEIDEN_BATCH")) // tuning knob
-            batch = std::max(256, atoi(e));
+        period = batch < 0 ? -batch : LEI_PICKLESS;
+        if (const char *e = getenv("MN_LEIDEN_BATCH")) { // tuning knob: MN_LEIDEN_BATCH=<round size> selects the round schedule
+            if (atoi(e) > 1) {
+                period = 0;
+                batch = std::max(256, atoi(e));
+            }
+        }
+        if (period)
+            batch = lei_round_default(N); // the rounds a synchronous phase falls back to
     }
     hipStream_t st = g->stream;
     DevGraph dg = {N, g->off_out, g->tgt_out, g->w_out, g->off_in, g->tgt_in, g->w_in};
@@ -1362,7 +1480,7 @@ extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int
     int grow_cap, div_unused;
     lei_grow_setting(&grow_cap, &div_unused);
     const int round_cap = (int)std::min<long long>((long long)batch * grow_cap, std::max(batch, N));
-    if (lei_prepare(g, mode, mode == MN_LEIDEN_BATCHED ? round_cap : batch, use_both, max_deg))
+    if (lei_prepare(g, mode, mode == MN_LEIDEN_BATCHED ? (period ? std::max(round_cap, N) : round_cap) : batch, use_both, max_deg))
         return -1;
     LeiWork &d = *g->work;
     const int nbN = (N + 255) / 256;
@@ -1436,7 +1554,7 @@ extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int
         a.label = d.label;
         a.sum_tot = d.sum_tot;
         a.elig_part = nullptr;
-        long long moves = run_phase(g, a, mode, batch, &g->stats.move_sweeps);
+        long long moves = period ? run_phase_sync(g, a, period, &g->stats.move_sweeps) : run_phase(g, a, mode, batch, &g->stats.move_sweeps);
         if (moves < 0)
             return -1;
         g->stats.iterations++;
@@ -1454,7 +1572,7 @@ extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int
             for (int i = 0; i < N; i++)
                 refined[i] = i;
         }
-        if (run_phase(g, a, mode, batch, &g->stats.refine_sweeps) < 0)
+        if ((period ? run_phase_sync(g, a, period, &g->stats.refine_sweeps) : run_phase(g, a, mode, batch, &g->stats.refine_sweeps)) < 0)
             return -1;
         if (on_dev) {
             // :388-408 adopt the refinement iff it has no more communities than phase 1; then renumber (:317-331)

@@ -27,7 +27,7 @@ def test_oracle_matches_reference_golden(name):
 
 
 @pytest.mark.parametrize("name", ["karate", "er200", "er2000", "er2000w", "planted600"])
-@pytest.mark.parametrize("batch", [16, 1000])
+@pytest.mark.parametrize("batch", [16, 1000, -3])
 def test_batched_schedule_pin(name, batch):
     """The batch-synchronous schedule is this repository's own (the reference has no such mode), so nothing in the
     reference pins it: this file does (oracle/gen_golden.py leiden_schedule_pins).  A change of round sizes, commit rule
@@ -72,7 +72,7 @@ def test_batched_schedule_quality_on_cpu():
     s, d, w = planted(600, 6, 0.15, 0.005, 7)
     csr = og.Csr(s, d, w, "both")
     _, q_seq, _ = og.leiden(csr, 1.0, 1)
-    for batch in (16, 256, 100000):
+    for batch in (16, 256, 100000, -2, -3, -4):  # rounds of `batch` nodes; < 0: whole-graph synchronous sweeps (pick-less period)
         comm, q, st = og.leiden(csr, 1.0, batch)
         assert q > 0 and q >= 0.85 * q_seq, (batch, q, q_seq)
         assert sorted(set(comm)) == list(range(comm.max() + 1))
@@ -113,6 +113,24 @@ def test_gpu_batched_matches_oracle_schedule(gpu, name, batch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("batch", [0, -2, -4])
+def test_gpu_synchronous_sweeps_match_oracle_schedule(gpu, name, batch):
+    """The default schedule (batch 0 = whole-graph synchronous sweeps, pick-less every 3rd) and two other periods against the
+    oracle's restatement (sync_phase): communities, Q bits, moves and sweep counts.  The Erdos-Renyi cases do not settle
+    within the sweep cap and are finished by the round schedule — that hand-over is part of what is compared."""
+    s, d, w, res = CASES[name]
+    csr = og.Csr(s, d, w, "both")
+    oc, oq, ost = og.leiden(csr, res, batch if batch else -3)
+    g = _dev_graph(gpu, csr)
+    comm, q, st = g.leiden(res, "both", gpu.LEIDEN_BATCHED, batch)
+    assert np.array_equal(comm, oc), (name, batch)
+    assert qbits(q) == qbits(oq)
+    assert (st["moves"], st["move_sweeps"], st["refine_sweeps"]) == (ost["moves"], ost["move_sweeps"], ost["refine_sweeps"])
+    g.close()
+
+
+@pytest.mark.gpu
 def test_gpu_high_degree_nodes_use_global_scratch(gpu):
     """a hub with > 1024 edges exercises the global-scratch path of best_move"""
     n = 3000
@@ -132,6 +150,9 @@ def test_gpu_high_degree_nodes_use_global_scratch(gpu):
     bc, bq, _ = og.leiden(csr, 1.0, 512)
     comm, q, _ = g.leiden(1.0, "both", gpu.LEIDEN_BATCHED, 512)
     assert np.array_equal(comm, bc) and qbits(q) == qbits(bq)
+    sc, sq, _ = og.leiden(csr, 1.0, -3)
+    comm, q, _ = g.leiden(1.0, "both", gpu.LEIDEN_BATCHED)  # default: synchronous sweeps (one launch over all nodes, hubs included)
+    assert np.array_equal(comm, sc) and qbits(q) == qbits(sq)
     g.close()
 
 
@@ -150,6 +171,11 @@ def test_gpu_batched_matches_oracle_schedule_at_100k_nodes(gpu, weighted):
     assert np.array_equal(comm, oc) and qbits(q) == qbits(oq) and st["moves"] == ost["moves"]
     comm2, q2, _ = g.leiden(1.0, "both", gpu.LEIDEN_BATCHED, 4096)  # the per-graph workspace is reused: same answer again
     assert np.array_equal(comm2, oc) and qbits(q2) == qbits(oq)
+    # the default schedule (whole-graph synchronous sweeps) on the same graph, same workspace
+    sc, sq, sst = og.leiden(csr, 1.0, -3)
+    comm3, q3, st3 = g.leiden(1.0, "both", gpu.LEIDEN_BATCHED)
+    assert np.array_equal(comm3, sc) and qbits(q3) == qbits(sq) and st3["moves"] == sst["moves"]
+    assert (st3["move_sweeps"], st3["refine_sweeps"]) == (sst["move_sweeps"], sst["refine_sweeps"])
     g.close()
 
 
