@@ -317,6 +317,38 @@ def recall_target_leg(pkg, args, dev_ord, order, M, EFC, target, datasets):
                      f"queries against k_brute_mfma", "datasets": rows}
 
 
+def graph_block(pkg, args, dev_ord, t_start):
+    """BASELINE configs 4 and 5 in the driver's own line (every graph-half figure used to be a builder claim under
+    profiles/): one run_leiden on config 5's graph, unweighted and weighted, and one Node2Vec training run on config 4's graph
+    with its "-> hnsw index" leg — each the line bench_graph.py prints for that workload (value, kernel_ms, roofline with PMC
+    traffic when the kernels are the profiled ones, cpu_baseline from the compiled reference, parity against the oracle).  A leg
+    is skipped, with the reason, when the run would pass --graph-budget-s (the whole default run has to stay within minutes)."""
+    import bench_graph as bg
+
+    def ns(**kw):
+        base = dict(steps=2, warmup=1, n2v_nodes=1_000_000, n2v_edges=20_000_000, n2v_cpu_nodes=1500, n2v_model="er",
+                    leiden_nodes=500_000, leiden_cpu_nodes=150_000, leiden_weighted=False, no_index_leg=False, dump_csr="",
+                    dump_only=False, gpus=1, backend=args.backend, device=dev_ord, ctx=(0, 1, None, dev_ord), quick=True)
+        base.update(kw)
+        return argparse.Namespace(**base)
+
+    out = {}
+    legs = (("leiden_config5", 40, lambda: bg.bench_leiden(pkg, ns())),
+            ("leiden_config5_weighted", 35, lambda: bg.bench_leiden(pkg, ns(leiden_weighted=True))),
+            ("node2vec_config4", 90, lambda: bg.bench_node2vec(pkg, ns(steps=1, warmup=0))))
+    for name, est_s, fn in legs:
+        spent = time.perf_counter() - t_start
+        if spent + est_s > args.graph_budget_s:
+            out[name] = {"skipped": f"{spent:.0f}s of the run already spent, this leg needs about {est_s}s, --graph-budget-s {args.graph_budget_s}"}
+            continue
+        progress(f"graph block: {name}")
+        t0 = time.perf_counter()
+        line = fn()
+        line["leg_wall_s"] = time.perf_counter() - t0
+        out[name] = line
+    return out
+
+
 def host_cpu():
     """model name and core counts of the host the CPU baselines ran on (north_star: "count stated")"""
     model = "unknown"
@@ -386,6 +418,10 @@ def main():
                          "index; auto = 128,256,512 at N=1 and nothing for N>1; '' = none")
     ap.add_argument("--target-datasets", default="lowrank16,lowrank32,lowrank64,clustered,clustered0.01",
                     help="datasets of the recall-target leg (each builds its own full-size index)")
+    ap.add_argument("--no-graph-block", action="store_true",
+                    help="N=1: skip the `graph` block (configs 4 and 5: Leiden unweighted + weighted, Node2Vec -> index)")
+    ap.add_argument("--graph-budget-s", type=float, default=480.0,
+                    help="a leg of the graph block is skipped when the run's wall time so far plus the leg's estimate exceeds this")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL over xGMI; gloo only to rehearse the N>1 path on one GPU)")
     ap.add_argument("--device", type=int, default=-1, help="HIP device ordinal (default: LOCAL_RANK)")
@@ -393,6 +429,7 @@ def main():
                     help="N>1: replica = same index on every GPU, queries sharded (no collective); sharded = config 3: "
                          "rowid mod N shards, same queries everywhere, RCCL all-gather + merge of per-shard top-k")
     args = ap.parse_args()
+    t_run0 = time.perf_counter()
     dataset_spec(args.dataset)
     spawn_ranks_if_needed(args.gpus, os.path.abspath(__file__), sys.argv[1:])
 
@@ -583,13 +620,22 @@ def main():
         nl = min(200, NQ)
         for i in range(20):
             g.search(Q[i], K, EF)
-        tl = []
+        tl, same_ids, same_bits = [], 0, 0
+        out_ds = np.empty((NQ, K), np.float32)
+        g.dev_download(out_ds, d_ds)
+        if sweep:  # the ef sweep left its last ef's answers in the buffers: bring the headline ef's back
+            run_steps(1, EF)
+            g.sync()
+            g.dev_download(out_ids, d_ids)
+            g.dev_download(out_ds, d_ds)
         for i in range(nl):
             t1 = time.perf_counter()
             li, ld_ = g.search(Q[i], K, EF)
             tl.append((time.perf_counter() - t1) * 1e3)
+            same_ids += int(np.array_equal(li, out_ids[i][:len(li)]))
+            same_bits += int(np.array_equal(np.asarray(ld_, np.float32).view(np.int32), out_ds[i][:len(li)].view(np.int32)))
         lone = {"queries": nl, "ms_per_query_median": float(np.median(tl)), "ms_per_query_p90": float(np.percentile(tl, 90)),
-                "same_ids_as_the_batch_kernel": bool(np.array_equal(li, out_ids[nl - 1][:len(li)])),
+                "same_ids_as_the_batch_kernel": same_ids, "same_distance_bits_as_the_batch_kernel": same_bits,
                 "what": "mn_hnsw_search, one query per call, host memory in and out (k_beam_coop; the batch above is k_beam)"}
 
     # ---- CPU baseline: the oracle (single-threaded port of the reference algorithm) on the SAME
@@ -714,6 +760,14 @@ def main():
         quality = graph_quality_leg(pkg, args, dev_ord, order, M, EFC, min(args.quality_n, N),
                                     [d for d in args.quality_datasets.split(",") if d], (128, 256))
 
+    graph = None
+    if rank == 0 and world == 1 and not streamed and not args.no_graph_block and not args.no_cpu_baseline:
+        if g is not None:
+            g.close()
+        g = None
+        X = None
+        graph = graph_block(pkg, args, dev_ord, t_run0)
+
     if rank == 0:
         total_q = NQ * args.steps * (1 if sharded else world)
         line = {
@@ -774,6 +828,8 @@ def main():
                 "kernel_ms": brute_ms, "wall_s": brute_s,
                 "tflops": 2.0 * nrec * N * D / (brute_ms * 1e-3) / 1e12 if brute_ms else None},
             "cpu_baseline": dict(cpu, host=host_cpu()) if cpu else None,
+            # configs 4 and 5 (Node2Vec, Leiden): bench_graph.py's lines for them, measured in this same run
+            "graph": graph,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

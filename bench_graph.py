@@ -49,6 +49,30 @@ def er_edges(n, m, seed=42):
     return s[keep], d[keep]
 
 
+def ba_edges(n, m, seed=42):
+    """Barabasi-Albert preferential attachment as the reference harness builds it (benchmarks/harness/common.py:689-742: a
+    complete graph on the first m + 1 nodes, then every new node attaches to m nodes drawn in proportion to their degree),
+    vectorised: nodes arrive in blocks of 1/8 of the nodes present, a block draws its targets from the ends of the edges that
+    existed when the block started (duplicate targets of one node are dropped by the adjacency build, as a set is there)."""
+    rng = np.random.default_rng(seed)
+    iu, ju = np.triu_indices(m + 1, 1)
+    src, dst = [ju.astype(np.int64)], [iu.astype(np.int64)]
+    ends = [src[0], dst[0]]
+    n_ends = 2 * len(iu)
+    pool = np.concatenate(ends)
+    v = m + 1
+    while v < n:
+        b = min(max(1, v // 8), n - v)
+        new = np.repeat(np.arange(v, v + b, dtype=np.int64), m)
+        tg = pool[rng.integers(0, n_ends, b * m)]
+        src.append(new)
+        dst.append(tg)
+        pool = np.concatenate([pool, new, tg])
+        n_ends = len(pool)
+        v += b
+    return np.concatenate(src), np.concatenate(dst)
+
+
 def _dist_ctx(args):
     """(rank, world, dist module or None, device ordinal) — ranks are started by torch.distributed.run (see bench.py)."""
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -80,11 +104,14 @@ def _max_over_ranks(dist, args, x):
 
 def bench_node2vec(pkg, args):
     n, m, dim = args.n2v_nodes, args.n2v_edges, 128
+    quick = getattr(args, "quick", False)  # bench.py's `graph` block: one training run, no host-side index build
     rank, world, dist, dev = args.ctx
     prm = dict(p=1.0, q=1.0, num_walks=10, walk_length=80, window=5, neg_samples=5, learning_rate=0.025, epochs=1)
     t0 = time.perf_counter()
-    off, adj = pkg.graph.n2v_csr_from_edges(n, *er_edges(n, m))
+    model = getattr(args, "n2v_model", "er")
+    off, adj = pkg.graph.n2v_csr_from_edges(n, *(ba_edges(n, max(1, m // n)) if model == "ba" else er_edges(n, m)))
     gen_s = time.perf_counter() - t0
+    deg = np.diff(off)
     if args.dump_csr:  # for tools/n2v_bench.cpp (the same graph under rocprofv3 --pmc, without Python in the process)
         with open(args.dump_csr, "wb") as f:
             f.write(np.int32(n).tobytes() + np.int64(len(adj)).tobytes())
@@ -140,22 +167,32 @@ def bench_node2vec(pkg, args):
     to_index = None
     if world == 1 and not args.no_index_leg:
         ids = np.arange(1, n + 1, dtype=np.int64)
-        ixh = pkg.HnswIndex(dim, "cosine", 16, 200, device=dev)
-        t0 = time.perf_counter()
-        if ixh.build(ids, emb, 16, 8192) != 0:
-            raise SystemExit("index build failed: " + pkg.hnsw._err())
-        ixh.sync()
-        host_build_s = time.perf_counter() - t0
-        ixh.close()
+        host_build_s = None
+        if not quick:
+            ixh = pkg.HnswIndex(dim, "cosine", 16, 200, device=dev)
+            t0 = time.perf_counter()
+            if ixh.build(ids, emb, 16, 8192) != 0:
+                raise SystemExit("index build failed: " + pkg.hnsw._err())
+            ixh.sync()
+            host_build_s = time.perf_counter() - t0
+            ixh.close()
         ixd = pkg.HnswIndex(dim, "cosine", 16, 200, device=dev)
         t0 = time.perf_counter()
         _, sti = pkg.graph.node2vec_train_into(off, adj, dim, ixd, 1, False, **prm)
         total_s = time.perf_counter() - t0
+        bst = ixd.build_stats()
         ixd.close()
+        # the index build's own roofline: its search half (k_beam<BUILD>) by SURVEY §8(d)'s bytes, counted on the device
+        ab = bst["n_dist"] * dim * 4 + bst["n_expanded"] * 32 * 4 + bst["n_dist"] * 4
         to_index = {"index": f"hnsw_index {n} x {dim} cosine M=16 efC=200, batch-synchronous build",
-                    "via_host_index_build_s": host_build_s, "via_host_total_s": wall + host_build_s,
+                    "via_host_index_build_s": host_build_s, "via_host_total_s": None if host_build_s is None else wall + host_build_s,
                     "device_resident_index_build_s": sti["build_seconds"], "device_resident_total_s": total_s,
-                    "index_vectors_per_s_device_resident": n / max(sti["build_seconds"], 1e-9)}
+                    "index_vectors_per_s_device_resident": n / max(sti["build_seconds"], 1e-9),
+                    "n_dist_per_insert": bst["n_dist"] / max(1, bst["nodes"]),
+                    "build_roofline": {"bound": "hbm", "kernel": "k_beam<BUILD>", "kernel_ms_total": bst["search_ms"],
+                                       "link_ms_total": bst["link_ms"], "batches": bst["batches"], "algorithmic_bytes": ab,
+                                       "achieved": ab / max(bst["search_ms"], 1e-9) / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": ab / max(bst["search_ms"], 1e-9) / 1e6 / HBM_PEAK_GBS}}
     # SGNS reads+writes (1+neg) context rows and the centre row per pair: (2(1+neg)+2)·dim·4 B;
     # the walk adds deg(cur)·4 B per step
     steps_walk = n * prm["num_walks"] * (prm["walk_length"] - 1)
@@ -203,10 +240,11 @@ def bench_node2vec(pkg, args):
         "value": pairs / wall, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"node2vec: ER G(n,m) seed 42, {n} nodes, {m} edge draws -> {len(adj)} directed adjacency "
+        "config": {"workload": f"node2vec: {'Barabasi-Albert m=' + str(max(1, m // n)) if model == 'ba' else 'ER G(n,m)'} seed 42, {n} nodes, {m} edge draws -> {len(adj)} directed adjacency "
                                f"entries; p=q=1, dim {dim}, window 5, neg 5, lr 0.025, 10 walks x 80, 1 epoch; "
                                f"batch-synchronous schedule (MN_N2V_BATCHED, default batch)",
                    "nodes": n, "adjacency_entries": int(len(adj)), "pairs": int(pairs), "graph_build_s": gen_s,
+                   "degree": {"mean": float(deg.mean()), "max": int(deg.max()), "p99": float(np.percentile(deg, 99))},
                    "parallelism": "single GPU" if world == 1 else
                                   f"data-parallel over {world} ranks ({args.backend}): walk/error phase split, samples all-gathered in walk "
                                   f"order, every replica applies the batch (embeddings bit-identical to 1 GPU)"},
@@ -215,7 +253,7 @@ def bench_node2vec(pkg, args):
         "embedding_norm_check": float(np.abs(np.linalg.norm(emb[:1000], axis=1) - 1.0).max()),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": _traffic("node2vec_er1M_20M_batched_default") if (n, m, world) == (1_000_000, 20_000_000, 1) else None,
+                     "traffic": _traffic("node2vec_er1M_20M_batched_default") if (n, m, world, model) == (1_000_000, 20_000_000, 1, "er") else None,
                      "per_kernel": "profiles/r03_n2v_per_kernel.json (k_n2v_walk_grad 0.48, k_n2v_apply 0.61 of 8 TB/s by their own algorithmic bytes)",
                      "kernel": "k_n2v_walk_grad + rocPRIM radix sort + k_n2v_apply (whole pipeline)",
                      "kernel_ms": dev_ms, "algorithmic_bytes_per_launch": alg},
@@ -223,13 +261,33 @@ def bench_node2vec(pkg, args):
     }
 
 
+_LFR_CACHE = {}
+
+
+def _nmi(a, b):
+    """normalised mutual information of two partitions (pair-counting F1 is O(n^2))"""
+    a = np.unique(a, return_inverse=True)[1]
+    b = np.unique(b, return_inverse=True)[1]
+    cont = np.zeros((a.max() + 1, b.max() + 1))
+    np.add.at(cont, (a, b), 1)
+    pa, pb, pab = cont.sum(1) / len(a), cont.sum(0) / len(a), cont / len(a)
+    nz = pab > 0
+    mi = (pab[nz] * np.log(pab[nz] / (pa[:, None] * pb[None, :])[nz])).sum()
+    ha, hb = -(pa[pa > 0] * np.log(pa[pa > 0])).sum(), -(pb[pb > 0] * np.log(pb[pb > 0])).sum()
+    return float(2 * mi / (ha + hb))
+
+
 def bench_leiden(pkg, args):
     n = args.leiden_nodes
+    quick = getattr(args, "quick", False)  # bench.py's `graph` block: bounded CPU legs
     rank, world, dist, dev = args.ctx  # run_leiden does not shard (SURVEY §8e: 1 GPU): N > 1 = N independent replicas
     t0 = time.perf_counter()
-    s, d, truth = pkg.lfr.lfr_like(n, 40, min(200, n // 10), 0.3)
-    # --leiden-weighted: the same graph with edge weights in [0.5, 2.5): list-order f64 sums in the evaluation and the round's
-    # winners applied in the reference's addition order on the device (stable sort by community), instead of integer counts
+    if n not in _LFR_CACHE:
+        _LFR_CACHE.clear()
+        _LFR_CACHE[n] = pkg.lfr.lfr_like(n, 40, min(200, n // 10), 0.3)
+    s, d, truth = _LFR_CACHE[n]
+    # --leiden-weighted: the same graph with edge weights in [0.5, 2.5): list-order f64 sums in the evaluation and the sweep's
+    # movers applied in the reference's addition order on the device (stable sort by community), instead of integer counts
     wts = (np.random.default_rng(8).random(len(s)) * 2 + 0.5) if args.leiden_weighted else None
     g = pkg.graph.graph_from_edges(n, s, d, wts, device=dev)
     gen_s = time.perf_counter() - t0
@@ -254,49 +312,70 @@ def bench_leiden(pkg, args):
 
     from oracle import orc_graph as og
 
-    csr = og.Csr(s, d, wts, "both", n_nodes=n, first_seen=False)
-    t0 = time.perf_counter()
-    oc, oq, ost = og.leiden(csr, 1.0, 1)  # the reference's sequential schedule
-    cpu_s = time.perf_counter() - t0
-    # the device's batched result against the CPU restatement of the same schedule (bit-exact), bounded size
+    # the device's result against the CPU restatement of the same schedule (bit-exact), bounded size: the default schedule
+    # (whole-graph synchronous sweeps, pick-less every 3rd = oracle batch -3) and the round schedule (rounds of 1024 nodes)
     pn = 20000
     ps, pd, _ = pkg.lfr.lfr_like(pn, 20, 100, 0.3, seed=5)
     pw = (np.random.default_rng(9).random(len(ps)) * 2 + 0.5) if args.leiden_weighted else None
     pg = pkg.graph.graph_from_edges(pn, ps, pd, pw)
-    pc, pq, _ = pg.leiden(1.0, "both", pkg.LEIDEN_BATCHED, 1024)
-    oc2, oq2, _ = og.leiden(og.Csr(ps, pd, pw, "both", n_nodes=pn, first_seen=False), 1.0, 1024)
+    pcsr = og.Csr(ps, pd, pw, "both", n_nodes=pn, first_seen=False)
+    par = {"graph": f"LFR-like n={pn}"}
+    for tag, dev_batch, orc_batch in (("default_synchronous_sweeps", 0, -3), ("rounds_of_1024", 1024, 1024)):
+        pc, pq, pst = pg.leiden(1.0, "both", pkg.LEIDEN_BATCHED, dev_batch)
+        oc2, oq2, ost2 = og.leiden(pcsr, 1.0, orc_batch)
+        par[tag] = {"communities_identical": bool(np.array_equal(pc, oc2)),
+                    "modularity_bits_identical": bool(np.float64(pq).view(np.int64) == np.float64(oq2).view(np.int64)),
+                    "sweeps_identical": bool((pst["move_sweeps"], pst["refine_sweeps"]) == (ost2["move_sweeps"], ost2["refine_sweeps"]))}
     pg.close()
-    # how well each partition recovers the planted communities (pair-counting F1 is O(n^2); use NMI)
-    def nmi(a, b):
-        a = np.unique(a, return_inverse=True)[1]
-        b = np.unique(b, return_inverse=True)[1]
-        cont = np.zeros((a.max() + 1, b.max() + 1))
-        np.add.at(cont, (a, b), 1)
-        pa, pb, pab = cont.sum(1) / len(a), cont.sum(0) / len(a), cont / len(a)
-        nz = pab > 0
-        mi = (pab[nz] * np.log(pab[nz] / (pa[:, None] * pb[None, :])[nz])).sum()
-        ha, hb = -(pa[pa > 0] * np.log(pa[pa > 0])).sum(), -(pb[pb > 0] * np.log(pb[pb > 0])).sum()
-        return float(2 * mi / (ha + hb))
+    # CPU beside it.  (a) the reference's own compiled run_leiden (oracle/_ref, src/graph_community.c, gcc -O2) on a bounded
+    # LFR-like sample of the same family; the port must return the same communities and Q bits on it.  (b) unless `quick`: the
+    # port (hashed dedup instead of the reference's O(n_neigh^2) scan) on the FULL graph, for Q / NMI of the sequential schedule
+    cpu = None
+    if og.have_ref_graph():
+        cn = getattr(args, "leiden_cpu_nodes", 150_000)
+        cs, cd, _ = pkg.lfr.lfr_like(cn, 40, 200, 0.3, seed=43)
+        cw = (np.random.default_rng(10).random(len(cs)) * 2 + 0.5) if args.leiden_weighted else None
+        t0 = time.perf_counter()
+        rc_, rq_, _ = og.ref_leiden(cs, cd, cw, "both", 1.0)
+        ref_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        oc_, oq_, _ = og.leiden(og.Csr(cs, cd, cw, "both"), 1.0, 1)
+        port_s = time.perf_counter() - t0
+        cpu = {"value": len(cs) / ref_s, "unit": "edges/s", "cores": 1, "kind": "reference", "host": host_cpu(),
+               "sample": f"the reference's own run_leiden (oracle/_ref/muninn.so, src/graph_community.c, gcc -O2) on an LFR-like graph "
+                         f"of the same family, {cn} nodes / {len(cs)} edges: {ref_s:.1f}s",
+               "communities_and_q_bits_equal_to_port": bool(np.array_equal(rc_, oc_) and np.float64(rq_).view(np.int64) == np.float64(oq_).view(np.int64)),
+               "port": {"value": len(cs) / port_s, "unit": "edges/s", "cores": 1,
+                        "sample": f"oracle/mn_graph_oracle.c (sequential schedule) on the same graph: {port_s:.1f}s"}}
+    seq = None
+    if not quick or cpu is None:
+        csr = og.Csr(s, d, wts, "both", n_nodes=n, first_seen=False)
+        t0 = time.perf_counter()
+        oc, oq, ost = og.leiden(csr, 1.0, 1)  # the reference's sequential schedule
+        cpu_s = time.perf_counter() - t0
+        seq = {"modularity": oq, "communities": int(oc.max()) + 1, "nmi_vs_planted": _nmi(oc, truth), "seconds": cpu_s}
+        if cpu is None:
+            cpu = {"value": E / cpu_s, "unit": "edges/s", "cores": 1, "kind": "port", "host": host_cpu(),
+                   "sample": f"the same graph, reference's sequential schedule (oracle/mn_graph_oracle.c, dedup by hashing "
+                             f"instead of the reference's O(n_neigh^2) scan): {cpu_s:.1f}s"}
+    tkey = f"leiden_lfr{n // 1000}k_{'weighted' if args.leiden_weighted else 'unweighted'}_sync_default"
     out = {
         "metric": "Leiden (local moving + refinement, run_leiden) input edges/sec on a 10M-edge LFR-like graph",
         "value": E * world / wall, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": f"leiden: LFR-like n={n}, <k>=40, k_max 200, mu=0.3, seed 42 -> {E} edges, {'weighted [0.5, 2.5)' if args.leiden_weighted else 'unweighted'}, "
-                               f"direction both, resolution 1.0; batch-synchronous schedule (MN_LEIDEN_BATCHED, default batch)",
+                               f"direction both, resolution 1.0; MN_LEIDEN_BATCHED default schedule: whole-graph synchronous sweeps, pick-less every 3rd",
                    "nodes": n, "edges": int(E), "graph_build_s": gen_s},
         "modularity": q, "communities": int(comm.max()) + 1, "sweeps": int(sweeps), "moves": int(st["moves"]),
-        "nmi_vs_planted": nmi(comm, truth),
-        "cpu_sequential": {"modularity": oq, "communities": int(oc.max()) + 1, "nmi_vs_planted": nmi(oc, truth)},
-        "parity_vs_oracle": {"graph": f"LFR-like n={pn}, batch 1024", "communities_identical": bool(np.array_equal(pc, oc2)),
-                             "modularity_bits_identical": bool(np.float64(pq).view(np.int64) == np.float64(oq2).view(np.int64))},
+        "nmi_vs_planted": _nmi(comm, truth),
+        "cpu_sequential": seq,
+        "parity_vs_oracle": par,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": _traffic("leiden_lfr500k_9.27M_batched_default") if n == 500_000 and not args.leiden_weighted else None,
-                     "kernel": "k_leiden_eval / k_leiden_win / k_leiden_apply rounds (whole run_leiden)", "kernel_ms": dev_ms,
+                     "traffic": _traffic(tkey),
+                     "kernel": "k_leiden_eval + k_leiden_apply_sync, one pair per sweep (whole run_leiden)", "kernel_ms": dev_ms,
                      "algorithmic_bytes_per_launch": alg},
-        "cpu_baseline": {"value": E / cpu_s, "unit": "edges/s", "cores": 1, "kind": "port", "host": host_cpu(),
-                         "sample": f"the same graph, reference's sequential schedule (oracle/mn_graph_oracle.c, dedup by hashing "
-                                   f"instead of the reference's O(n_neigh^2) scan): {cpu_s:.1f}s"},
+        "cpu_baseline": cpu,
     }
     g.close()
     return out
@@ -447,7 +526,10 @@ def main():
     ap.add_argument("--n2v-nodes", type=int, default=1_000_000)
     ap.add_argument("--n2v-edges", type=int, default=20_000_000)
     ap.add_argument("--n2v-cpu-nodes", type=int, default=1500)
+    ap.add_argument("--n2v-model", default="er", choices=["er", "ba"],
+                    help="node2vec graph: er = G(n,m); ba = Barabasi-Albert with m = edges/nodes (SURVEY 8d: power-law degrees)")
     ap.add_argument("--leiden-nodes", type=int, default=500_000)
+    ap.add_argument("--leiden-cpu-nodes", type=int, default=150_000, help="leiden: size of the LFR-like sample the compiled reference is timed on")
     ap.add_argument("--leiden-weighted", action="store_true", help="leiden: random edge weights (the f64 list-order path)")
     ap.add_argument("--no-index-leg", action="store_true", help="node2vec: skip the '-> hnsw index' leg (two 1M-row index builds)")
     ap.add_argument("--dump-csr", default="", help="node2vec: also write the graph as a binary CSR file (tools/n2v_bench.cpp)")

@@ -54,6 +54,13 @@ int mn_abi_version(void);
 const char *mn_last_error(void);
 /* number of usable gfx950 devices (0 → every compute call fails) */
 int mn_device_count(void);
+/* Error convention under memory pressure (src/hnsw_algo.h:55-79: hnsw_create → NULL, hnsw_insert / hnsw_delete → -1,
+ * hnsw_search → 0): no C++ exception ever leaves this library.  Every entry point that can allocate is closed by an exception
+ * barrier (csrc/mn_guard.hpp) which maps std::bad_alloc and friends to the function's error value and names the failure in the
+ * thread's last-error string; a call that may have left its handle half-edited marks the handle unusable, later calls on it
+ * fail cleanly.  Test hook: the nth host allocation this library makes from now on throws std::bad_alloc (0 disarms);
+ * returns the number of host allocations counted since the previous call. */
+long long mn_debug_fault_alloc(long long nth);
 
 /* ---- vec_math.c replacements (a1-a4) ---- */
 /* src/vec_math.c:192-204: "l2" | "cosine" | "inner_product" → 0, else -1 */

@@ -32,7 +32,7 @@ def stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS + ["exports.map"]] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -59,7 +59,9 @@ def build(force: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(one, SOURCES))
-    subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"], check=True, cwd=CSRC)
+    # exports.map: the C-ABI (mn_*) is the only thing this library exports
+    subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"),
+                    "-o", LIB] + objs + ["-ldl"], check=True, cwd=CSRC)
     return LIB
 
 

@@ -1,6 +1,7 @@
 // mn_comm.hip — communicator of the multi-GPU paths: RCCL over xGMI (one rank per GPU, processes or threads), or a
 // caller-supplied host all-gather for rehearsals.  See mn_comm.hpp.
 #include "mn_comm.hpp"
+#include "mn_guard.hpp"
 
 #include <cstdarg>
 #include <cstdio>
@@ -61,7 +62,7 @@ bool rccl_load() {
 }
 } // namespace
 
-extern "C" int mn_comm_unique_id(void *id128) {
+extern "C" int mn_comm_unique_id(void *id128) try {
     if (!rccl_load()) {
         cset_err("mn_comm_unique_id: librccl.so.1 could not be loaded");
         return -1;
@@ -74,9 +75,9 @@ extern "C" int mn_comm_unique_id(void *id128) {
     }
     memcpy(id128, id.internal, MN_COMM_ID_BYTES);
     return 0;
-}
+} MN_GUARD_END(cset_err, MN_NOTHING, -1)
 
-extern "C" mn_comm *mn_comm_init_rccl(int world, int rank, const void *id128, int device) {
+extern "C" mn_comm *mn_comm_init_rccl(int world, int rank, const void *id128, int device) try {
     if (world < 1 || rank < 0 || rank >= world || !id128) {
         cset_err("mn_comm_init_rccl: bad arguments");
         return nullptr;
@@ -103,9 +104,9 @@ extern "C" mn_comm *mn_comm_init_rccl(int world, int rank, const void *id128, in
     c->device = device;
     c->nccl = nc;
     return c;
-}
+} MN_GUARD_END(cset_err, MN_NOTHING, nullptr)
 
-extern "C" mn_comm *mn_comm_init_host(int world, int rank, mn_host_allgather_fn fn, void *user, int device) {
+extern "C" mn_comm *mn_comm_init_host(int world, int rank, mn_host_allgather_fn fn, void *user, int device) try {
     if (world < 1 || rank < 0 || rank >= world || (world > 1 && !fn)) {
         cset_err("mn_comm_init_host: bad arguments");
         return nullptr;
@@ -117,7 +118,7 @@ extern "C" mn_comm *mn_comm_init_host(int world, int rank, mn_host_allgather_fn 
     c->host_fn = fn;
     c->host_user = user;
     return c;
-}
+} MN_GUARD_END(cset_err, MN_NOTHING, nullptr)
 
 extern "C" int mn_comm_world(mn_comm *c) { return c->world; }
 extern "C" int mn_comm_rank(mn_comm *c) { return c->rank; }

@@ -28,6 +28,7 @@
 // Weighted graphs keep those sums on the host in the reference's node order (f64 addition is not associative).
 // All device buffers are allocated once per graph (LeiWork) and reused by later calls.
 #include "../../include/muninn_hip.h"
+#include "mn_guard.hpp"
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -83,25 +84,65 @@ DEVI int best_move(const DevGraph &g, int v, const int *label, const double *sum
     const int old = ld_i<COH>(label + v);
     const int mypart = elig_part ? elig_part[v] : 0;
     __builtin_amdgcn_wave_barrier();
-    for (int e = lane; e < d4; e += 64) {
-        int c = -2; // padding never matches a community
-        double w = 0.0;
-        unsigned char ok = 0;
-        if (e < d) {
-            int t;
-            if (e < d_out) {
-                t = g.tgt_out[o0 + e];
-                w = g.w_out ? g.w_out[o0 + e] : 1.0;
-            } else {
-                t = g.tgt_in[i0 + (e - d_out)];
-                w = g.w_in ? g.w_in[i0 + (e - d_out)] : 1.0;
+    if (COH) {
+        for (int e = lane; e < d4; e += 64) {
+            int c = -2; // padding never matches a community
+            double w = 0.0;
+            unsigned char ok = 0;
+            if (e < d) {
+                int t;
+                if (e < d_out) {
+                    t = g.tgt_out[o0 + e];
+                    w = g.w_out ? g.w_out[o0 + e] : 1.0;
+                } else {
+                    t = g.tgt_in[i0 + (e - d_out)];
+                    w = g.w_in ? g.w_in[i0 + (e - d_out)] : 1.0;
+                }
+                c = ld_i<COH>(label + t);
+                ok = (!elig_part || elig_part[t] == mypart) ? 1 : 0;
             }
-            c = ld_i<COH>(label + t);
-            ok = (!elig_part || elig_part[t] == mypart) ? 1 : 0;
+            ec[e] = c;
+            ew[e] = w;
+            el[e] = ok;
         }
-        ec[e] = c;
-        ew[e] = w;
-        el[e] = ok;
+    } else {
+        // parallel rounds: four edges per lane in flight — every load unconditional (index clamped to the last edge), the four
+        // targets and weights go out back to back, then the four labels (and partitions): two round trips per 256 edges
+        // instead of two per 64 (the guarded one-edge-per-lane loop above is one s_waitcnt per load)
+        const bool has_w = g.w_out != nullptr || g.w_in != nullptr;
+        for (int e0 = 0; e0 < d4; e0 += 256) {
+            int t[4], c[4], part[4];
+            double w[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int ecl = max(0, min(e0 + j * 64 + lane, d - 1));
+                const bool out = ecl < d_out;
+                t[j] = *(out ? g.tgt_out + o0 + ecl : g.tgt_in + i0 + (ecl - d_out));
+                w[j] = 1.0;
+                if (has_w) {
+                    const double *pw = out ? g.w_out : g.w_in;
+                    w[j] = pw ? pw[(out ? o0 + ecl : i0 + (ecl - d_out))] : 1.0;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                c[j] = label[t[j]];
+            if (elig_part) {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    part[j] = elig_part[t[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int e = e0 + j * 64 + lane;
+                if (e >= d4)
+                    continue;
+                const bool in = e < d;
+                ec[e] = in ? c[j] : -2;
+                ew[e] = in ? w[j] : 0.0;
+                el[e] = in && (!elig_part || part[j] == mypart) ? 1 : 0;
+            }
+        }
     }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
@@ -171,102 +212,17 @@ DEVI int best_move(const DevGraph &g, int v, const int *label, const double *sum
 }
 
 
-// best_move for SG-lane sub-groups: the same decisions (staging in list order, in-order f64 sums, strict-gain
-// first-seen rule), 64/SG nodes per wavefront.  All lane exchange stays inside the aligned sub-group, so sub-groups
-// may diverge freely.  lane = absolute lane, sl = lane % SG.  Degree must be <= LEI_SG_CAP.
+// best_move for SG-lane sub-groups (weighted graphs): the same decisions (staging in list order, in-order f64 sums,
+// strict-gain first-seen rule), 64/SG nodes per wavefront.  All lane exchange stays inside the aligned sub-group, so
+// sub-groups may diverge freely.  lane = absolute lane, sl = lane % SG.  Degree must be <= LEI_SG_CAP.
+// Round 4: (i) every load whose address is known goes out at once — head (lei_head), then all targets and weights, then all
+// labels and partitions, then the candidates' sum_tot while the list is scanned: four round trips where the guarded loop made
+// two per SG edges; (ii) ONE scan of the staged list serves all of a lane's LEI_SG_CAP / SG candidate edges (and
+// weight_to_community(v, old)): a third of the LDS reads of one scan per pass; (iii) the closing reduction runs on DPP.
+struct LeiHead;
 template <int SG>
-DEVI int best_move_sg(const DevGraph &g, int v, const int *label, const double *sum_tot, const double *kdeg, double m,
-                      double resolution, int use_both, const int *elig_part, int *ec, double *ew, unsigned char *el, int lane,
-                      int sl, double *dk_out, int pickless) {
-    const int o0 = g.off_out[v], d_out = g.off_out[v + 1] - o0;
-    const int i0 = use_both ? g.off_in[v] : 0, d_in = use_both ? g.off_in[v + 1] - i0 : 0;
-    const int d = d_out + d_in;
-    const int d4 = (d + 3) & ~3;
-    const int old = label[v];
-    const int mypart = elig_part ? elig_part[v] : 0;
-    for (int e = sl; e < d4; e += SG) {
-        int c = -2;
-        double w = 0.0;
-        unsigned char ok = 0;
-        if (e < d) {
-            int t;
-            if (e < d_out) {
-                t = g.tgt_out[o0 + e];
-                w = g.w_out ? g.w_out[o0 + e] : 1.0;
-            } else {
-                t = g.tgt_in[i0 + (e - d_out)];
-                w = g.w_in ? g.w_in[i0 + (e - d_out)] : 1.0;
-            }
-            c = label[t];
-            ok = (!elig_part || elig_part[t] == mypart) ? 1 : 0;
-        }
-        ec[e] = c;
-        ew[e] = w;
-        el[e] = ok;
-    }
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
-    const double k_v = kdeg[v];
-    const int4 *ec4 = reinterpret_cast<const int4 *>(ec);
-    const double2 *ew2 = reinterpret_cast<const double2 *>(ew);
-    const uchar4 *el4 = reinterpret_cast<const uchar4 *>(el);
-    double k_v_to_old = 0.0;
-    for (int q = 0; q < (d4 >> 2); q++) {
-        const int4 cj = ec4[q];
-        const double2 wa = ew2[2 * q], wb = ew2[2 * q + 1];
-        if (cj.x == old) k_v_to_old += wa.x;
-        if (cj.y == old) k_v_to_old += wa.y;
-        if (cj.z == old) k_v_to_old += wb.x;
-        if (cj.w == old) k_v_to_old += wb.y;
-    }
-    const double st_old = sum_tot[old];
-    double best_gain = 0.0;
-    int best = old;
-    for (int base = 0; base < d; base += SG) {
-        const int e = base + sl;
-        const int c = e < d ? ec[e] : -3;
-        bool cand = e < d && el[e] && c != old && !(pickless && c > old);
-        double sacc = 0.0;
-        bool dup = false;
-        for (int q = 0; q < (d4 >> 2); q++) {
-            const int4 cj = ec4[q];
-            const double2 wa = ew2[2 * q], wb = ew2[2 * q + 1];
-            const uchar4 ej = el4[q];
-            const int j = q << 2;
-            if (cj.x == c) { sacc += wa.x; dup |= (j < e) && ej.x; }
-            if (cj.y == c) { sacc += wa.y; dup |= (j + 1 < e) && ej.y; }
-            if (cj.z == c) { sacc += wb.x; dup |= (j + 2 < e) && ej.z; }
-            if (cj.w == c) { sacc += wb.y; dup |= (j + 3 < e) && ej.w; }
-        }
-        cand = cand && !dup;
-        double gain = -1.0, dk = 0.0;
-        if (cand) {
-            const double st_c = sum_tot[c];
-            dk = sacc - k_v_to_old;
-            gain = (sacc - k_v_to_old) / m + resolution * k_v * (st_old - k_v - st_c) / (2.0 * m * m); // :209-210
-            if (!(gain > 0.0))
-                gain = -1.0;
-        }
-        double bg = gain;
-        int bl = lane;
-#pragma unroll
-        for (int mk = SG / 2; mk >= 1; mk >>= 1) {
-            double og = __shfl_xor(bg, mk);
-            int ol = __shfl_xor(bl, mk);
-            if (og > bg || (og == bg && ol < bl)) {
-                bg = og;
-                bl = ol;
-            }
-        }
-        if (bg > best_gain) {
-            best_gain = bg;
-            best = __shfl(c, bl);
-            *dk_out = __shfl(dk, bl);
-        }
-    }
-    return best;
-}
-
+DEVI int best_move_sg(const DevGraph &g, const LeiHead &hd, const int *label, const double *sum_tot, double m, double resolution,
+                      const int *elig_part, int *ec, double *ew, unsigned char *el, int lane, int sl, double *dk_out, int pickless);
 
 // ── unweighted graphs: O(degree) evaluation ──
 // Every weight is 1.0, so weight_to_community(v, c) (:75-90) is the NUMBER of v's edges into c — an integer, exact in
@@ -298,6 +254,138 @@ DEVI LeiHead lei_head(const DevGraph &g, int v, const int *label, const double *
     return h;
 }
 
+// Lane exchange for the reductions inside a sub-group, without the LDS crossbar (__shfl_xor = ds_bpermute, and the SQ counters of
+// round 4 put this kernel's LDS pipe at ≈ 88 % busy): DPP inside a row of 16 lanes — quad exchanges, then the mirrors (any pairing
+// that ends with every lane holding the row's result serves a commutative, associative reduction) —, shuffles only above 16.
+template <int STEP> DEVI int lei_peer(int v) {
+    if (STEP == 0) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+    if (STEP == 1) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+    if (STEP == 2) return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false); // row_half_mirror
+    if (STEP == 3) return __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false); // row_mirror
+    return __shfl_xor(v, STEP == 4 ? 16 : 32);
+}
+template <int STEP> DEVI double lei_peer(double v) {
+    return __hiloint2double(lei_peer<STEP>(__double2hiint(v)), lei_peer<STEP>(__double2loint(v)));
+}
+struct LeiBest {
+    double gain, dk;
+    int pos, c;
+};
+template <int STEP> DEVI void lei_best_step(LeiBest &b) {
+    const double og = lei_peer<STEP>(b.gain), od = lei_peer<STEP>(b.dk);
+    const int op = lei_peer<STEP>(b.pos), oc = lei_peer<STEP>(b.c);
+    if (og > b.gain || (og == b.gain && op < b.pos)) {
+        b.gain = og;
+        b.pos = op;
+        b.c = oc;
+        b.dk = od;
+    }
+}
+
+template <int SG>
+DEVI int best_move_sg(const DevGraph &g, const LeiHead &hd, const int *label, const double *sum_tot, double m, double resolution,
+                      const int *elig_part, int *ec, double *ew, unsigned char *el, int lane, int sl, double *dk_out, int pickless) {
+    constexpr int PER = LEI_SG_CAP / SG; // candidate edges per lane
+    const int o0 = hd.o0, d_out = hd.d_out, i0 = hd.i0, d_in = hd.d_in;
+    const int d = d_out + d_in;
+    const int d4 = (d + 3) & ~3;
+    const int old = hd.old;
+    const int mypart = elig_part ? hd.mypart : 0;
+    const double k_v = hd.k_v;
+    if (d == 0) { // (uniform over the sub-group; the clamped loads below need one edge to clamp to)
+        *dk_out = 0.0;
+        return old;
+    }
+    const double st_old = sum_tot[old];
+    int t[PER], c[PER], part[PER];
+    double w[PER];
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        const int ecl = max(0, min(j * SG + sl, d - 1));
+        const bool out = ecl < d_out;
+        t[j] = *(out ? g.tgt_out + o0 + ecl : g.tgt_in + i0 + (ecl - d_out));
+        const double *pw = out ? g.w_out : g.w_in;
+        w[j] = pw ? pw[out ? o0 + ecl : i0 + (ecl - d_out)] : 1.0;
+    }
+#pragma unroll
+    for (int j = 0; j < PER; j++)
+        c[j] = label[t[j]];
+#pragma unroll
+    for (int j = 0; j < PER; j++)
+        part[j] = elig_part ? elig_part[t[j]] : mypart;
+    double stc[PER];
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        const int e = j * SG + sl;
+        if (e < d4) {
+            const bool in = e < d;
+            ec[e] = in ? c[j] : -2; // padding never matches a community
+            ew[e] = in ? w[j] : 0.0;
+            el[e] = in && part[j] == mypart ? 1 : 0;
+        }
+        stc[j] = sum_tot[c[j]]; // consumed after the scan
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int4 *ec4 = reinterpret_cast<const int4 *>(ec);
+    const double2 *ew2 = reinterpret_cast<const double2 *>(ew);
+    const uchar4 *el4 = reinterpret_cast<const uchar4 *>(el);
+    double k_v_to_old = 0.0, sacc[PER];
+    bool dup[PER];
+#pragma unroll
+    for (int p = 0; p < PER; p++) {
+        sacc[p] = 0.0;
+        dup[p] = false;
+    }
+    // one pass over the list: weight_to_community(v, old) (:163), and for each of the lane's candidate edges the in-order
+    // weight sum of its community (:206) and "an eligible earlier edge already carries it" (the dedup scan of :173-199)
+    for (int q = 0; q < (d4 >> 2); q++) {
+        const int4 cj = ec4[q];
+        const double2 wa = ew2[2 * q], wb = ew2[2 * q + 1];
+        const uchar4 ej = el4[q];
+        const int j = q << 2;
+        if (cj.x == old) k_v_to_old += wa.x;
+        if (cj.y == old) k_v_to_old += wa.y;
+        if (cj.z == old) k_v_to_old += wb.x;
+        if (cj.w == old) k_v_to_old += wb.y;
+#pragma unroll
+        for (int p = 0; p < PER; p++) {
+            const int e = p * SG + sl;
+            if (cj.x == c[p]) { sacc[p] += wa.x; dup[p] |= (j < e) && ej.x; }
+            if (cj.y == c[p]) { sacc[p] += wa.y; dup[p] |= (j + 1 < e) && ej.y; }
+            if (cj.z == c[p]) { sacc[p] += wb.x; dup[p] |= (j + 2 < e) && ej.z; }
+            if (cj.w == c[p]) { sacc[p] += wb.y; dup[p] |= (j + 3 < e) && ej.w; }
+        }
+    }
+    // max gain, lowest edge position on ties == the first candidate with the strictly largest gain (:212)
+    LeiBest b = {-1.0, 0.0, 0x7fffffff, old};
+#pragma unroll
+    for (int p = 0; p < PER; p++) {
+        const int e = p * SG + sl;
+        if (e >= d || part[p] != mypart || c[p] == old || dup[p] || (pickless && c[p] > old))
+            continue;
+        const double gain = (sacc[p] - k_v_to_old) / m + resolution * k_v * (st_old - k_v - stc[p]) / (2.0 * m * m); // :209-210
+        if (gain > 0.0 && gain > b.gain) { // (also drops NaN)
+            b.gain = gain;
+            b.pos = e;
+            b.c = c[p];
+            b.dk = sacc[p] - k_v_to_old;
+        }
+    }
+    lei_best_step<0>(b);
+    lei_best_step<1>(b);
+    lei_best_step<2>(b);
+    lei_best_step<3>(b);
+    if (SG > 16)
+        lei_best_step<4>(b);
+    *dk_out = b.gain > 0.0 ? b.dk : 0.0;
+    return b.gain > 0.0 ? b.c : old;
+}
+
+// Round 4 (the kernel is bound by the LDS pipe): (i) only the KEYS are cleared, four per ds_write_b128 — whoever inserts a key
+// initialises its count and position (LDS operations of one wavefront execute in program order, and the additions come after the
+// probe loop); (ii) edges into the node's own community, most of them once communities have formed, never touch the table:
+// weight_to_community(v, old) is counted in registers and reduced across the sub-group by DPP; (iii) the closing max-reduction
+// runs on DPP as well.  Same decisions, bit for bit.
 template <int SG>
 DEVI int best_move_hash(const DevGraph &g, const LeiHead &hd, const int *label, const double *sum_tot, double m,
                         double resolution, const int *elig_part, int *tk, int *tc, int *tp, int *cl, int log2h, int lane,
@@ -310,17 +398,15 @@ DEVI int best_move_hash(const DevGraph &g, const LeiHead &hd, const int *label, 
     // issued now, consumed after the table is built: this round trip overlaps the targets → labels chain
     const double k_v = hd.k_v;
     const double st_old = sum_tot[old];
-    for (int j = sl; j < H; j += SG) {
-        tk[j] = LEI_EMPTY;
-        tc[j] = 0;
-        tp[j] = 0x7fffffff;
-    }
+    for (int j = 4 * sl; j < H; j += 4 * SG)
+        *reinterpret_cast<int4 *>(tk + j) = make_int4(LEI_EMPTY, LEI_EMPTY, LEI_EMPTY, LEI_EMPTY);
     // cl[0]: number of occupied entries; then their slots (16-bit), appended by whoever inserts a key — the candidate
     // scan below visits the occupied entries only (a handful once communities have formed), not the whole table
     unsigned short *clist = reinterpret_cast<unsigned short *>(cl + 4);
     if (sl == 0)
         cl[0] = 0;
     __builtin_amdgcn_wave_barrier();
+    int n_old = 0; // this lane's edges into the node's own community
     // Four edges per lane at a time, every load unconditional (index clamped to the last edge): the four targets go out
     // back to back, then their four labels (and partitions) — two round trips per 4·SG edges instead of two per SG edges.
     for (int e0 = 0; e0 < d; e0 += 4 * SG) {
@@ -348,13 +434,20 @@ DEVI int best_move_hash(const DevGraph &g, const LeiHead &hd, const int *label, 
             const int e = e0 + j * SG + sl;
             if (e >= d)
                 continue;
+            if (c[j] == old) {
+                n_old++;
+                continue;
+            }
             unsigned h = lei_hash(c[j], log2h);
             for (;;) {
                 int prev = tk[h]; // (a plain read first: most edges find their community already inserted)
                 if (prev == LEI_EMPTY) {
                     prev = atomicCAS(&tk[h], LEI_EMPTY, c[j]);
-                    if (prev == LEI_EMPTY)
+                    if (prev == LEI_EMPTY) {
+                        tc[h] = 0;
+                        tp[h] = 0x7fffffff;
                         clist[atomicAdd(&cl[0], 1)] = (unsigned short)h;
+                    }
                 }
                 if (prev == LEI_EMPTY || prev == c[j])
                     break;
@@ -367,56 +460,45 @@ DEVI int best_move_hash(const DevGraph &g, const LeiHead &hd, const int *label, 
     }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
-    double k_v_to_old = 0.0; // weight_to_community(v, old), :163
-    {
-        unsigned h = lei_hash(old, log2h);
-        for (int probe = 0; probe < H; probe++) {
-            const int key = tk[h];
-            if (key == old) {
-                k_v_to_old = (double)tc[h];
-                break;
-            }
-            if (key == LEI_EMPTY)
-                break;
-            h = (h + 1) & (H - 1);
-        }
-    }
-    double bg = -1.0, bdk = 0.0;
-    int bpos = 0x7fffffff, bc = old;
+    n_old += lei_peer<0>(n_old);
+    n_old += lei_peer<1>(n_old);
+    n_old += lei_peer<2>(n_old);
+    n_old += lei_peer<3>(n_old);
+    if (SG > 16)
+        n_old += lei_peer<4>(n_old);
+    if (SG > 32)
+        n_old += lei_peer<5>(n_old);
+    const double k_v_to_old = (double)n_old; // weight_to_community(v, old), :163
+    LeiBest b = {-1.0, 0.0, 0x7fffffff, old};
     // candidates = the occupied entries, one per lane per pass (max gain, ties to the lowest first position: any order)
     const int ncand = cl[0];
     for (int i = sl; i < ncand; i += SG) {
         const int slot = clist[i];
         const int c = tk[slot], pos = tp[slot];
-        if (c == old || pos == 0x7fffffff || (pickless && c > old))
+        if (pos == 0x7fffffff || (pickless && c > old))
             continue;
         const double sacc = (double)tc[slot];
         const double st_c = sum_tot[c];
         double gain = (sacc - k_v_to_old) / m + resolution * k_v * (st_old - k_v - st_c) / (2.0 * m * m); // :209-210
         if (!(gain > 0.0))
             continue;
-        if (gain > bg || (gain == bg && pos < bpos)) {
-            bg = gain;
-            bpos = pos;
-            bc = c;
-            bdk = sacc - k_v_to_old;
+        if (gain > b.gain || (gain == b.gain && pos < b.pos)) {
+            b.gain = gain;
+            b.pos = pos;
+            b.c = c;
+            b.dk = sacc - k_v_to_old;
         }
     }
-#pragma unroll
-    for (int mk = SG / 2; mk >= 1; mk >>= 1) {
-        const double og = __shfl_xor(bg, mk);
-        const int op = __shfl_xor(bpos, mk);
-        const int oc = __shfl_xor(bc, mk);
-        const double od = __shfl_xor(bdk, mk);
-        if (og > bg || (og == bg && op < bpos)) {
-            bg = og;
-            bpos = op;
-            bc = oc;
-            bdk = od;
-        }
-    }
-    *dk_out = bg > 0.0 ? bdk : 0.0;
-    return bg > 0.0 ? bc : old;
+    lei_best_step<0>(b);
+    lei_best_step<1>(b);
+    lei_best_step<2>(b);
+    lei_best_step<3>(b);
+    if (SG > 16)
+        lei_best_step<4>(b);
+    if (SG > 32)
+        lei_best_step<5>(b);
+    *dk_out = b.gain > 0.0 ? b.dk : 0.0;
+    return b.gain > 0.0 ? b.c : old;
 }
 
 struct LeiArgs {
@@ -544,15 +626,15 @@ __global__ void __launch_bounds__(64 * LEI_WPB) k_leiden_eval(LeiArgs a, int nsm
             best = best_move_hash<SG>(a.g, hd, a.label, a.sum_tot, a.m, a.resolution, a.elig_part, tk, tk + 2 * LEI_SG_CAP,
                                       tk + 4 * LEI_SG_CAP, tk + 6 * LEI_SG_CAP, LEI_SG_LOG2H, lane, sl, &dk, a.pickless);
         } else {
-            if (node_degree(a, v) > LEI_SG_CAP)
+            const LeiHead hd = lei_head(a.g, v, a.label, a.kdeg, a.use_both, a.elig_part);
+            if (hd.d_out + hd.d_in > LEI_SG_CAP)
                 return;
-            old = a.label[v];
+            old = hd.old;
             double *lds_w = reinterpret_cast<double *>(lei_smem);
             int *lds_c = reinterpret_cast<int *>(lds_w + NG * LEI_SG_CAP);
             unsigned char *lds_e = reinterpret_cast<unsigned char *>(lds_c + NG * LEI_SG_CAP);
-            best = best_move_sg<SG>(a.g, v, a.label, a.sum_tot, a.kdeg, a.m, a.resolution, a.use_both, a.elig_part,
-                                    lds_c + grp * LEI_SG_CAP, lds_w + grp * LEI_SG_CAP, lds_e + grp * LEI_SG_CAP, lane, sl, &dk,
-                                    a.pickless);
+            best = best_move_sg<SG>(a.g, hd, a.label, a.sum_tot, a.m, a.resolution, a.elig_part, lds_c + grp * LEI_SG_CAP,
+                                    lds_w + grp * LEI_SG_CAP, lds_e + grp * LEI_SG_CAP, lane, sl, &dk, a.pickless);
         }
         if (sl == 0)
             lei_tally(a, v, old, best, dk);
@@ -836,7 +918,7 @@ template <typename T> static int up(T **dst, const T *src, size_t n) {
 }
 
 extern "C" mn_graph *mn_graph_create(int n_nodes, const int *off_out, const int *tgt_out, const double *w_out,
-                                     const int *off_in, const int *tgt_in, const double *w_in, int device) {
+                                     const int *off_in, const int *tgt_in, const double *w_in, int device) try {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
         gset_err("mn_graph_create: HIP device %d not available (no CPU fallback)", device);
@@ -872,7 +954,7 @@ extern "C" mn_graph *mn_graph_create(int n_nodes, const int *off_out, const int 
     g->h_off_out.assign(off_out, off_out + n_nodes + 1);
     g->h_off_in.assign(off_in, off_in + n_nodes + 1);
     return g;
-}
+} MN_GUARD_END(gset_err, MN_NOTHING, nullptr)
 
 // One direction of a blocked CSR (the rows of "{t}_csr_fwd" / "{t}_csr_rev") straight into device buffers: per
 // block, node count = offsets_bytes/4 - 1 and edge count = targets_bytes/4 (csr_deserialize, src/graph_csr.c:122-163);
@@ -929,7 +1011,7 @@ static int upload_blocks(const mn_csr_block *blk, int nb, int n_nodes, std::vect
 }
 
 extern "C" mn_graph *mn_graph_create_blocked(int n_nodes, const mn_csr_block *fwd, int n_fwd, const mn_csr_block *rev, int n_rev,
-                                             int device) {
+                                             int device) try {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
         gset_err("mn_graph_create_blocked: HIP device %d not available (no CPU fallback)", device);
@@ -984,7 +1066,7 @@ extern "C" mn_graph *mn_graph_create_blocked(int n_nodes, const mn_csr_block *fw
     g->h_off_out.swap(oo);
     g->h_off_in.swap(oi);
     return g;
-}
+} MN_GUARD_END(gset_err, MN_NOTHING, nullptr)
 
 // ───────────────────────── run_leiden workspace (one per graph, reused) ─────────────────────────
 
@@ -1450,7 +1532,7 @@ static long long run_phase_sync(mn_graph *g, LeiArgs a, int period, int64_t *swe
 }
 
 extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int mode, int batch, int *community_out,
-                               double *modularity_out) {
+                               double *modularity_out) try {
     GCHK(hipSetDevice(g->device));
     const int N = g->n;
     memset(&g->stats, 0, sizeof(g->stats));
@@ -1656,12 +1738,12 @@ extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int
     if (modularity_out)
         *modularity_out = Q;
     return 0;
-}
+} MN_GUARD_END(gset_err, MN_NOTHING, -1)
 
-extern "C" int mn_graph_leiden_stats(mn_graph *g, mn_leiden_stats *out) {
+extern "C" int mn_graph_leiden_stats(mn_graph *g, mn_leiden_stats *out) try {
     *out = g->stats;
     return 0;
-}
+} MN_GUARD_END(gset_err, MN_NOTHING, -1)
 
 // ───────────────────────── Brandes betweenness (src/graph_centrality.c:260-505) ─────────────────────────
 // The reference runs one single-source shortest-path pass per source — BFS for unweighted graphs, Dijkstra with a lazy binary
@@ -1874,7 +1956,7 @@ __global__ void k_scale_d(double *x, long long n, double mul, double div1, doubl
     x[i] = v;
 }
 
-extern "C" int mn_graph_betweenness(mn_graph *g, int direction, int auto_approx, int normalized, double *cb_out, double *eb_out) {
+extern "C" int mn_graph_betweenness(mn_graph *g, int direction, int auto_approx, int normalized, double *cb_out, double *eb_out) try {
     GCHK(hipSetDevice(g->device));
     const int N = g->n;
     if (N == 0)
@@ -2008,16 +2090,16 @@ extern "C" int mn_graph_betweenness(mn_graph *g, int direction, int auto_approx,
     if (hipEventElapsedTime(&ms, g->ev0, g->ev1) == hipSuccess)
         g->last_ms = ms;
     return 0;
-}
+} MN_GUARD_END(gset_err, MN_NOTHING, -1)
 
 extern "C" double mn_graph_last_ms(mn_graph *g) { return g->last_ms; }
 
 // GraphData.out as the host sees it (graph_edge_betweenness emits its rows in this order, src/graph_centrality.c:1172-1182)
 extern "C" long long mn_graph_out_edge_count(mn_graph *g) { return g->e_out; }
-extern "C" int mn_graph_out_lists(mn_graph *g, int *off, int *tgt) {
+extern "C" int mn_graph_out_lists(mn_graph *g, int *off, int *tgt) try {
     GCHK(hipSetDevice(g->device));
     memcpy(off, g->h_off_out.data(), ((size_t)g->n + 1) * sizeof(int));
     if (g->e_out)
         GCHK(hipMemcpy(tgt, g->tgt_out, (size_t)g->e_out * sizeof(int), hipMemcpyDeviceToHost));
     return 0;
-}
+} MN_GUARD_END(gset_err, MN_NOTHING, -1)

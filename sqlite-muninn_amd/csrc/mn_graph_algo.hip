@@ -16,6 +16,7 @@
 // uses for inputs of the reference's own test sizes); MN_COMPONENTS_FAST hooks roots in parallel (atomicMin) until
 // nothing changes and compresses: the same partition and sizes, component_id = smallest node index of the component.
 #include "../../include/muninn_hip.h"
+#include "mn_guard.hpp"
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -117,7 +118,7 @@ __global__ void __launch_bounds__(PR_CHUNK)
 }
 
 extern "C" int mn_graph_pagerank(int n, int64_t n_edges, const int *src, const int *dst, double damping, int iterations,
-                                 int device, double *rank_out, mn_graph_algo_stats *stats) {
+                                 int device, double *rank_out, mn_graph_algo_stats *stats) try {
     if (stats)
         memset(stats, 0, sizeof(*stats));
     if (n < 0 || n_edges < 0 || (n_edges && (!src || !dst)) || n_edges > 0x7fffffffLL) {
@@ -203,7 +204,7 @@ extern "C" int mn_graph_pagerank(int n, int64_t n_edges, const int *src, const i
         stats->aux = (int64_t)dang.size();
     }
     return 0;
-}
+} MN_GUARD_END(aset_err, MN_NOTHING, -1)
 
 // ───────────────────────── connected components ─────────────────────────
 
@@ -287,7 +288,7 @@ __global__ void k_cc_out(const int *root, const int *size, int n, int *comp_size
 }
 
 extern "C" int mn_graph_components(int n, int64_t n_edges, const int *src, const int *dst, int mode, int device, int *component_id,
-                                   int *component_size, mn_graph_algo_stats *stats) {
+                                   int *component_size, mn_graph_algo_stats *stats) try {
     if (stats)
         memset(stats, 0, sizeof(*stats));
     if (n < 0 || n_edges < 0 || (n_edges && (!src || !dst)) || (mode != MN_COMPONENTS_EXACT && mode != MN_COMPONENTS_FAST)) {
@@ -352,7 +353,7 @@ extern "C" int mn_graph_components(int n, int64_t n_edges, const int *src, const
         stats->iterations = rounds;
     }
     return 0;
-}
+} MN_GUARD_END(aset_err, MN_NOTHING, -1)
 
 // ───────────────────────── csr_apply_delta (src/graph_csr.c:175-325) ─────────────────────────
 // The reference turns the CSR into per-node lists, replays the delta log in order (INSERT appends, DELETE removes the
@@ -446,7 +447,7 @@ __global__ void k_delta_compact(const int *tmp_off, const int *tmp_tgt, const do
 
 extern "C" int mn_csr_apply_delta(int old_node_count, const int *old_offsets, const int *old_targets, const double *old_weights,
                                   int has_weights, const mn_csr_delta *deltas, int delta_count, int new_node_count, int device,
-                                  int *new_offsets, int **new_targets, double **new_weights, int *new_edge_count) {
+                                  int *new_offsets, int **new_targets, double **new_weights, int *new_edge_count) try {
     if (old_node_count < 0 || delta_count < 0 || !old_offsets || !new_offsets || !new_targets || !new_edge_count) {
         aset_err("mn_csr_apply_delta: bad arguments");
         return -1;
@@ -575,6 +576,6 @@ extern "C" int mn_csr_apply_delta(int old_node_count, const int *old_offsets, co
     }
     *new_edge_count = total;
     return 0;
-}
+} MN_GUARD_END(aset_err, MN_NOTHING, -1)
 
 extern "C" void mn_host_free(void *p) { free(p); }

@@ -3,6 +3,7 @@
 // updates are HIP kernels (mn_kernels.hip, mn_build.hip); the host only keeps the id→slot table,
 // per-node metadata, the level RNG (src/hnsw_algo.c:19-30,240-248) and the cold delete path.
 #include "../../include/muninn_hip.h"
+#include "mn_guard.hpp"
 #include "mn_device.hpp"
 #include "mn_comm.hpp"
 
@@ -28,6 +29,32 @@ static void set_err(const char *fmt, ...) {
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
     g_err = buf;
+}
+
+// ── host allocations of this library: countable, and the n-th one can be made to fail (test hook of the exception barrier,
+//    mn_guard.hpp).  The linker's export map (exports.map: mn_* only) keeps the replacement private to this shared object: it
+//    serves the new-expressions compiled into it (std::vector, std::string bodies instantiated here) and nothing else in the
+//    process. ──
+#include <atomic>
+static std::atomic<long long> g_alloc_count{0}, g_alloc_fail_at{0};
+static inline void *mn_counted_alloc(size_t n) {
+    const long long c = g_alloc_count.fetch_add(1, std::memory_order_relaxed) + 1;
+    if (c == g_alloc_fail_at.load(std::memory_order_relaxed))
+        throw std::bad_alloc();
+    void *p = malloc(n ? n : 1);
+    if (!p)
+        throw std::bad_alloc();
+    return p;
+}
+void *operator new(size_t n) { return mn_counted_alloc(n); }
+void *operator new[](size_t n) { return mn_counted_alloc(n); }
+void operator delete(void *p) noexcept { free(p); }
+void operator delete[](void *p) noexcept { free(p); }
+void operator delete(void *p, size_t) noexcept { free(p); }
+void operator delete[](void *p, size_t) noexcept { free(p); }
+extern "C" long long mn_debug_fault_alloc(long long nth) {
+    g_alloc_fail_at.store(nth > 0 ? nth : 0, std::memory_order_relaxed);
+    return g_alloc_count.exchange(0, std::memory_order_relaxed);
 }
 
 #define HIPCHK(expr)                                                                      \
@@ -536,7 +563,7 @@ static int h_row_count(const int *row, int W) {
 extern "C" int mn_abi_version(void) { return MN_ABI_VERSION; }
 extern "C" const char *mn_last_error(void) { return g_err.c_str(); }
 
-extern "C" int mn_device_count(void) {
+extern "C" int mn_device_count(void) try {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess)
         return 0;
@@ -547,7 +574,7 @@ extern "C" int mn_device_count(void) {
             ok++;
     }
     return ok;
-}
+} MN_GUARD_END(set_err, MN_NOTHING, -1)
 
 extern "C" int mn_vec_parse_metric(const char *name, int *out) { // src/vec_math.c:192-204
     if (!name || !out)
@@ -568,7 +595,7 @@ extern "C" int mn_vec_parse_metric(const char *name, int *out) { // src/vec_math
 }
 
 extern "C" int mn_vec_dist_batch(int metric, int order, const float *query, const float *rows, int64_t n, int dim,
-                                 float *out) {
+                                 float *out) try {
     if (mn_device_count() <= 0) {
         set_err("mn_vec_dist_batch: no gfx950 device");
         return -1;
@@ -588,11 +615,11 @@ extern "C" int mn_vec_dist_batch(int metric, int order, const float *query, cons
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, dout.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
-}
+} MN_GUARD_END(set_err, MN_NOTHING, -1)
 
 // ───────────────────────── create / destroy ─────────────────────────
 
-extern "C" mn_index *mn_hnsw_create_on(int dim, int metric, int M, int ef_construction, int device) {
+extern "C" mn_index *mn_hnsw_create_on(int dim, int metric, int M, int ef_construction, int device) try {
     if (dim <= 0 || M < 2 || ef_construction < 1 || metric < 0 || metric > 2) {
         set_err("mn_hnsw_create: bad parameters");
         return nullptr;
@@ -625,11 +652,11 @@ extern "C" mn_index *mn_hnsw_create_on(int dim, int metric, int M, int ef_constr
         return nullptr;
     }
     return x;
-}
+} MN_GUARD_END(set_err, MN_NOTHING, nullptr)
 
-extern "C" mn_index *mn_hnsw_create(int dim, int metric, int M, int ef_construction) {
+extern "C" mn_index *mn_hnsw_create(int dim, int metric, int M, int ef_construction) try {
     return mn_hnsw_create_on(dim, metric, M, ef_construction, 0);
-}
+} MN_GUARD_END(set_err, MN_NOTHING, nullptr)
 
 extern "C" void mn_hnsw_destroy(mn_index *x) {
     if (!x)
@@ -659,7 +686,7 @@ extern "C" void mn_hnsw_destroy(mn_index *x) {
 
 extern "C" void mn_hnsw_seed_rng(mn_index *x, unsigned seed) { x->rng_state = seed ? seed : 1; }
 
-extern "C" int mn_hnsw_set_order(mn_index *x, int order) {
+extern "C" int mn_hnsw_set_order(mn_index *x, int order) try {
     if (x->n_slots > 0) {
         set_err("mn_hnsw_set_order: index not empty");
         return -1;
@@ -668,7 +695,7 @@ extern "C" int mn_hnsw_set_order(mn_index *x, int order) {
         return -1;
     x->order = order;
     return 0;
-}
+} MN_GUARD_END(set_err, if (x) x->broken = true, -1)
 
 // ───────────────────────── search ─────────────────────────
 
@@ -732,7 +759,7 @@ static int fetch_counters(mn_index *x) {
 }
 
 extern "C" int mn_hnsw_search_batch_dev(mn_index *x, const float *d_queries, int64_t nq, int k, int ef, int64_t *d_ids,
-                                        float *d_dists, int *d_counts) {
+                                        float *d_dists, int *d_counts) try {
     if (use_device(x))
         return -1;
     if (nq <= 0)
@@ -784,7 +811,7 @@ extern "C" int mn_hnsw_search_batch_dev(mn_index *x, const float *d_queries, int
     HIPCHK(hipEventRecord(x->ev1, st));
     HIPCHK(hipGetLastError());
     return 0;
-}
+} MN_GUARD_END(set_err, MN_NOTHING, -1)
 
 // A sharded search all-gathers every shard's overflow count next to its top-k (mn_hnsw_search_sharded_dev): every rank sees
 // the same counts, so every rank fails alike — and names the shard — the first time its host looks (any synchronising call).
@@ -816,12 +843,12 @@ int mn_index_search_overflow(mn_index *x, long long *n_overflow) {
     return 0;
 }
 
-extern "C" int mn_hnsw_sync(mn_index *x) {
+extern "C" int mn_hnsw_sync(mn_index *x) try {
     if (use_device(x))
         return -1;
     HIPCHK(hipStreamSynchronize(x->stream));
     return check_sharded_overflow(x);
-}
+} MN_GUARD_END(set_err, MN_NOTHING, -1)
 
 static int counters_from(mn_index *x, const unsigned long long *c) {
     float ms = 0;
@@ -871,7 +898,7 @@ static int search_small(mn_index *x, const float *queries, int64_t nq, int k, in
 }
 
 extern "C" int mn_hnsw_search_batch(mn_index *x, const float *queries, int64_t nq, int k, int ef, int64_t *out_ids,
-                                    float *out_dists, int *out_counts) {
+                                    float *out_dists, int *out_counts) try {
     if (use_device(x))
         return -1;
     if (nq <= 0)
@@ -899,9 +926,9 @@ extern "C" int mn_hnsw_search_batch(mn_index *x, const float *queries, int64_t n
         }
     }
     return 0;
-}
+} MN_GUARD_END(set_err, MN_NOTHING, -1)
 
-extern "C" int mn_hnsw_search(mn_index *x, const float *query, int k, int ef, mn_search_result *results) {
+extern "C" int mn_hnsw_search(mn_index *x, const float *query, int k, int ef, mn_search_result *results) try {
     if (k <= 0)
         return 0;
     std::vector<int64_t> ids((size_t)k);
@@ -914,7 +941,7 @@ extern "C" int mn_hnsw_search(mn_index *x, const float *query, int k, int ef, mn
         results[i].distance = ds[i];
     }
     return cnt;
-}
+} MN_GUARD_END(set_err, MN_NOTHING, 0)
 
 // ───────────────────────── insert ─────────────────────────
 
@@ -1268,6 +1295,8 @@ static int insert_impl(mn_index *x, const int64_t *ids, const float *vectors, in
     undo.n_pool_rows = x->n_pool_rows;
     undo.rng = x->rng_state;
     undo.entry_id = x->entry_id;
+    bool links_touched = false, any_rest = false;
+    try {
     std::vector<int> slots((size_t)n);
     for (int64_t i = 0; i < n; i++) {
         if (x->node_count * 10 > x->ht_cap * 7) { // :527
@@ -1312,7 +1341,8 @@ static int insert_impl(mn_index *x, const int64_t *ids, const float *vectors, in
         return 0;
     }
     int rc;
-    bool links_touched = true; // the exact modes edit rows in place from the first insert on
+    any_rest = !rest.empty();
+    links_touched = true; // the exact modes edit rows in place from the first insert on
     if (mode == MN_BUILD_SEQUENTIAL) {
         // same result either way; speculation pays once several inserts are queued (MN_SPECULATE=0 turns it off)
         const char *sp = getenv("MN_SPECULATE");
@@ -1334,11 +1364,20 @@ static int insert_impl(mn_index *x, const int64_t *ids, const float *vectors, in
             x->broken = true;
     }
     return rc;
+    } catch (...) {
+        // the same promise when host memory ran out half way (std::bad_alloc out of a table or a staging vector): nothing
+        // inserted while the graph is as it was, an unusable index past that point; the C-ABI's barrier reports it
+        if (!links_touched)
+            undo_insert(x, undo);
+        else if (any_rest)
+            x->broken = true;
+        throw;
+    }
 }
 
 // The persist set of src/hnsw_vtab.c:755-768, accumulated over any number of inserts: every new node and
 // every node that was a neighbour of a new node when it was linked.  Reading it clears it.
-extern "C" int64_t mn_hnsw_take_dirty(mn_index *x, int64_t *ids, int64_t cap) {
+extern "C" int64_t mn_hnsw_take_dirty(mn_index *x, int64_t *ids, int64_t cap) try {
     if (use_device(x))
         return -1;
     if (x->n_slots == 0 || !x->d_dirty.p)
@@ -1363,15 +1402,15 @@ extern "C" int64_t mn_hnsw_take_dirty(mn_index *x, int64_t *ids, int64_t cap) {
         }
     HIPCHK(hipMemset(x->d_dirty.p, 0, n));
     return cnt;
-}
+} MN_GUARD_END(set_err, MN_NOTHING, -1)
 
-extern "C" int mn_hnsw_insert(mn_index *x, int64_t id, const float *vector) {
+extern "C" int mn_hnsw_insert(mn_index *x, int64_t id, const float *vector) try {
     return insert_impl(x, &id, vector, 1, MN_BUILD_SEQUENTIAL);
-}
+} MN_GUARD_END(set_err, MN_NOTHING, -1)
 
-extern "C" int mn_hnsw_insert_batch(mn_index *x, const int64_t *ids, const float *vectors, int64_t n, int mode) {
+extern "C" int mn_hnsw_insert_batch(mn_index *x, const int64_t *ids, const float *vectors, int64_t n, int mode) try {
     return insert_impl(x, ids, vectors, n, mode);
-}
+} MN_GUARD_END(set_err, MN_NOTHING, -1)
 
 // hnsw_insert (src/hnsw_algo.c:520-666) that also says WHICH edges it added and removed: the caller's persistence
 // (src/hnsw_vtab.c:755-776 rewrites the "{t}_edges" rows of the new node and of every neighbour — ≈ 1 100 rows per insert) can
@@ -1381,7 +1420,7 @@ extern "C" int mn_hnsw_insert_batch(mn_index *x, const int64_t *ids, const float
 // persisted those edits, so only a whole rewrite of that node matches it): the persist set (mn_hnsw_take_dirty) is then
 // still complete.  With a valid log the persist set is emptied — the caller has everything.  Same graph, same return
 // convention as mn_hnsw_insert.
-extern "C" int mn_hnsw_insert_logged(mn_index *x, int64_t id, const float *vector, mn_edge_change *log, int cap, int *n_log) {
+extern "C" int mn_hnsw_insert_logged(mn_index *x, int64_t id, const float *vector, mn_edge_change *log, int cap, int *n_log) try {
     *n_log = -1;
     if (use_device(x))
         return -1;
@@ -1415,7 +1454,7 @@ extern "C" int mn_hnsw_insert_logged(mn_index *x, int64_t id, const float *vecto
     if (*n_log >= 0 && x->d_dirty.p && x->n_slots > 0) // (the log replaces the persist set for this insert)
         HIPCHK(hipMemsetAsync(x->d_dirty.p, 0, std::min((size_t)x->n_slots, x->d_dirty.cap), x->stream));
     return 0;
-}
+} MN_GUARD_END(set_err, MN_NOTHING, -1)
 
 // The caller's edge-by-edge copy of the graph no longer matches the index — for the n given nodes, or (ids == NULL) for every
 // node present now (its transaction rolled back): logged inserts report -1 for every insert that touches such a node, until
@@ -1428,7 +1467,7 @@ static void mark_stale(mn_index *x, int slot) {
         x->n_stale++;
     }
 }
-extern "C" int mn_hnsw_log_invalidate(mn_index *x, const int64_t *ids, int64_t n) {
+extern "C" int mn_hnsw_log_invalidate(mn_index *x, const int64_t *ids, int64_t n) try {
     if (!x)
         return -1;
     if (!ids) {
@@ -1442,7 +1481,7 @@ extern "C" int mn_hnsw_log_invalidate(mn_index *x, const int64_t *ids, int64_t n
             mark_stale(x, s);
     }
     return 0;
-}
+} MN_GUARD_END(set_err, MN_NOTHING, -1)
 
 static int build_impl(mn_index *x, const int64_t *ids, const float *vectors, int64_t n, int grow_div, int max_batch,
                       bool src_on_device) {
@@ -1463,16 +1502,16 @@ static int build_impl(mn_index *x, const int64_t *ids, const float *vectors, int
 }
 
 extern "C" int mn_hnsw_build(mn_index *x, const int64_t *ids, const float *vectors, int64_t n, int grow_div,
-                             int max_batch) {
+                             int max_batch) try {
     return build_impl(x, ids, vectors, n, grow_div, max_batch, false);
-}
+} MN_GUARD_END(set_err, if (x) x->broken = true, -1)
 
 // the same build from rows that are already in HBM on the index's device ([n][dim] f32, e.g. the embeddings a Node2Vec run
 // has just normalised: mn_node2vec_train_into): same batches, same graph as mn_hnsw_build on a host copy of those rows
 extern "C" int mn_hnsw_build_dev(mn_index *x, const int64_t *ids, const float *d_vectors, int64_t n, int grow_div,
-                                 int max_batch) {
+                                 int max_batch) try {
     return build_impl(x, ids, d_vectors, n, grow_div, max_batch, true);
-}
+} MN_GUARD_END(set_err, if (x) x->broken = true, -1)
 
 extern "C" int mn_hnsw_device(mn_index *x) { return x->device; }
 
@@ -1482,7 +1521,7 @@ extern "C" int mn_hnsw_device(mn_index *x) { return x->device; }
     if (use_device(x))                                                          \
         return -1;
 
-extern "C" int mn_hnsw_batch_stage(mn_index *x, const int64_t *ids, const float *vectors, int64_t n) {
+extern "C" int mn_hnsw_batch_stage(mn_index *x, const int64_t *ids, const float *vectors, int64_t n) try {
     MN_STAGE_CHECK(x)
     if (!x->staged.empty()) {
         set_err("mn_hnsw_batch_stage: the previous batch was not linked");
@@ -1496,15 +1535,15 @@ extern "C" int mn_hnsw_batch_stage(mn_index *x, const int64_t *ids, const float 
         HIPCHK(hipMemcpy(x->d_staged.p, x->staged.data(), (size_t)m * sizeof(int), hipMemcpyHostToDevice));
     }
     return m;
-}
+} MN_GUARD_END(set_err, if (x) x->broken = true, -1)
 
-extern "C" int mn_hnsw_batch_dims(mn_index *x, int *nlev, int *row_width) {
+extern "C" int mn_hnsw_batch_dims(mn_index *x, int *nlev, int *row_width) try {
     *nlev = x->max_level + 1;
     *row_width = x->M_max0;
     return 0;
-}
+} MN_GUARD_END(set_err, MN_NOTHING, -1)
 
-extern "C" int mn_hnsw_batch_search(mn_index *x, int lo, int hi, int *d_sel, int *d_nsel) {
+extern "C" int mn_hnsw_batch_search(mn_index *x, int lo, int hi, int *d_sel, int *d_nsel) try {
     MN_STAGE_CHECK(x)
     const int m = (int)x->staged.size();
     if (lo < 0 || hi > m || lo > hi) {
@@ -1529,21 +1568,21 @@ extern "C" int mn_hnsw_batch_search(mn_index *x, int lo, int hi, int *d_sel, int
         return -1;
     }
     return 0;
-}
+} MN_GUARD_END(set_err, if (x) x->broken = true, -1)
 
-extern "C" int mn_hnsw_batch_link(mn_index *x, const int *d_sel, const int *d_nsel) {
+extern "C" int mn_hnsw_batch_link(mn_index *x, const int *d_sel, const int *d_nsel) try {
     MN_STAGE_CHECK(x)
     std::vector<int> slots;
     slots.swap(x->staged);
     if (slots.empty())
         return 0;
     return link_batch(x, slots, x->d_staged.p, x->max_level + 1, d_sel, d_nsel);
-}
+} MN_GUARD_END(set_err, if (x) x->broken = true, -1)
 
 // ───────────────────────── multi-GPU: shared build, sharded search ─────────────────────────
 
 extern "C" int mn_hnsw_build_shared(mn_index *x, mn_comm *c, const int64_t *ids, const float *vectors, int64_t n, int grow_div,
-                                    int max_batch, int min_split) {
+                                    int max_batch, int min_split) try {
     MN_STAGE_CHECK(x)
     if (grow_div <= 0)
         grow_div = 16;
@@ -1627,10 +1666,10 @@ extern "C" int mn_hnsw_build_shared(mn_index *x, mn_comm *c, const int64_t *ids,
         }
     }
     return 0;
-}
+} MN_GUARD_END(set_err, if (x) x->broken = true, -1)
 
 extern "C" int mn_hnsw_search_sharded_dev(mn_index *x, mn_comm *c, const float *d_queries, int64_t nq, int k, int ef,
-                                          int64_t *d_ids, float *d_dists, int *d_counts) {
+                                          int64_t *d_ids, float *d_dists, int *d_counts) try {
     if (use_device(x))
         return -1;
     if (nq <= 0)
@@ -1679,10 +1718,10 @@ extern "C" int mn_hnsw_search_sharded_dev(mn_index *x, mn_comm *c, const float *
     mn_launch_merge_topk(x->sh_gids.p, x->sh_gd.p, x->sh_gcnt.p, world, nq, k, (long long *)d_ids, d_dists, d_counts, st);
     HIPCHK(hipGetLastError());
     return 0;
-}
+} MN_GUARD_END(set_err, MN_NOTHING, -1)
 
 extern "C" int mn_hnsw_search_sharded(mn_index *x, mn_comm *c, const float *queries, int64_t nq, int k, int ef, int64_t *out_ids,
-                                      float *out_dists, int *out_counts) {
+                                      float *out_dists, int *out_counts) try {
     if (use_device(x))
         return -1;
     if (nq <= 0)
@@ -1699,7 +1738,7 @@ extern "C" int mn_hnsw_search_sharded(mn_index *x, mn_comm *c, const float *quer
     HIPCHK(hipMemcpyAsync(out_counts, x->sh_lcnt.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return check_sharded_overflow(x);
-}
+} MN_GUARD_END(set_err, MN_NOTHING, -1)
 
 // ───────────────────────── delete (cold path, host-side list surgery) ─────────────────────────
 // hnsw_delete edits the lists of the deleted node's neighbours only (a few dozen rows).  Those rows are worked on as
@@ -1738,7 +1777,7 @@ static int grown_stride(int W, int need) { // a little headroom, so that a run o
     return (nw + 15) & ~15;
 }
 
-extern "C" int mn_hnsw_delete(mn_index *x, int64_t id) { // src/hnsw_algo.c:717-805
+extern "C" int mn_hnsw_delete(mn_index *x, int64_t id) try { // src/hnsw_algo.c:717-805
     if (use_device(x))
         return -1;
     const int s = ht_find(x, id);
@@ -1855,11 +1894,11 @@ extern "C" int mn_hnsw_delete(mn_index *x, int64_t id) { // src/hnsw_algo.c:717-
     if (s < x->meta_uploaded)
         HIPCHK(hipMemcpy(x->d_deleted.p + s, &x->deleted[s], 1, hipMemcpyHostToDevice));
     return 0;
-}
+} MN_GUARD_END(set_err, if (x) x->broken = true, -1)
 
 // ───────────────────────── inspection / load ─────────────────────────
 
-extern "C" int mn_hnsw_get_vector(mn_index *x, int64_t id, float *out) {
+extern "C" int mn_hnsw_get_vector(mn_index *x, int64_t id, float *out) try {
     if (use_device(x))
         return -1;
     int s = ht_find(x, id);
@@ -1869,21 +1908,21 @@ extern "C" int mn_hnsw_get_vector(mn_index *x, int64_t id, float *out) {
         return -1;
     HIPCHK(hipMemcpy(out, x->d_vectors.p + (size_t)s * x->ld, (size_t)x->dim * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
-}
+} MN_GUARD_END(set_err, MN_NOTHING, -1)
 
 extern "C" int mn_hnsw_node_count(mn_index *x) { return x->node_count; }
 extern "C" int64_t mn_hnsw_entry_point(mn_index *x) { return x->entry_id; }
 extern "C" int mn_hnsw_max_level(mn_index *x) { return x->max_level; }
-extern "C" int mn_hnsw_node_level(mn_index *x, int64_t id) {
+extern "C" int mn_hnsw_node_level(mn_index *x, int64_t id) try {
     int s = ht_find(x, id);
     return s < 0 ? -1 : x->levels[s];
-}
-extern "C" int mn_hnsw_node_deleted(mn_index *x, int64_t id) {
+} MN_GUARD_END(set_err, MN_NOTHING, -1)
+extern "C" int mn_hnsw_node_deleted(mn_index *x, int64_t id) try {
     int s = ht_find(x, id);
     return s < 0 ? -1 : x->deleted[s];
-}
+} MN_GUARD_END(set_err, MN_NOTHING, -1)
 
-extern "C" int mn_hnsw_neighbors(mn_index *x, int64_t id, int level, int64_t *out, int cap) {
+extern "C" int mn_hnsw_neighbors(mn_index *x, int64_t id, int level, int64_t *out, int cap) try {
     if (use_device(x))
         return -1;
     int s = ht_find(x, id);
@@ -1905,9 +1944,9 @@ extern "C" int mn_hnsw_neighbors(mn_index *x, int64_t id, int level, int64_t *ou
     for (int i = 0; i < n && i < cap; i++)
         out[i] = x->ids[row[i]];
     return n;
-}
+} MN_GUARD_END(set_err, MN_NOTHING, -1)
 
-extern "C" int mn_hnsw_load_node(mn_index *x, int64_t id, const float *vector, int level, int deleted) {
+extern "C" int mn_hnsw_load_node(mn_index *x, int64_t id, const float *vector, int level, int deleted) try {
     if (use_device(x))
         return -1;
     if (level < 0 || level >= 32)
@@ -1936,9 +1975,9 @@ extern "C" int mn_hnsw_load_node(mn_index *x, int64_t id, const float *vector, i
     if (x->load_vecs.size() * sizeof(float) >= (256u << 20))
         return sync_meta(x);
     return 0;
-}
+} MN_GUARD_END(set_err, if (x) x->broken = true, -1)
 
-extern "C" int mn_hnsw_load_neighbors(mn_index *x, int64_t id, int level, const int64_t *nbrs, int n) {
+extern "C" int mn_hnsw_load_neighbors(mn_index *x, int64_t id, int level, const int64_t *nbrs, int n) try {
     if (use_device(x))
         return -1;
     int s = ht_find(x, id);
@@ -1974,28 +2013,28 @@ extern "C" int mn_hnsw_load_neighbors(mn_index *x, int64_t id, int level, const 
     x->dev_links_stale = true;
     x->dev_links_all = true;
     return 0;
-}
+} MN_GUARD_END(set_err, if (x) x->broken = true, -1)
 
-extern "C" int mn_hnsw_set_entry(mn_index *x, int64_t entry, int max_level) {
+extern "C" int mn_hnsw_set_entry(mn_index *x, int64_t entry, int max_level) try {
     x->entry_id = entry;
     x->max_level = max_level;
     return 0;
-}
+} MN_GUARD_END(set_err, if (x) x->broken = true, -1)
 
 // ───────────────────────── bulk export ─────────────────────────
 
 extern "C" int mn_hnsw_slot_count(mn_index *x) { return x->n_slots; }
 
-extern "C" int mn_hnsw_export_nodes(mn_index *x, int64_t *ids, int *levels, int *deleted) {
+extern "C" int mn_hnsw_export_nodes(mn_index *x, int64_t *ids, int *levels, int *deleted) try {
     for (int s = 0; s < x->n_slots; s++) {
         ids[s] = x->ids[s];
         levels[s] = x->levels[s];
         deleted[s] = x->deleted[s];
     }
     return 0;
-}
+} MN_GUARD_END(set_err, MN_NOTHING, -1)
 
-extern "C" int mn_hnsw_export_vectors(mn_index *x, float *out) {
+extern "C" int mn_hnsw_export_vectors(mn_index *x, float *out) try {
     if (use_device(x))
         return -1;
     if (x->n_slots == 0)
@@ -2006,11 +2045,11 @@ extern "C" int mn_hnsw_export_vectors(mn_index *x, float *out) {
     HIPCHK(hipMemcpy2D(out, (size_t)x->dim * sizeof(float), x->d_vectors.p, (size_t)x->ld * sizeof(float),
                        (size_t)x->dim * sizeof(float), (size_t)x->n_slots, hipMemcpyDeviceToHost));
     return 0;
-}
+} MN_GUARD_END(set_err, MN_NOTHING, -1)
 
 extern "C" int mn_hnsw_row_width(mn_index *x, int level) { return level == 0 ? x->W0 : x->WU; }
 
-extern "C" int mn_hnsw_export_links(mn_index *x, int level, int *out, int *width) {
+extern "C" int mn_hnsw_export_links(mn_index *x, int level, int *out, int *width) try {
     if (use_device(x))
         return -1;
     if (pull_links(x))
@@ -2029,10 +2068,10 @@ extern "C" int mn_hnsw_export_links(mn_index *x, int level, int *out, int *width
         }
     }
     return 0;
-}
+} MN_GUARD_END(set_err, MN_NOTHING, -1)
 
 extern "C" int64_t mn_hnsw_edges_of(mn_index *x, const int64_t *ids, int n, int64_t *out_src, int64_t *out_dst,
-                                    int *out_level, float *out_dist, int64_t cap) {
+                                    int *out_level, float *out_dist, int64_t cap) try {
     if (use_device(x))
         return -1;
     if (push_links(x) || sync_meta(x))
@@ -2082,53 +2121,53 @@ extern "C" int64_t mn_hnsw_edges_of(mn_index *x, const int64_t *ids, int n, int6
             ne++;
         }
     return ne;
-}
+} MN_GUARD_END(set_err, MN_NOTHING, -1)
 
 // ───────────────────────── measurement hooks ─────────────────────────
 
-extern "C" int mn_hnsw_build_stats(mn_index *x, mn_build_stats *out, int reset) {
+extern "C" int mn_hnsw_build_stats(mn_index *x, mn_build_stats *out, int reset) try {
     *out = x->bstats;
     if (reset)
         x->bstats = {0, 0, 0, 0, 0, 0};
     return 0;
-}
+} MN_GUARD_END(set_err, MN_NOTHING, -1)
 
-extern "C" int mn_hnsw_last_launch(mn_index *x, mn_launch_stats *out) {
+extern "C" int mn_hnsw_last_launch(mn_index *x, mn_launch_stats *out) try {
     if (use_device(x))
         return -1;
     if (fetch_counters(x))
         return -1;
     *out = x->last;
     return 0;
-}
+} MN_GUARD_END(set_err, MN_NOTHING, -1)
 
-extern "C" void *mn_dev_malloc(mn_index *x, size_t bytes) {
+extern "C" void *mn_dev_malloc(mn_index *x, size_t bytes) try {
     void *p = nullptr;
     if (hipSetDevice(x->device) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) {
         set_err("mn_dev_malloc(%zu) failed", bytes);
         return nullptr;
     }
     return p;
-}
+} MN_GUARD_END(set_err, MN_NOTHING, nullptr)
 extern "C" void mn_dev_free(mn_index *x, void *p) {
     (void)hipSetDevice(x->device);
     (void)hipFree(p);
 }
-extern "C" int mn_dev_upload(mn_index *x, void *dst, const void *src, size_t bytes) {
+extern "C" int mn_dev_upload(mn_index *x, void *dst, const void *src, size_t bytes) try {
     if (use_device(x))
         return -1;
     HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
     return 0;
-}
-extern "C" int mn_dev_download(mn_index *x, void *dst, const void *src, size_t bytes) {
+} MN_GUARD_END(set_err, MN_NOTHING, -1)
+extern "C" int mn_dev_download(mn_index *x, void *dst, const void *src, size_t bytes) try {
     if (use_device(x))
         return -1;
     HIPCHK(hipStreamSynchronize(x->stream));
     HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     return 0;
-}
+} MN_GUARD_END(set_err, MN_NOTHING, -1)
 
-extern "C" int mn_hnsw_bruteforce_topk(mn_index *x, const float *d_queries, int64_t nq, int k, int64_t *out_ids) {
+extern "C" int mn_hnsw_bruteforce_topk(mn_index *x, const float *d_queries, int64_t nq, int k, int64_t *out_ids) try {
     if (use_device(x))
         return -1;
     if (push_links(x) || sync_meta(x))
@@ -2162,4 +2201,4 @@ extern "C" int mn_hnsw_bruteforce_topk(mn_index *x, const float *d_queries, int6
     HIPCHK(hipMemcpyAsync(out_ids, x->ws_outi.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return 0;
-}
+} MN_GUARD_END(set_err, MN_NOTHING, -1)

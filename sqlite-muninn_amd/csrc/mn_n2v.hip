@@ -15,6 +15,7 @@
 // stream (:323-325), the (deg+1)^0.75 negative table (:284-303, f64 pow) and the 1001-entry sigmoid
 // LUT (:247-258, expf) — these are inputs of the hot loop, not part of it.
 #include "../../include/muninn_hip.h"
+#include "mn_guard.hpp"
 #include <hip/hip_runtime.h>
 #include <chrono>
 
@@ -435,7 +436,7 @@ static int session_init(mn_n2v_session *S, int n, const int *off, const int *adj
     return 0;
 }
 
-extern "C" mn_n2v_session *mn_n2v_begin(int n, const int *off, const int *adj, const mn_n2v_params *prm, int device) {
+extern "C" mn_n2v_session *mn_n2v_begin(int n, const int *off, const int *adj, const mn_n2v_params *prm, int device) try {
     if (n <= 0 || !valid_params(prm)) {
         nset_err("mn_n2v_begin: invalid parameters");
         return nullptr;
@@ -447,30 +448,30 @@ extern "C" mn_n2v_session *mn_n2v_begin(int n, const int *off, const int *adj, c
     }
     (void)hipEventRecord(S->e0, S->st);
     return S;
-}
+} MN_GUARD_END(nset_err, MN_NOTHING, nullptr)
 extern "C" int mn_n2v_batch_walks(mn_n2v_session *S) { return S->B; }
 extern "C" int mn_n2v_sample_slots(mn_n2v_session *S) { return S->cap; }
 extern "C" int mn_n2v_position_slots(mn_n2v_session *S) { return S->a.walk_length; }
 extern "C" int mn_n2v_samples(mn_n2v_session *S, int epoch, int w, int lo, int hi, int *d_center, int *d_target, float *d_err,
-                              int *d_pcenter, float *d_pneu) {
+                              int *d_pcenter, float *d_pneu) try {
     NCHK(hipSetDevice(S->device));
     if (lo < 0 || hi > S->a.n || hi <= lo || hi - lo > S->B) {
         nset_err("mn_n2v_samples: bad walk range [%d, %d)", lo, hi);
         return -1;
     }
     return n2v_samples(S, epoch, w, lo, hi, d_center, d_target, d_err, d_pcenter, d_pneu);
-}
+} MN_GUARD_END(nset_err, MN_NOTHING, -1)
 extern "C" int mn_n2v_apply(mn_n2v_session *S, const int *d_center, const int *d_target, const float *d_err, int64_t ns,
-                            const int *d_pcenter, const float *d_pneu, int64_t np) {
+                            const int *d_pcenter, const float *d_pneu, int64_t np) try {
     NCHK(hipSetDevice(S->device));
     return n2v_apply(S, d_center, d_target, d_err, ns, d_pcenter, d_pneu, np);
-}
-extern "C" int mn_n2v_sync(mn_n2v_session *S) {
+} MN_GUARD_END(nset_err, MN_NOTHING, -1)
+extern "C" int mn_n2v_sync(mn_n2v_session *S) try {
     NCHK(hipSetDevice(S->device));
     NCHK(hipDeviceSynchronize());
     return 0;
-}
-extern "C" int mn_n2v_finish(mn_n2v_session *S, float *out, mn_n2v_stats *stats) {
+} MN_GUARD_END(nset_err, MN_NOTHING, -1)
+extern "C" int mn_n2v_finish(mn_n2v_session *S, float *out, mn_n2v_stats *stats) try {
     NCHK(hipSetDevice(S->device));
     const int n = S->a.n, dim = S->a.dim;
     hipLaunchKernelGGL(k_n2v_normalize, dim3(n), dim3(64), (size_t)dim * sizeof(float), S->st, S->syn0, n, dim);
@@ -486,10 +487,10 @@ extern "C" int mn_n2v_finish(mn_n2v_session *S, float *out, mn_n2v_stats *stats)
         stats->device_ms = ms;
     }
     return n;
-}
+} MN_GUARD_END(nset_err, MN_NOTHING, -1)
 // the same, with the normalised embeddings left where they are: *d_out = [n][dim] f32 in HBM on the session's device, valid
 // until mn_n2v_end (config 4's "-> hnsw index" leg feeds them to mn_hnsw_build_dev without a host round trip)
-extern "C" int mn_n2v_finish_dev(mn_n2v_session *S, const float **d_out, mn_n2v_stats *stats) {
+extern "C" int mn_n2v_finish_dev(mn_n2v_session *S, const float **d_out, mn_n2v_stats *stats) try {
     NCHK(hipSetDevice(S->device));
     const int n = S->a.n, dim = S->a.dim;
     hipLaunchKernelGGL(k_n2v_normalize, dim3(n), dim3(64), (size_t)dim * sizeof(float), S->st, S->syn0, n, dim);
@@ -505,7 +506,7 @@ extern "C" int mn_n2v_finish_dev(mn_n2v_session *S, const float **d_out, mn_n2v_
         stats->device_ms = ms;
     }
     return n;
-}
+} MN_GUARD_END(nset_err, MN_NOTHING, -1)
 
 extern "C" void mn_n2v_end(mn_n2v_session *S) {
     if (!S)
@@ -518,7 +519,7 @@ extern "C" void mn_n2v_end(mn_n2v_session *S) {
 // MN_N2V_BATCHED over several GPUs (config 4), see muninn_hip.h.  The slices are contiguous and gathered in rank order, so
 // the sample order every replica applies is the single-GPU order.
 extern "C" int mn_node2vec_train_shared(mn_comm *c, int n, const int *off, const int *adj, const mn_n2v_params *prm, int device,
-                                        float *out, mn_n2v_stats *stats) {
+                                        float *out, mn_n2v_stats *stats) try {
     if (stats)
         memset(stats, 0, sizeof(*stats));
     if (n == 0)
@@ -641,7 +642,7 @@ extern "C" int mn_node2vec_train_shared(mn_comm *c, int n, const int *off, const
     if (rc == 0)
         rc = mn_n2v_finish(S, out, stats);
     return cleanup(rc < 0 ? -1 : n);
-}
+} MN_GUARD_END(nset_err, MN_NOTHING, -1)
 
 // node2vec_train's compute followed by its output step (src/node2vec.c:540-583: INSERT every embedding into the output
 // hnsw_index) with the embeddings never leaving HBM: trained and normalised on the index's device, then handed to
@@ -649,7 +650,7 @@ extern "C" int mn_node2vec_train_shared(mn_comm *c, int n, const int *off, const
 // receives the embeddings — one bulk copy, for a host that persists them (the extension's "{t}_nodes" shadow table).
 // Same embedding bytes as mn_node2vec_train, same graph as mn_hnsw_build on them.  Returns n, or -1.
 extern "C" int mn_node2vec_train_into(int n, const int *off, const int *adj, const mn_n2v_params *prm, int mode, mn_index *idx,
-                                      int64_t first_rowid, float *host_out, mn_n2v_stats *stats, double *build_seconds) {
+                                      int64_t first_rowid, float *host_out, mn_n2v_stats *stats, double *build_seconds) try {
     if (stats)
         memset(stats, 0, sizeof(*stats));
     if (build_seconds)
@@ -699,10 +700,10 @@ extern "C" int mn_node2vec_train_into(int n, const int *off, const int *adj, con
     }
     mn_n2v_end(S);
     return rc < 0 ? -1 : n;
-}
+} MN_GUARD_END(nset_err, MN_NOTHING, -1)
 
 extern "C" int mn_node2vec_train(int n, const int *off, const int *adj, const mn_n2v_params *prm, int mode, int device,
-                                 float *out, mn_n2v_stats *stats) {
+                                 float *out, mn_n2v_stats *stats) try {
     if (stats)
         memset(stats, 0, sizeof(*stats));
     if (n == 0)
@@ -749,4 +750,4 @@ extern "C" int mn_node2vec_train(int n, const int *off, const int *adj, const mn
     hipLaunchKernelGGL(k_n2v_seq, dim3(1), dim3(64), lds, S->st, S->a);
     NCHK(hipGetLastError());
     return mn_n2v_finish(S, out, stats) < 0 ? -1 : n;
-}
+} MN_GUARD_END(nset_err, MN_NOTHING, -1)

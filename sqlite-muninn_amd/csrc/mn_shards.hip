@@ -7,6 +7,7 @@
 //           (hipMemcpyPeerAsync over xGMI) and merged there in the total order (distance, shard, position).
 //   build : ids are split by shard and the shards are built side by side, one host thread per GPU.
 #include "../../include/muninn_hip.h"
+#include "mn_guard.hpp"
 #include "mn_device.hpp"
 
 #include <cstdarg>
@@ -88,7 +89,7 @@ extern "C" void mn_shards_destroy(mn_shards *s) {
     delete s;
 }
 
-extern "C" mn_shards *mn_shards_create(int dim, int metric, int M, int ef_construction, const int *devices, int n) {
+extern "C" mn_shards *mn_shards_create(int dim, int metric, int M, int ef_construction, const int *devices, int n) try {
     if (n < 1 || n > 64 || !devices) {
         sset_err("mn_shards_create: 1..64 shards");
         return nullptr;
@@ -120,36 +121,36 @@ extern "C" mn_shards *mn_shards_create(int dim, int metric, int M, int ef_constr
         }
     (void)hipGetLastError();
     return s;
-}
+} MN_GUARD_END(sset_err, MN_NOTHING, nullptr)
 
 extern "C" int mn_shards_count(const mn_shards *s) { return s ? s->n : 0; }
 extern "C" mn_index *mn_shards_index(mn_shards *s, int i) { return s && i >= 0 && i < s->n ? s->ix[i] : nullptr; }
 extern "C" int mn_shards_of(const mn_shards *s, int64_t id) { return (int)(((id % s->n) + s->n) % s->n); }
 
-extern "C" int mn_shards_set_order(mn_shards *s, int order) {
+extern "C" int mn_shards_set_order(mn_shards *s, int order) try {
     for (int i = 0; i < s->n; i++)
         if (mn_hnsw_set_order(s->ix[i], order)) {
             sset_err("%s", mn_last_error());
             return -1;
         }
     return 0;
-}
+} MN_GUARD_END(sset_err, MN_NOTHING, -1)
 
-extern "C" int mn_shards_insert(mn_shards *s, int64_t id, const float *vector) {
+extern "C" int mn_shards_insert(mn_shards *s, int64_t id, const float *vector) try {
     const int rc = mn_hnsw_insert(s->ix[mn_shards_of(s, id)], id, vector);
     if (rc)
         sset_err("%s", mn_last_error());
     return rc;
-}
+} MN_GUARD_END(sset_err, MN_NOTHING, -1)
 
-extern "C" int mn_shards_delete(mn_shards *s, int64_t id) {
+extern "C" int mn_shards_delete(mn_shards *s, int64_t id) try {
     const int rc = mn_hnsw_delete(s->ix[mn_shards_of(s, id)], id);
     if (rc)
         sset_err("%s", mn_last_error());
     return rc;
-}
+} MN_GUARD_END(sset_err, MN_NOTHING, -1)
 
-extern "C" int mn_shards_build(mn_shards *s, const int64_t *ids, const float *vectors, int64_t n, int grow_div, int max_batch) {
+extern "C" int mn_shards_build(mn_shards *s, const int64_t *ids, const float *vectors, int64_t n, int grow_div, int max_batch) try {
     const int ns = s->n;
     std::vector<std::vector<int64_t>> sid((size_t)ns);
     std::vector<std::vector<float>> sv((size_t)ns);
@@ -177,11 +178,11 @@ extern "C" int mn_shards_build(mn_shards *s, const int64_t *ids, const float *ve
             return -1;
         }
     return 0;
-}
+} MN_GUARD_END(sset_err, MN_NOTHING, -1)
 
 // queries host [nq][dim]; out_* host [nq][k] / [nq]
 extern "C" int mn_shards_search_batch(mn_shards *s, const float *queries, int64_t nq, int k, int ef_search, int64_t *out_ids,
-                                      float *out_dists, int *out_counts) {
+                                      float *out_dists, int *out_counts) try {
     if (nq <= 0)
         return 0;
     if (k < 1) {
@@ -230,9 +231,9 @@ extern "C" int mn_shards_search_batch(mn_shards *s, const float *queries, int64_
     SCHK(hipMemcpyAsync(out_counts, s->o_cnt, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, s->st0));
     SCHK(hipStreamSynchronize(s->st0));
     return 0;
-}
+} MN_GUARD_END(sset_err, MN_NOTHING, -1)
 
-extern "C" int mn_shards_search(mn_shards *s, const float *query, int k, int ef_search, mn_search_result *results) {
+extern "C" int mn_shards_search(mn_shards *s, const float *query, int k, int ef_search, mn_search_result *results) try {
     if (k < 1) // (before anything is sized by k: nothing may throw across the C boundary)
         return 0;
     std::vector<int64_t> ids((size_t)k);
@@ -245,4 +246,4 @@ extern "C" int mn_shards_search(mn_shards *s, const float *query, int k, int ef_
         results[i].distance = ds[(size_t)i];
     }
     return cnt;
-}
+} MN_GUARD_END(sset_err, MN_NOTHING, 0)

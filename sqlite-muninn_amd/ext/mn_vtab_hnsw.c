@@ -44,6 +44,10 @@ typedef struct {
     sqlite3_int64 *pset_key; /* open-addressing set of the queued rowids */
     unsigned char *pset_used;
     int pset_cap;
+    /* sp_mark[n] = rows queued when savepoint n was established (xSavepoint; statement savepoints included), -1 = not seen:
+     * ROLLBACK TO n cuts the queue back to it, otherwise xSync would insert and persist rows the user rolled back */
+    int *sp_mark;
+    int sp_cap;
     int mode; /* MUNINN_HNSW_MODE */
     /* exact mode, one row at a time: the device says which edges the insert added and removed, and only those rows of
      * "{t}_edges" are written (insert_one_delta) — valid for nodes whose shadow rows equal the index.  A ROLLBACK takes rows
@@ -283,12 +287,32 @@ static void pend_clear(VtabHnsw *v) {
     v->n_pend = 0;
     if (v->pset_used)
         memset(v->pset_used, 0, (size_t)v->pset_cap);
+    for (int i = 0; i < v->sp_cap; i++) /* the queue starts again: every open savepoint now stands at its beginning */
+        if (v->sp_mark[i] > 0)
+            v->sp_mark[i] = 0;
+}
+/* cut the queue back to its first n rows (ROLLBACK TO) and rebuild the rowid set from what is kept */
+static void pend_truncate(VtabHnsw *v, int n) {
+    if (n >= v->n_pend)
+        return;
+    v->n_pend = n;
+    if (v->pset_used)
+        memset(v->pset_used, 0, (size_t)v->pset_cap);
+    for (int i = 0; i < n; i++)
+        pset_put(v, v->pend_ids[i]);
+}
+static void sp_forget(VtabHnsw *v, int from) {
+    for (int i = from < 0 ? 0 : from; i < v->sp_cap; i++)
+        v->sp_mark[i] = -1;
 }
 static void pend_free(VtabHnsw *v) {
     free(v->pend_ids);
     free(v->pend_vecs);
     free(v->pset_key);
     free(v->pset_used);
+    free(v->sp_mark);
+    v->sp_mark = 0;
+    v->sp_cap = 0;
     v->pend_ids = 0;
     v->pend_vecs = 0;
     v->pset_key = 0;
@@ -367,6 +391,8 @@ static int persist_marked(VtabHnsw *v, const sqlite3_int64 *new_ids, const float
     }
     if (nd < 0) {
         free(marked);
+        sqlite3_free(v->base.zErrMsg);
+        v->base.zErrMsg = sqlite3_mprintf("hnsw_index: cannot read the persist set (%s)", mn_last_error());
         return SQLITE_ERROR;
     }
     /* persist_node upserts the node row of every neighbour as well (src/hnsw_vtab.c:243-256).  For a row that exists
@@ -451,6 +477,8 @@ static int persist_marked(VtabHnsw *v, const sqlite3_int64 *new_ids, const float
             continue;
         }
         if (ne < 0) {
+            sqlite3_free(v->base.zErrMsg);
+            v->base.zErrMsg = sqlite3_mprintf("hnsw_index: cannot read neighbour lists (%s)", mn_last_error());
             rc = SQLITE_ERROR;
             break;
         }
@@ -959,7 +987,7 @@ static int x_update(sqlite3_vtab *vt, int argc, sqlite3_value **argv, sqlite3_in
 /* Transaction hooks exist only to learn when the statement/transaction ends (the reference's module has
  * none, src/hnsw_vtab.c:788-803): xSync applies and persists the queue, xRollback drops it. */
 static int x_begin(sqlite3_vtab *vt) {
-    (void)vt;
+    sp_forget((VtabHnsw *)vt, 0);
     return SQLITE_OK;
 }
 static int x_sync(sqlite3_vtab *vt) {
@@ -976,29 +1004,49 @@ static int x_sync(sqlite3_vtab *vt) {
     return rc;
 }
 static int x_commit(sqlite3_vtab *vt) {
-    (void)vt;
+    sp_forget((VtabHnsw *)vt, 0);
     return SQLITE_OK;
 }
 static int x_rollback(sqlite3_vtab *vt) {
     pend_clear((VtabHnsw *)vt);
+    sp_forget((VtabHnsw *)vt, 0);
     mn_hnsw_log_invalidate(((VtabHnsw *)vt)->index, 0, 0); /* shadow rows are gone that the index still holds */
     return SQLITE_OK;
 }
 /* statement and savepoint rollbacks take shadow rows away just the same (a multi-row INSERT that fails half way inside a
  * transaction): the module is version 2 only to hear about them */
 static int x_savepoint(sqlite3_vtab *vt, int n) {
-    (void)vt;
-    (void)n;
+    VtabHnsw *v = (VtabHnsw *)vt;
+    if (n < 0)
+        return SQLITE_OK;
+    if (n >= v->sp_cap) {
+        int nc = v->sp_cap ? v->sp_cap : 8;
+        while (nc <= n)
+            nc *= 2;
+        int *nm = (int *)realloc(v->sp_mark, (size_t)nc * sizeof(int));
+        if (!nm)
+            return SQLITE_NOMEM;
+        for (int i = v->sp_cap; i < nc; i++)
+            nm[i] = -1;
+        v->sp_mark = nm;
+        v->sp_cap = nc;
+    }
+    v->sp_mark[n] = v->n_pend;
+    sp_forget(v, n + 1);
     return SQLITE_OK;
 }
 static int x_release(sqlite3_vtab *vt, int n) {
-    (void)vt;
-    (void)n;
+    sp_forget((VtabHnsw *)vt, n);
     return SQLITE_OK;
 }
 static int x_rollback_to(sqlite3_vtab *vt, int n) {
-    (void)n;
-    mn_hnsw_log_invalidate(((VtabHnsw *)vt)->index, 0, 0);
+    VtabHnsw *v = (VtabHnsw *)vt;
+    /* Rows queued since savepoint n go (deferred / fast mode; in exact mode the queue is always empty here).  A savepoint
+     * this table never heard of was opened before its transaction began (sqlite3VtabBegin announces only the innermost
+     * one), i.e. when the queue was empty. */
+    pend_truncate(v, n >= 0 && n < v->sp_cap && v->sp_mark[n] >= 0 ? v->sp_mark[n] : 0);
+    sp_forget(v, n + 1);
+    mn_hnsw_log_invalidate(v->index, 0, 0);
     return SQLITE_OK;
 }
 

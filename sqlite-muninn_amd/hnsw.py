@@ -46,6 +46,7 @@ SYMBOLS = [
     ("mn_abi_version", C.c_int, []),
     ("mn_last_error", C.c_char_p, []),
     ("mn_device_count", C.c_int, []),
+    ("mn_debug_fault_alloc", C.c_longlong, [C.c_longlong]),
     ("mn_vec_parse_metric", C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     ("mn_vec_dist_batch", C.c_int, [C.c_int, C.c_int, _f32p, _f32p, C.c_int64, C.c_int, _f32p]),
     ("mn_hnsw_create", C.c_void_p, [C.c_int] * 4),

@@ -365,7 +365,8 @@ def test_hnsw_search_batch_tvf_equals_per_query_results(conn, gpu):
 
 @gpu_mark
 def test_graph_leiden_sql_fast_mode_matches_oracle_schedule(conn, gpu, monkeypatch):
-    """MUNINN_GRAPH_MODE=fast → batch-synchronous schedule; must equal the CPU restatement with the same batch."""
+    """MUNINN_GRAPH_MODE=fast → MN_LEIDEN_BATCHED's default schedule (whole-graph synchronous sweeps, pick-less every 3rd);
+    must equal the CPU restatement of it (oracle batch -3)."""
     from oracle import orc_graph as og
     from oracle.graph_cases import leiden_cases
 
@@ -375,8 +376,7 @@ def test_graph_leiden_sql_fast_mode_matches_oracle_schedule(conn, gpu, monkeypat
     monkeypatch.setenv("MUNINN_GRAPH_MODE", "fast")
     rows = conn.execute("SELECT node, community_id, modularity FROM graph_leiden WHERE edge_table='gf' AND src_col='src' AND dst_col='dst'").fetchall()
     csr = og.Csr(s, d, None, "both")
-    batch = min(32768, max(256, csr.n // 16))  # the device's default round size
-    oc, oq, _ = og.leiden(csr, res, batch)
+    oc, oq, _ = og.leiden(csr, res, -3)
     assert np.array_equal(np.array([r[1] for r in rows], np.int32), oc)
     assert rows[0][2] == oq
     monkeypatch.setenv("MUNINN_GRAPH_MODE", "exact")
@@ -433,6 +433,39 @@ def test_queued_rows_rollback_duplicates_and_visibility(conn, gpu, monkeypatch):
     conn.execute("COMMIT")
     assert conn.execute("SELECT rowid FROM q WHERE rowid = 3").fetchall() == [(3,)]
     assert conn.execute("SELECT count(*) FROM q_edges WHERE source_id = 3").fetchone()[0] >= 1
+
+
+@gpu_mark
+@pytest.mark.parametrize("mode", ["deferred", "fast"])
+def test_rolled_back_savepoints_and_failed_statements_take_their_queued_rows_with_them(conn, gpu, monkeypatch, mode):
+    """rows queued after a SAVEPOINT (or by the first rows of a multi-row INSERT that then fails) must not be inserted
+    and persisted by the COMMIT that follows a ROLLBACK TO / the statement's rollback."""
+    monkeypatch.setenv("MUNINN_HNSW_MODE", mode)
+    conn.execute("CREATE VIRTUAL TABLE q USING hnsw_index(dimensions=2, metric='l2', m=4)")
+    conn.isolation_level = None
+    ins = "INSERT INTO q (rowid, vector) VALUES (?, ?)"
+    conn.execute("BEGIN")
+    conn.execute(ins, (1, vec([0, 0])))
+    conn.execute("SAVEPOINT s")
+    conn.execute(ins, (2, vec([1, 0])))
+    conn.execute("ROLLBACK TO s")
+    conn.execute(ins, (3, vec([0, 1])))
+    conn.execute("SAVEPOINT a")
+    conn.execute(ins, (20, vec([2, 2])))
+    conn.execute("SAVEPOINT b")
+    conn.execute(ins, (21, vec([3, 3])))
+    conn.execute("RELEASE b")
+    conn.execute("ROLLBACK TO a")  # takes 20 and (released into a) 21
+    conn.execute(ins, (2, vec([9, 9])))  # rowid 2 is free again: the rolled-back row left the queue's id set too
+    with pytest.raises(Exception, match=r"insert failed \(duplicate rowid 1\?\)"):  # third row fails: the statement's first two go
+        conn.execute("INSERT INTO q (rowid, vector) VALUES (11, ?), (12, ?), (1, ?)", (vec([4, 4]), vec([5, 5]), vec([6, 6])))
+    conn.execute("COMMIT")
+    assert [r[0] for r in conn.execute("SELECT id FROM q_nodes ORDER BY id")] == [1, 2, 3]
+    assert conn.execute("SELECT vector FROM q_nodes WHERE id = 2").fetchone()[0] == vec([9, 9])
+    for gone in (11, 12, 20, 21):
+        assert conn.execute("SELECT rowid FROM q WHERE rowid = ?", (gone,)).fetchall() == []
+    assert sorted(r[0] for r in conn.execute("SELECT rowid FROM q WHERE vector MATCH ? AND k = 10", (vec([0, 0]),))) == [1, 2, 3]
+    assert conn.execute("SELECT count(*) FROM q_edges WHERE source_id NOT IN (1, 2, 3) OR target_id NOT IN (1, 2, 3)").fetchone()[0] == 0
 
 
 @gpu_mark
