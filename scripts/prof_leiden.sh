@@ -1,5 +1,8 @@
+#!/bin/bash
+set -u
 # round-3 Leiden profiles: kernel trace + separate PMC passes over ONE run_leiden on the config-5 graph (scripts/probe_leiden.py 1)
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+[ -d "$R/sqlite-muninn_amd" ] || { echo "repository root not found: $R" >&2; exit 1; }
 cd /tmp && export TMPDIR=/tmp
 W=${1:-}
 T=${2:-lei}

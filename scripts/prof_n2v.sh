@@ -1,5 +1,8 @@
+#!/bin/bash
+set -u
 set -e
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+[ -d "$R/sqlite-muninn_amd" ] || { echo "repository root not found: $R" >&2; exit 1; }
 cd $R
 python bench_graph.py --workload node2vec --dump-csr /tmp/n2v.csr --dump-only
 g++ -O2 -o /tmp/n2v_bench tools/n2v_bench.cpp -Iinclude -Lsqlite-muninn_amd -lmuninn_hip -Wl,-rpath,$R/sqlite-muninn_amd

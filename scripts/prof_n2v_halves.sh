@@ -1,6 +1,9 @@
+#!/bin/bash
+set -u
 # per-half PMC passes of config 4 (tools/n2v_kernels.hip); every profiler run is bounded: rocprofv3's counter collection has
 # hung on this pipeline before
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+[ -d "$R/sqlite-muninn_amd" ] || { echo "repository root not found: $R" >&2; exit 1; }
 cd $R
 python bench_graph.py --workload node2vec --dump-csr /tmp/n2v.csr --dump-only
 hipcc --offload-arch=gfx950 -O2 -o /tmp/n2v_kernels tools/n2v_kernels.hip -Iinclude -Lsqlite-muninn_amd -lmuninn_hip -Wl,-rpath,$R/sqlite-muninn_amd 2>/dev/null

@@ -1,4 +1,7 @@
-R=$GRAFT_REPO_ROOT
+#!/bin/bash
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+[ -d "$R/sqlite-muninn_amd" ] || { echo "repository root not found: $R" >&2; exit 1; }
 cd $R
 python - <<'PY'
 import numpy as np, sys

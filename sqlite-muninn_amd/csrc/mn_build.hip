@@ -74,8 +74,43 @@ __global__ void k_link_scatter(MnLinkArgs a, int max_tuples) {
     a.bins[a.binoff[t] + p] = a.t_src[i];
 }
 
+// Sources of a target in batch order: a bitmap over the batch indices (LDS, nq bits) is walked from the lowest set bit up —
+// the O(sources²) "smallest j above the last one" scan of round 1 made a hub with thousands of reverse edges a straggler.
+DEVI int next_source(const unsigned *bm, int words, int after, int lane) { // smallest set bit > after, or -1 (uniform)
+    int w0 = (after + 1) >> 5;
+    if (after + 1 < 0)
+        w0 = 0;
+    for (int base = w0; base < words; base += 64) {
+        const int wi = base + lane;
+        unsigned v = wi < words ? bm[wi] : 0u;
+        if (wi == w0 && after >= 0)
+            v &= ~((((after + 1) & 31) == 0) ? 0u : ((1u << ((after + 1) & 31)) - 1u));
+        const unsigned long long any = __ballot(v != 0);
+        if (any) {
+            const int l = __ffsll((long long)any) - 1;
+            const unsigned vv = __shfl(v, l);
+            return ((base + l) << 5) + (__ffs((int)vv) - 1);
+        }
+    }
+    return -1;
+}
+
+// One wavefront per touched target replays the reference's steps in batch order: append (node_add_neighbor, :142-163), and on
+// every overflow the MN-RU prune (:601-646).  Round 3 ran each prune from scratch — 33 distances from the target, a ranking
+// pass — which made a HUB a straggler: node2vec embeddings concentrate, most of a batch's 8 192 nodes select the same few
+// dozen neighbours, and each of those received thousands of reverse edges, i.e. thousands of full prunes one after the other
+// (92 ms for one launch, 9.4 of the 10.3 s of the 1M x 128 index build in round 3's profiles).  The replay is now incremental,
+// with the same outcome at every step:
+//   * a distance is computed ONCE per candidate (the row's own entries at the first overflow, the sources 64 at a time): a
+//     prune recomputes d(target, x) from the same operands each time, so the value it would get is the value kept here;
+//   * after a prune without equal distances the row is its candidates in ascending order, so the next overflow is a sorted
+//     insert: a source strictly farther than the last entry is what the prune would drop, any other one lands between its
+//     neighbours in distance and the last entry falls off;
+//   * equal (or unordered) distances are where the mutual-neighbour count and the selection sort's mechanics decide
+//     (:613-639): such a step runs the reference's procedure verbatim (prune_ties) on the M_max + 1 candidates, and keeps
+//     doing so while equal distances remain in the row.
 template <int ORDER, int NCH>
-__global__ void __launch_bounds__(64) k_link_reverse(MnDevIndex ix, MnLinkArgs a, int LW) {
+__global__ void __launch_bounds__(64) k_link_reverse(MnDevIndex ix, MnLinkArgs a, int LW, int bm_words) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
     if ((int)blockIdx.x >= a.counters[1])
@@ -84,14 +119,27 @@ __global__ void __launch_bounds__(64) k_link_reverse(MnDevIndex ix, MnLinkArgs a
     const int W = a.level == 0 ? ix.W0 : ix.WU;
     const int M_max = a.M_max;
     int *list = reinterpret_cast<int *>(smem);        // [LW]  (the row, up to its full capacity, + the new link)
-    float *nd = reinterpret_cast<float *>(list + LW); // [LW]
+    float *nd = reinterpret_cast<float *>(list + LW); // [LW]  distances of list[] from the target, once known
     int *mn = reinterpret_cast<int *>(nd + LW);       // [LW]
-    float *q = reinterpret_cast<float *>(mn + LW);    // [ld]
+    int *tid = mn + LW;                               // [LW]  scatter scratch
+    float *tdd = reinterpret_cast<float *>(tid + LW); // [LW]
+    unsigned *bm = reinterpret_cast<unsigned *>(tdd + LW); // [bm_words] sources of this target by batch index
+    float *q = reinterpret_cast<float *>(bm + bm_words);   // [ld]
 
     const float *tv = ix.vectors + (size_t)t * ix.ld;
     for (int i = lane; i < ix.ld; i += 64)
         q[i] = tv[i];
     const int *row = row_ptr(ix, t, a.level);
+    const float tnorm = ix.metric == 1 ? ix.norms[t] : 0.0f;
+    const int nb = a.count[t];
+    const int *bin = a.bins + a.binoff[t];
+    for (int i = lane; i < bm_words; i += 64)
+        bm[i] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < nb; i += 64) {
+        const int j = bin[i];
+        atomicOr(&bm[j >> 5], 1u << (j & 31));
+    }
     int nc = 0;
     for (int c0 = 0; c0 < W; c0 += 64) { // 64 links per pass
         const int cur = c0 + lane < W ? row[c0 + lane] : -1;
@@ -100,41 +148,127 @@ __global__ void __launch_bounds__(64) k_link_reverse(MnDevIndex ix, MnLinkArgs a
     }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
-    const float tnorm = ix.metric == 1 ? ix.norms[t] : 0.0f;
 
-    const int nb = a.count[t];
-    const int *bin = a.bins + a.binoff[t];
+    const bool may_overflow = nc + nb > M_max; // otherwise every source is appended and no distance is ever needed
+    const int n_init = nc;                     // the row's own entries: their distances are computed at the first overflow
+    bool have_nd = false, clean = false;       // clean: list[0..M_max) ascending by distance, all different, none unordered
+    float worst = 0.0f;
     int last = -1;
-    for (int it = 0; it < nb; it++) {
-        // next source in batch order: smallest j > last
-        int best = 0x7fffffff;
-        for (int i = lane; i < nb; i += 64) {
-            int j = bin[i];
-            if (j > last && j < best)
-                best = j;
+    for (int c0 = 0; c0 < nb; c0 += 64) {
+        const int n = nb - c0 < 64 ? nb - c0 : 64;
+        // the next n sources in batch order, one per lane, and their distances in one pass
+        int myj = 0;
+        for (int k = 0; k < n; k++) {
+            last = next_source(bm, bm_words, last, lane);
+            if (lane == k)
+                myj = last;
         }
-        for (int m = 32; m >= 1; m >>= 1) {
-            int o = __shfl_xor(best, m);
-            best = o < best ? o : best;
+        const int svec = lane < n ? a.query_slots[myj] : 0;
+        float dvec = 0.0f;
+        if (may_overflow) {
+            dvec = rows_distance<ORDER, NCH>(ix, q, tnorm, svec, n, lane);
+            if (lane < n && ix.deleted[svec])
+                dvec = 1e30f; // :610-612
         }
-        last = best;
-        const int s = a.query_slots[best];
-        // node_add_neighbor (src/hnsw_algo.c:142-163): skip if already present
-        bool present = false;
-        for (int c0 = 0; c0 < nc; c0 += 64)
-            present |= __ballot(c0 + lane < nc && list[c0 + lane] == s) != 0;
-        if (present)
-            continue;
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0)
-            list[nc] = s;
-        nc++;
-        __builtin_amdgcn_wave_barrier();
-        if (nc <= M_max)
-            continue;
-        // ── prune to M_max (:601-646) ──
-        prune_any<ORDER, NCH, false>(ix, q, tnorm, list, nd, mn, nc, M_max, a.level, lane);
-        nc = M_max;
+        for (int k = 0; k < n; k++) {
+            const int s = __builtin_amdgcn_readlane(svec, k);
+            const float ds = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dvec), k));
+            // node_add_neighbor (src/hnsw_algo.c:142-163): skip if already present
+            bool present = false;
+            for (int x0 = 0; x0 < nc; x0 += 64)
+                present |= __ballot(x0 + lane < nc && list[x0 + lane] == s) != 0;
+            if (present)
+                continue;
+            if (nc < M_max) { // room left: appended, nothing pruned
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) {
+                    list[nc] = s;
+                    nd[nc] = ds;
+                }
+                nc++;
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
+            if (!have_nd) { // first overflow: the distances of the row's own entries (later ones came with their source)
+                for (int x0 = 0; x0 < n_init; x0 += 64) {
+                    const int m = n_init - x0 < 64 ? n_init - x0 : 64;
+                    const int sl = lane < m ? list[x0 + lane] : 0;
+                    float d = rows_distance<ORDER, NCH>(ix, q, tnorm, sl, m, lane);
+                    if (lane < m && ix.deleted[sl])
+                        d = 1e30f;
+                    if (lane < m)
+                        nd[x0 + lane] = d;
+                }
+                __builtin_amdgcn_wave_barrier();
+                have_nd = true;
+            }
+            if (clean && M_max <= 64 && ds == ds) {
+                if (ds > worst)
+                    continue; // strictly the farthest of the M_max + 1 candidates: the prune drops it, the row stays as it is
+                const float di = lane < M_max ? nd[lane] : 3.0e38f;
+                const unsigned long long lt = __ballot(lane < M_max && di < ds), eq = __ballot(lane < M_max && di == ds);
+                if (!eq) { // lands between its neighbours in distance; the last entry falls off
+                    const int pos = __popcll(lt);
+                    const int idi = lane < M_max ? list[lane] : 0;
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane >= pos && lane + 1 < M_max) {
+                        list[lane + 1] = idi;
+                        nd[lane + 1] = di;
+                    }
+                    if (lane == 0) {
+                        list[pos] = s;
+                        nd[pos] = ds;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    worst = nd[M_max - 1];
+                    continue;
+                }
+            }
+            // ── the prune itself (:601-646) on the nc + 1 candidates, distances known ──
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                list[nc] = s;
+                nd[nc] = ds;
+            }
+            nc++;
+            __builtin_amdgcn_wave_barrier();
+            bool cl = false; // all distances different and ordered → the selection sort is an ascending sort: rank and scatter
+            for (int e0 = 0; e0 < nc; e0 += 64) {
+                const int e = e0 + lane;
+                if (e < nc) {
+                    const float de = nd[e];
+                    int r = 0;
+                    for (int x = 0; x < nc; x++) {
+                        const float o = nd[x];
+                        if (x != e && !(o < de) && !(de < o))
+                            cl = true;
+                        r += o < de;
+                    }
+                    mn[e] = r;
+                    tid[e] = list[e];
+                    tdd[e] = de;
+                }
+            }
+            if (!__ballot(cl)) {
+                __builtin_amdgcn_wave_barrier();
+                for (int e = lane; e < nc; e += 64)
+                    if (mn[e] < M_max) {
+                        list[mn[e]] = tid[e];
+                        nd[mn[e]] = tdd[e];
+                    }
+                __builtin_amdgcn_wave_barrier();
+                clean = true;
+            } else { // equal or unordered distances: mutual-neighbour counts and the reference's selection sort, verbatim
+                __builtin_amdgcn_wave_barrier();
+                prune_ties<false>(ix, list, nd, mn, nc, M_max, a.level, lane);
+                bool dirty = false; // do equal / unordered distances remain among the kept entries?
+                for (int e = lane; e + 1 < M_max; e += 64)
+                    dirty |= !(nd[e] < nd[e + 1]);
+                clean = !__ballot(dirty);
+            }
+            nc = M_max;
+            worst = nd[M_max - 1];
+        }
     }
     // stage the finished row
     int *out = a.newrows + (size_t)blockIdx.x * ix.WX;
@@ -169,11 +303,12 @@ static int pick_nch_b(int ld) {
 
 template <int ORDER, int NCH>
 static void launch_reverse(const MnDevIndex &ix, const MnLinkArgs &a, int max_tuples, hipStream_t st) {
-    int LW = (ix.WX + 64 + 63) & ~63; // the row is staged 64 links at a time, then one more is appended
+    int LW = (ix.WX + 64 + 63) & ~63; // the row is staged 64 links at a time, then one more / a chunk of 64 sources is appended
     if (LW < 192)
         LW = 192;
-    size_t lds = (size_t)LW * 3 * sizeof(int) + (size_t)ix.ld * sizeof(float);
-    hipLaunchKernelGGL((k_link_reverse<ORDER, NCH>), dim3(max_tuples), dim3(64), lds, st, ix, a, LW);
+    const int bm_words = ((a.nq + 31) / 32 + 3) & ~3; // sources of one target by batch index
+    size_t lds = (size_t)LW * 5 * sizeof(int) + (size_t)bm_words * sizeof(unsigned) + (size_t)ix.ld * sizeof(float);
+    hipLaunchKernelGGL((k_link_reverse<ORDER, NCH>), dim3(max_tuples), dim3(64), lds, st, ix, a, LW, bm_words);
 }
 
 void mn_launch_link(const MnDevIndex &ix, const MnLinkArgs &a, int max_tuples, hipStream_t st) {

@@ -88,6 +88,67 @@ DEVI void sse_chunks(const float *__restrict__ row, const float *q_lds, int j, i
     }
 }
 
+#ifndef MN_SSE_QUAD2
+#define MN_SSE_QUAD2 8 // float4 loads in flight per lane (0: the dword walk).  Same-box A/B, 1M x 768, ef 128, 10k queries
+                       // (scripts/ab_search2.sh): dword walk 28.85 ms, 4 in flight 27.83 ms, 8 in flight 27.43 ms per launch
+#endif
+// MN_SSE_QUAD2 (round 4): the SSE-order walk with 16-byte loads.  Quad lane q of a row fetches the float4 of chain position
+// 4t + q — the quad reads 64 contiguous bytes of the row with ONE load instruction where the dword walk needs four, and a
+// quarter of the cache-line look-ups per byte —, forms its four products, and a 4 x 4 transpose inside the quad (two DPP
+// exchange rounds) hands accumulator j its terms of positions 4t .. 4t+3, which it adds in that order: the reference's
+// operations in the reference's order, same bits.  UB float4 loads are in flight per lane before the first use.
+template <bool L2, int UB>
+DEVI void sse_blocks_quad(const float *__restrict__ row, const float *q_lds, int j, int blocks, int &t, float &s) {
+    const bool b0 = j & 1, b1 = j & 2;
+    for (; t + UB <= blocks; t += UB) {
+        float4 bv[UB];
+#pragma unroll
+        for (int u = 0; u < UB; u++)
+            bv[u] = *reinterpret_cast<const float4 *>(row + 16 * (t + u) + 4 * j);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            const float4 a = *reinterpret_cast<const float4 *>(q_lds + 16 * (t + u) + 4 * j);
+            const float4 b = bv[u];
+            float p0, p1, p2, p3;
+            if (L2) {
+                const float d0 = __fsub_rn(a.x, b.x), d1 = __fsub_rn(a.y, b.y), d2 = __fsub_rn(a.z, b.z), d3 = __fsub_rn(a.w, b.w);
+                p0 = __fmul_rn(d0, d0);
+                p1 = __fmul_rn(d1, d1);
+                p2 = __fmul_rn(d2, d2);
+                p3 = __fmul_rn(d3, d3);
+            } else {
+                p0 = __fmul_rn(a.x, b.x);
+                p1 = __fmul_rn(a.y, b.y);
+                p2 = __fmul_rn(a.z, b.z);
+                p3 = __fmul_rn(a.w, b.w);
+            }
+            // lane q holds the products of position 4t+q for accumulators 0..3; accumulator j wants positions 4t..4t+3 of j
+            float r0 = quad_xor1(b0 ? p0 : p1), r1 = quad_xor1(b0 ? p2 : p3); // across lane bit 0: pairs (0,1), (2,3)
+            if (b0) {
+                p0 = r0;
+                p2 = r1;
+            } else {
+                p1 = r0;
+                p3 = r1;
+            }
+            r0 = quad_xor2(b1 ? p0 : p2); // across lane bit 1: pairs (0,2), (1,3)
+            r1 = quad_xor2(b1 ? p1 : p3);
+            if (b1) {
+                p0 = r0;
+                p1 = r1;
+            } else {
+                p2 = r0;
+                p3 = r1;
+            }
+            s = __fadd_rn(s, p0);
+            s = __fadd_rn(s, p1);
+            s = __fadd_rn(s, p2);
+            s = __fadd_rn(s, p3);
+        }
+    }
+}
+
 template <bool L2, bool LAT = false>
 DEVI float sse_row(const float *__restrict__ row, const float *q_lds, int dim, int lane) {
     const int j = lane & 3;
@@ -143,6 +204,15 @@ DEVI float sse_row(const float *__restrict__ row, const float *q_lds, int dim, i
         s = __fadd_rn(s, p3);
     }
     c = blocks << 2;
+#endif
+#if MN_SSE_QUAD2 > 0
+    if (!LAT) { // (the lone-search kernels keep the dword walk: they run one wavefront against the instruction cache)
+        const int blocks = steps >> 2;
+        int t = 0;
+        sse_blocks_quad<L2, (MN_SSE_QUAD2 > 0 ? MN_SSE_QUAD2 : 1)>(row, q_lds, j, blocks, t, s);
+        sse_blocks_quad<L2, 1>(row, q_lds, j, blocks, t, s);
+        c = blocks << 2;
+    }
 #endif
     // Whole batches first, with every load of a batch issued before its first use: the sums are one dependent chain, so the
     // loads are the only parallelism there is.  (Batches of 64 and 32 positions for the lone-search kernels were tried: 768-d

@@ -46,8 +46,11 @@
 #ifndef LEI_SG_CAP
 #define LEI_SG_CAP 64 // sub-group evaluation: edges staged per node (more → the node takes a whole wavefront); power of two
 #endif
-// ints per sub-group: table of 2 * LEI_SG_CAP entries (key, count, first position) + counter (4 ints) + 16-bit slot list
-#define LEI_SG_AREA (6 * LEI_SG_CAP + 4 + LEI_SG_CAP / 2)
+// ints per sub-group: table of 1 << log2h entries (key, count, first position) + counter (4 ints) + 16-bit slot list (one per
+// edge at most).  log2h is LEI_SG_LOG2H (two entries per edge) while most labels are still different — the first sweeps of a
+// phase — and one less afterwards (round 4): the table then takes half the LDS and 32 wavefronts fit a CU instead of 20.  Only
+// communities other than the node's own enter it, at most one per edge, so it cannot overflow at either size.
+#define LEI_SG_AREA_OF(log2h) (3 * (1 << (log2h)) + 4 + LEI_SG_CAP / 2)
 #define LEI_WPB 4 // wavefronts per k_leiden_eval workgroup (at most; power of two)
 #define LEI_SG_LOG2H (LEI_SG_CAP == 32 ? 6 : LEI_SG_CAP == 64 ? 7 : LEI_SG_CAP == 128 ? 8 : 9) // table of 2 * LEI_SG_CAP entries
 
@@ -438,6 +441,11 @@ DEVI int best_move_hash(const DevGraph &g, const LeiHead &hd, const int *label, 
                 n_old++;
                 continue;
             }
+            // refinement: a target in another phase-1 community carries a refined label that no candidate of this node can
+            // have (a refined community lies inside one phase-1 community, and candidates need an eligible edge) and that is
+            // not `old` either: it changes no count that is looked at — it does not enter the table
+            if (part[j] != mypart)
+                continue;
             unsigned h = lei_hash(c[j], log2h);
             for (;;) {
                 int prev = tk[h]; // (a plain read first: most edges find their community already inserted)
@@ -454,8 +462,7 @@ DEVI int best_move_hash(const DevGraph &g, const LeiHead &hd, const int *label, 
                 h = (h + 1) & (H - 1);
             }
             atomicAdd(&tc[h], 1);
-            if (part[j] == mypart)
-                atomicMin(&tp[h], e);
+            atomicMin(&tp[h], e);
         }
     }
     __builtin_amdgcn_s_waitcnt(0);
@@ -531,6 +538,7 @@ struct LeiArgs {
     int big_log2h;               // hash table size of a wide node (unweighted): 2^big_log2h >= 2 * lds_cap
     int sync;                    // 1: whole-graph synchronous sweep — every positive-gain mover applies, no tallies (k_leiden_apply_sync)
     int pickless;                // this sweep only allows moves to a community with a smaller id
+    int sg_log2h;                // log2 of a sub-group's table size (unweighted): LEI_SG_LOG2H, or one less once labels have merged
 };
 
 #define LEI_FX 1048576.0
@@ -622,9 +630,10 @@ __global__ void __launch_bounds__(64 * LEI_WPB) k_leiden_eval(LeiArgs a, int nsm
             if (hd.d_out + hd.d_in > LEI_SG_CAP)
                 return;
             old = hd.old;
-            int *tk = reinterpret_cast<int *>(lei_smem) + grp * LEI_SG_AREA; // H = 2 * LEI_SG_CAP entries
-            best = best_move_hash<SG>(a.g, hd, a.label, a.sum_tot, a.m, a.resolution, a.elig_part, tk, tk + 2 * LEI_SG_CAP,
-                                      tk + 4 * LEI_SG_CAP, tk + 6 * LEI_SG_CAP, LEI_SG_LOG2H, lane, sl, &dk, a.pickless);
+            const int H = 1 << a.sg_log2h;
+            int *tk = reinterpret_cast<int *>(lei_smem) + grp * LEI_SG_AREA_OF(a.sg_log2h);
+            best = best_move_hash<SG>(a.g, hd, a.label, a.sum_tot, a.m, a.resolution, a.elig_part, tk, tk + H, tk + 2 * H, tk + 3 * H,
+                                      a.sg_log2h, lane, sl, &dk, a.pickless);
         } else {
             const LeiHead hd = lei_head(a.g, v, a.label, a.kdeg, a.use_both, a.elig_part);
             if (hd.d_out + hd.d_in > LEI_SG_CAP)
@@ -651,8 +660,8 @@ __global__ void __launch_bounds__(64 * LEI_WPB) k_leiden_eval(LeiArgs a, int nsm
         int *tk = reinterpret_cast<int *>(lei_smem);
         const int H = 1 << a.big_log2h;
         const LeiHead hd = lei_head(a.g, v, a.label, a.kdeg, a.use_both, a.elig_part);
-        int lg = 8; // the table is sized to this node (≥ 2 · degree), not to the widest one: less to clear and to scan
-        while ((1 << lg) < 2 * deg)
+        int lg = 8; // the table is sized to this node (≥ its degree: one entry per edge at most), not to the widest one
+        while ((1 << lg) < deg)
             lg++;
         best = best_move_hash<64>(a.g, hd, a.label, a.sum_tot, a.m, a.resolution, a.elig_part, tk, tk + H, tk + 2 * H, tk + 3 * H,
                                   lg, lane, lane, &dk, a.pickless);
@@ -672,9 +681,9 @@ __global__ void __launch_bounds__(64 * LEI_WPB) k_leiden_eval(LeiArgs a, int nsm
 }
 
 // LDS bytes of one k_leiden_eval workgroup
-static size_t lei_eval_lds(int sg, bool hash, int lds_cap, int big_log2h) {
+static size_t lei_eval_lds(int sg, bool hash, int lds_cap, int big_log2h, int sg_log2h) {
     const int ng = 64 / sg;
-    const size_t small = hash ? (size_t)ng * LEI_SG_AREA * sizeof(int) : (size_t)ng * LEI_SG_CAP * 13;
+    const size_t small = hash ? (size_t)ng * LEI_SG_AREA_OF(sg_log2h) * sizeof(int) : (size_t)ng * LEI_SG_CAP * 13;
     // table (3 ints per entry) + occupied-entry list: a counter (16 B) and one 16-bit slot per edge
     const size_t big = hash ? (size_t)3 * ((size_t)1 << big_log2h) * sizeof(int) + 16 + (((size_t)lds_cap * 2 + 15) & ~(size_t)15)
                             : (size_t)lds_cap * 13;
@@ -1337,7 +1346,7 @@ static void lei_grow_setting(int *grow, int *grow_div) {
 // evaluation of the nodes [a.b0, a.b1) (+ the wide nodes a.big0..a.big1 of that range) against the frozen state
 static void lei_launch_eval(const LeiArgs &a, int nb, int sg, bool hashed, hipStream_t st) {
     const int nsmall = (nb + (64 / sg) - 1) / (64 / sg);
-    const unsigned wlds = (unsigned)((lei_eval_lds(sg, hashed, a.lds_cap, a.big_log2h) + 15) & ~(size_t)15);
+    const unsigned wlds = (unsigned)((lei_eval_lds(sg, hashed, a.lds_cap, a.big_log2h, a.sg_log2h) + 15) & ~(size_t)15);
     int wpb = LEI_WPB; // (wide nodes with large tables: fewer wavefronts per workgroup, 64 KB of dynamic LDS at most)
     while (wpb > 1 && (size_t)wlds * wpb > 60 * 1024)
         wpb >>= 1;
@@ -1495,6 +1504,8 @@ static long long run_phase_sync(mn_graph *g, LeiArgs a, int period, int64_t *swe
     while (sweeps < cap && sweeps < a.max_sweeps) {
         sweeps++;
         a.pickless = period > 0 && sweeps % period == 0;
+        // (table size is a matter of speed only: full-size while most neighbours still carry labels of their own)
+        a.sg_log2h = sweeps <= 3 || getenv("MN_LEIDEN_FULL_TABLES") ? LEI_SG_LOG2H : LEI_SG_LOG2H - 1;
         GCHK(hipMemsetAsync(a.out, 0, sizeof(int), st));
         lei_launch_eval(a, N, sg, hashed, st);
         if (!a.apply_on_device) {
@@ -1523,6 +1534,7 @@ static long long run_phase_sync(mn_graph *g, LeiArgs a, int period, int64_t *swe
     if (!converged) {
         a.sync = 0;
         a.pickless = 0;
+        a.sg_log2h = LEI_SG_LOG2H;
         const long long more = run_phase(g, a, MN_LEIDEN_BATCHED, lei_round_default(N), sweeps_out);
         if (more < 0)
             return -1;
@@ -1626,9 +1638,10 @@ extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int
     a.Lq = d.Lq;
     a.apply_on_device = g->weighted ? 0 : 1;
     a.lds_cap = std::min(LEI_CAP, std::max(64, (max_deg + 15) & ~15));
-    a.big_log2h = 7;
-    while ((1 << a.big_log2h) < 2 * a.lds_cap)
+    a.big_log2h = 8; // a wide node's table: one entry per edge at most (only other communities enter it)
+    while ((1 << a.big_log2h) < a.lds_cap)
         a.big_log2h++;
+    a.sg_log2h = LEI_SG_LOG2H;
     a.biglist = d.biglist;
     a.bigoff = d.bigoff;
 

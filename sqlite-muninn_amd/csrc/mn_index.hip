@@ -1086,7 +1086,7 @@ static int run_sequential(mn_index *x, const std::vector<int> &slots) {
     const int n = (int)slots.size();
     if (n == 0)
         return 0;
-    if (mn_insert_seq_lds_bytes(dev_view(x)) > MN_LDS_LIMIT) {
+    if (mn_insert_seq_lds_bytes(dev_view(x)) > mn_lds_optin_limit()) { // (beyond 64 KB the launcher asks the device for the grant)
         set_err("mn_hnsw_insert: dimension %d with neighbour lists of up to %d entries does not fit the insert kernel's LDS", x->dim,
                 std::max(x->W0, x->WU));
         return -1;

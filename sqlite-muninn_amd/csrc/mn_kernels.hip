@@ -331,16 +331,22 @@ size_t mn_search_lds_bytes(int ld, bool tile) {
 // Dynamic LDS beyond 64 KB has to be asked for per kernel (hipFuncAttributeMaxDynamicSharedMemorySize); what the device would
 // grant is asked once.  Anything that fails leaves the 64 KB every kernel gets.
 size_t mn_lds_optin_limit() {
-    static size_t lim = 0;
-    if (lim)
-        return lim;
-    lim = 64 * 1024;
+    // per device ordinal (an index lives on its own device and any host thread may serve it), under a mutex
+    static std::mutex mu;
+    static std::unordered_map<int, size_t> lims;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = lims.find(dev);
+    if (it != lims.end())
+        return it->second;
+    size_t lim = 64 * 1024;
     const char *e = getenv("MN_LDS_OPTIN"); // MN_LDS_OPTIN=0: never ask
-    int dev = 0, v = 0;
-    if (!(e && atoi(e) == 0) && hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&v, hipDeviceAttributeSharedMemPerBlockOptin, dev) == hipSuccess && v > 64 * 1024)
+    int v = 0;
+    if (!(e && atoi(e) == 0) && hipDeviceGetAttribute(&v, hipDeviceAttributeSharedMemPerBlockOptin, dev) == hipSuccess && v > 64 * 1024)
         lim = (size_t)v;
     (void)hipGetLastError();
+    lims[dev] = lim;
     return lim;
 }
 // one request per kernel and size (the call is not free, and these kernels are launched once per query / insert)
@@ -348,18 +354,27 @@ bool mn_lds_grant(const void *kern, size_t bytes) {
     if (bytes <= 64 * 1024)
         return true;
     static std::mutex mu;
-    static std::unordered_map<unsigned long long, size_t> granted; // (kernel, device) -> largest size granted (0: refused)
+    struct Seen {
+        size_t granted = 0;           // largest size granted
+        size_t refused = (size_t)-1;  // smallest size refused: only requests below it are tried again
+    };
+    static std::unordered_map<unsigned long long, Seen> seen; // (kernel, device)
     int dev = 0;
     (void)hipGetDevice(&dev);
     const unsigned long long key = (unsigned long long)reinterpret_cast<uintptr_t>(kern) * 64ull + (unsigned)(dev & 63);
     std::lock_guard<std::mutex> lk(mu);
-    auto it = granted.find(key);
-    if (it != granted.end() && (it->second >= bytes || it->second == 0))
-        return it->second >= bytes;
+    Seen &sn = seen[key];
+    if (sn.granted >= bytes)
+        return true;
+    if (bytes >= sn.refused)
+        return false;
     const bool ok = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
-    if (!ok)
+    if (ok) {
+        sn.granted = bytes;
+    } else {
         (void)hipGetLastError();
-    granted[key] = ok ? bytes : 0;
+        sn.refused = bytes;
+    }
     return ok;
 }
 template <typename K> static bool lds_grant(K kern, size_t bytes) { return mn_lds_grant(reinterpret_cast<const void *>(kern), bytes); }

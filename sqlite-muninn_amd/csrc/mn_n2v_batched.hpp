@@ -127,63 +127,117 @@ DEVI int gen_walk(const N2vArgs &a, int n, unsigned &rng, int *walk, double *cum
     return a.walk_length;
 }
 
-// Samples s0 .. s0+nd-1 of one (centre, context) pair (src/node2vec.c:353-386): draw the targets (the stream is
-// consumed in sample order), fetch all their rows at once, then score them in order.  FULL (nd == PF) is the
-// branch-free path: a rejected negative (== centre or context, :361-363) still has its row fetched, but leaves no
-// sample and no contribution.  The sample slot is written before it is known to be kept; a rejected one is
-// overwritten by the next sample or by the walk's -1 tail fill.
-template <int NR, int PF, bool FULL>
-DEVI void n2v_score_chunk(const N2vArgs &a, const N2vBatchArgs &b, unsigned &rng, int s0, int nd, int center, int context,
-                          const float (&vc)[NR], float (&neu)[NR], float lr, size_t base, int &ns, int lane, const float *sig) {
-    const int dim = a.dim;
+// The samples of a walk are processed as a stream of CHUNKS: (position, context, s0) = samples s0 .. s0+PF-1 of the pair
+// (walk[position], walk[context]) (src/node2vec.c:353-386).  A chunk has two halves.  FETCH draws its targets (the walk's
+// xorshift32 stream is consumed in sample order, and by draws only) and requests their rows — and the centre row when the chunk
+// opens a position.  SCORE takes the dot products in order, writes the samples and folds err·row into the position's neu1e.
+// Round 4: the two halves are software-pipelined — chunk k+1 is fetched BEFORE chunk k is scored, so that the negative-table
+// gather and the row gather of the next pair overlap the butterflies, LUT look-ups and stores of this one (the per-pair chain
+// was draw → table gather → row gather → six reductions → stores, one after the other: 0.48 of the HBM roofline with only
+// 1.08x traffic).  Same operations on the same operands in the same order: same bits.
+struct N2vIt {
+    int pos, c, s0, cs, ce;
+    bool valid;
+};
+DEVI void n2v_it_seek(N2vIt &it, int pe, int wlen, int window) { // first chunk at or after position it.pos
+    for (; it.pos < pe; it.pos++) {
+        it.cs = it.pos - window < 0 ? 0 : it.pos - window;
+        it.ce = it.pos + window >= wlen ? wlen - 1 : it.pos + window;
+        it.c = it.cs == it.pos ? it.cs + 1 : it.cs;
+        if (it.c <= it.ce) {
+            it.s0 = 0;
+            it.valid = true;
+            return;
+        }
+    }
+    it.valid = false;
+}
+template <int PF> DEVI void n2v_it_next(N2vIt &it, int neg, int pe, int wlen, int window) {
+    it.s0 += PF;
+    if (it.s0 <= neg)
+        return;
+    it.s0 = 0;
+    it.c++;
+    if (it.c == it.pos)
+        it.c++;
+    if (it.c <= it.ce)
+        return;
+    it.pos++;
+    n2v_it_seek(it, pe, wlen, window);
+}
+template <int NR, int PF> struct N2vChunkBuf {
     int tg[PF];
     bool ok[PF];
+    float tr[PF][NR];
+    float vc[NR]; // the centre row, when the chunk opens its position
+};
+
+template <int NR, int PF>
+DEVI void n2v_chunk_fetch(const N2vArgs &a, unsigned &rng, const N2vIt &it, const int *walk, N2vChunkBuf<NR, PF> &f, int lane) {
+    const int dim = a.dim;
+    const int center = walk[it.pos], context = walk[it.c];
+    const int nd = a.neg + 1 - it.s0 < PF ? a.neg + 1 - it.s0 : PF;
 #pragma unroll
     for (int i = 0; i < PF; i++) {
-        tg[i] = context;
-        ok[i] = false;
-        if (FULL || i < nd) {
-            if (i == 0 && s0 == 0) {
-                ok[i] = true; // the positive sample
+        f.tg[i] = context;
+        f.ok[i] = false;
+        if (i < nd) {
+            if (i == 0 && it.s0 == 0) {
+                f.ok[i] = true; // the positive sample
             } else {
-                tg[i] = a.neg_table[xs32(rng) % N2V_NEG_TABLE];
-                ok[i] = tg[i] != center && tg[i] != context;
+                f.tg[i] = a.neg_table[xs32(rng) % N2V_NEG_TABLE];
+                f.ok[i] = f.tg[i] != center && f.tg[i] != context; // :361-363 (the draw is consumed either way)
             }
         }
     }
-    float tr[PF][NR];
 #pragma unroll
-    for (int i = 0; i < PF; i++)
-        if (FULL || i < nd) {
-            const float *rowt = a.syn1neg + (size_t)tg[i] * dim;
+    for (int i = 0; i < PF; i++) { // (a slot past nd re-reads the context row: branch-free, contributes nothing)
+        const float *rowt = a.syn1neg + (size_t)f.tg[i] * dim;
 #pragma unroll
-            for (int r = 0; r < NR; r++) {
-                int d = lane + 64 * r;
-                tr[i][r] = d < dim ? rowt[d] : 0.0f;
-            }
+        for (int r = 0; r < NR; r++) {
+            const int d = lane + 64 * r;
+            f.tr[i][r] = d < dim ? rowt[d] : 0.0f;
         }
+    }
+    const bool opens = it.s0 == 0 && it.c == (it.cs == it.pos ? it.cs + 1 : it.cs);
+    if (opens) {
+        const float *rowc = a.syn0 + (size_t)center * dim;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int d = lane + 64 * r;
+            f.vc[r] = d < dim ? rowc[d] : 0.0f;
+        }
+    }
+}
+
+template <int NR, int PF>
+DEVI void n2v_chunk_score(const N2vArgs &a, const N2vBatchArgs &b, const N2vIt &it, const int *walk, const N2vChunkBuf<NR, PF> &f,
+                          const float (&vc)[NR], float (&neu)[NR], float lr, size_t base, int &ns, int lane, const float *sig) {
+    const int dim = a.dim;
+    const int center = walk[it.pos];
+    const int nd = a.neg + 1 - it.s0 < PF ? a.neg + 1 - it.s0 : PF;
 #pragma unroll
     for (int i = 0; i < PF; i++)
-        if (FULL || i < nd) {
+        if (i < nd) {
             float acc = 0.0f;
 #pragma unroll
             for (int r = 0; r < NR; r++)
                 if (lane + 64 * r < dim)
-                    acc = fmaf(vc[r], tr[i][r], acc);
+                    acc = fmaf(vc[r], f.tr[i][r], acc);
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1)
                 acc = __fadd_rn(acc, __shfl_xor(acc, m));
-            const float label = (i == 0 && s0 == 0) ? 1.0f : 0.0f;
+            const float label = (i == 0 && it.s0 == 0) ? 1.0f : 0.0f;
             const float err = __fmul_rn(__fsub_rn(label, fast_sigmoid(sig, acc)), lr);
-            if (lane == 0) {
+            if (lane == 0) { // (written before it is known to be kept: a rejected one is overwritten by the next sample or the tail fill)
                 b.s_center[base + ns] = center;
-                b.s_target[base + ns] = tg[i];
+                b.s_target[base + ns] = f.tg[i];
                 b.s_err[base + ns] = err;
             }
-            ns += ok[i] ? 1 : 0;
+            ns += f.ok[i] ? 1 : 0;
 #pragma unroll
             for (int r = 0; r < NR; r++)
-                neu[r] = ok[i] ? fmaf(err, tr[i][r], neu[r]) : neu[r];
+                neu[r] = f.ok[i] ? fmaf(err, f.tr[i][r], neu[r]) : neu[r];
         }
 }
 
@@ -243,45 +297,66 @@ __global__ void __launch_bounds__(64) k_n2v_walk_grad(N2vBatchArgs b) {
 #endif
     int ns = pairs_p0 * (1 + a.neg);
     unsigned long long pairs = 0;
-    for (int pos = p0; pos < pe; pos++) {
-        const int center = walk[pos];
-        int cs = pos - a.window, ce = pos + a.window;
-        if (cs < 0)
-            cs = 0;
-        if (ce >= wlen)
-            ce = wlen - 1;
-        float vc[NR], neu[NR];
-        const float *rowc = a.syn0 + (size_t)center * dim;
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-            int d = lane + 64 * r;
-            vc[r] = d < dim ? rowc[d] : 0.0f;
-            neu[r] = 0.0f;
-        }
-        for (int c = cs; c <= ce; c++) {
-            if (c == pos)
-                continue;
-            const int context = walk[c];
-            pairs++;
-            for (int s0 = 0; s0 <= a.neg; s0 += PF) {
-                const int nd = a.neg + 1 - s0 < PF ? a.neg + 1 - s0 : PF;
-                if (nd == PF)
-                    n2v_score_chunk<NR, PF, true>(a, b, rng, s0, nd, center, context, vc, neu, lr, base, ns, lane, sig_l);
-                else
-                    n2v_score_chunk<NR, PF, false>(a, b, rng, s0, nd, center, context, vc, neu, lr, base, ns, lane, sig_l);
-            }
-        }
+    float vc[NR], neu[NR];
+    int live = -1; // the position whose neu1e is being accumulated
+    auto close_position = [&]() {
+        if (live < 0)
+            return;
         if (lane == 0)
-            b.p_center[pbase + pos] = center;
+            b.p_center[pbase + live] = walk[live];
 #ifndef MN_N2V_NO_PNEU // timing experiments only
-        float *pn = b.p_neu + (pbase + pos) * dim;
+        float *pn = b.p_neu + (pbase + live) * dim;
 #pragma unroll
         for (int r = 0; r < NR; r++) {
-            int d = lane + 64 * r;
+            const int d = lane + 64 * r;
             if (d < dim)
                 pn[d] = neu[r];
         }
 #endif
+    };
+    if (wlen < 2) { // a start node without neighbours: its one position has no context, an all-zero neu1e
+        for (int pos = p0; pos < pe; pos++) {
+#pragma unroll
+            for (int r = 0; r < NR; r++)
+                neu[r] = 0.0f;
+            live = pos;
+            close_position();
+        }
+        live = -1;
+    } else {
+        N2vChunkBuf<NR, PF> bufA, bufB;
+        N2vIt cur;
+        cur.pos = p0;
+        n2v_it_seek(cur, pe, wlen, a.window);
+        if (cur.valid)
+            n2v_chunk_fetch<NR, PF>(a, rng, cur, walk, bufA, lane);
+        // one step: fetch the chunk after `cur` into N, then score `cur` out of C
+        auto step = [&](N2vChunkBuf<NR, PF> &C, N2vChunkBuf<NR, PF> &N) {
+            N2vIt nxt = cur;
+            n2v_it_next<PF>(nxt, a.neg, pe, wlen, a.window);
+            if (nxt.valid)
+                n2v_chunk_fetch<NR, PF>(a, rng, nxt, walk, N, lane);
+            if (cur.pos != live) { // this chunk opens its position: the centre row came with it
+                close_position();
+                live = cur.pos;
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    vc[r] = C.vc[r];
+                    neu[r] = 0.0f;
+                }
+            }
+            if (cur.s0 == 0)
+                pairs++;
+            n2v_chunk_score<NR, PF>(a, b, cur, walk, C, vc, neu, lr, base, ns, lane, sig_l);
+            cur = nxt;
+        };
+        while (cur.valid) {
+            step(bufA, bufB);
+            if (!cur.valid)
+                break;
+            step(bufB, bufA);
+        }
+        close_position();
     }
     for (int i = ns + lane; i < slot_end; i += 64) {
         b.s_center[base + i] = -1;

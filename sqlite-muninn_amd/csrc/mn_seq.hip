@@ -454,6 +454,8 @@ void mn_launch_insert_seq(const MnDevIndex &ix, const int *d_slots, int n, int e
                     a.pre_rows = a.pre_w = a.wave_floats = 0;                                                                \
                     lds = lds0;                                                                                              \
                 }                                                                                                            \
+                if (lds > 64 * 1024)                                                                                         \
+                    (void)mn_lds_grant(kp, lds); /* the kernel's own arrays alone pass 64 KB: refused = the launch fails */  \
             }                                                                                                                \
         }                                                                                                                    \
         if (ix.WX > 64)                                                                                                      \

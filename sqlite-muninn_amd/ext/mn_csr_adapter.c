@@ -46,6 +46,8 @@ int csr_apply_delta(const CsrArray *old_csr, const CsrDelta *deltas, int delta_c
                            old_csr->weights, old_csr->has_weights, (const mn_csr_delta *)deltas, delta_count, new_node_count,
                            mn_env_device(), offsets, &targets, old_csr->has_weights ? &weights : NULL, &n_edges) != 0) {
         free(offsets);
+        mn_host_free(targets); /* (the merge may have handed these out before it failed) */
+        mn_host_free(weights);
         return -1; /* as the reference on allocation failure (:311-324); the caller rolls its savepoint back */
     }
     new_csr->node_count = new_node_count;

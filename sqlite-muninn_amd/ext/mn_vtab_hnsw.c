@@ -1255,6 +1255,19 @@ static sqlite3_module batch_module = {
  * once from one bulk copy.  Same rows, same rowids (first-seen index + 1), same "{t}_nodes" / "{t}_edges" as the generic INSERT
  * path in this mode (MUNINN_N2V_DIRECT=0 forces that path; the tests compare the two).
  * Returns 1: done, *inserted rows; 0: not applicable, the caller INSERTs as usual; -1: error, *err (sqlite3_mprintf). */
+/* A failed direct fill may have left some batches of nodes in HBM with no shadow rows behind them; the index was verified
+ * empty on entry, so it is simply replaced by a fresh one — a retry (or plain INSERTs) then start from the empty table the
+ * shadow tables describe.  If even that fails the old handle stays and says what it holds. */
+static void n2v_fill_undo(VtabHnsw *v) {
+    if (mn_hnsw_node_count(v->index) == 0)
+        return;
+    mn_index *fresh = mn_hnsw_create_on(v->dim, v->metric, v->m, v->efc, mn_hnsw_device(v->index));
+    if (!fresh)
+        return;
+    mn_hnsw_destroy(v->index);
+    v->index = fresh;
+}
+
 int mn_vtab_hnsw_fill_from_n2v(sqlite3 *db, const char *table, int n, const int *off, const int *adj, const mn_n2v_params *prm,
                                int *inserted, char **err) {
     const char *e = getenv("MUNINN_N2V_DIRECT");
@@ -1279,6 +1292,7 @@ int mn_vtab_hnsw_fill_from_n2v(sqlite3 *db, const char *table, int n, const int 
     if (mn_node2vec_train_into(n, off, adj, prm, MN_N2V_BATCHED, v->index, 1, emb, 0, 0) < 0) {
         free(emb);
         *err = sqlite3_mprintf("node2vec_train: %s", mn_node2vec_last_error());
+        n2v_fill_undo(v);
         return -1;
     }
     rc = SQLITE_OK;
@@ -1290,6 +1304,7 @@ int mn_vtab_hnsw_fill_from_n2v(sqlite3 *db, const char *table, int n, const int 
     pend_clear(v);
     if (rc != SQLITE_OK) {
         *err = sqlite3_mprintf("node2vec_train: writing the shadow tables of \"%s\" failed", table);
+        n2v_fill_undo(v);
         return -1;
     }
     *inserted = n;

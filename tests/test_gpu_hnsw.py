@@ -782,3 +782,31 @@ def test_latency_kernel_fallbacks_give_the_same_graph_and_answers(gpu, knob):
     env[knob] = "0"
     r = subprocess.run([sys.executable, "-c", _KNOB_SCRIPT], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-1500:]
+
+
+@pytest.mark.parametrize("metric,M,dup", [("l2", 16, False), ("cosine", 8, True), ("inner_product", 16, False), ("l2", 40, True)])
+def test_batched_link_step_with_hub_targets_equals_the_oracle(gpu, orc, metric, M, dup):
+    """One batch whose thousands of nodes all link back to a few dozen existing nodes: every existing node is a hub that
+    receives hundreds to thousands of reverse edges in ONE link step.  k_link_reverse scores such a target's sources 64 at a
+    time and keeps the M_max nearest (round 4) instead of replaying thousands of prunes; the oracle replays them one by one
+    (src/hnsw_algo.c:583-653).  Same rows, bit for bit — also when duplicate vectors tie (those targets go back to the
+    reference's steps), on upper layers, and with the batch index order scrambled by the hash of the bins."""
+    dim, n0, nb = 12, 70, 3000
+    X = gauss(n0 + nb, dim, 77)
+    if dup:
+        X[n0 + 5:n0 + nb:37] = X[n0 + 5]      # many copies of one batch vector: equal distances to every target
+        X[n0 + 9:n0 + nb:101] = X[3]          # and copies of an existing node
+    ids = np.arange(1, n0 + nb + 1, dtype=np.int64)
+    o = orc.Oracle(dim, metric, M, 60)
+    g = gpu.HnswIndex(dim, metric, M, 60)
+    for lo, hi in ((0, 1), (1, 8), (8, n0), (n0, n0 + nb)):
+        assert o.insert_batch(ids[lo:hi], X[lo:hi]) == 0
+        assert g.insert_batch(ids[lo:hi], X[lo:hi], gpu.BUILD_BATCHED) == 0
+    assert g.graph(ids) == o.graph(ids)
+    # and a second large batch on top of the grown graph (rows are full now: every append overflows)
+    X2 = gauss(2500, dim, 78)
+    ids2 = np.arange(10_001, 12_501, dtype=np.int64)
+    assert o.insert_batch(ids2, X2) == 0
+    assert g.insert_batch(ids2, X2, gpu.BUILD_BATCHED) == 0
+    assert g.graph(np.concatenate([ids, ids2])) == o.graph(np.concatenate([ids, ids2]))
+    g.close()
