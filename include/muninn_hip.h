@@ -413,6 +413,13 @@ int mn_hnsw_search_sharded(mn_index *idx, mn_comm *c, const float *queries, int6
  * one GPU.  stats->pairs is this rank's share.  Returns n / -1. */
 int mn_node2vec_train_shared(mn_comm *c, int n_nodes, const int *off, const int *adj, const mn_n2v_params *prm, int device,
                              float *out, mn_n2v_stats *stats);
+/* run_leiden (src/graph_community.c:336-429) on the ranks' GPUs — north_star: the per-node local-move sweep "partitioned
+ * across the GPUs ... modularity partials".  Every rank holds the whole graph (g on its own device) and the whole state; the
+ * evaluation of every synchronous sweep is divided by node range, the decisions (N int32 per sweep) are all-gathered and every
+ * replica applies all of them; compute_modularity's per-node terms (:131) are divided and all-gathered the same way.  Every
+ * rank returns what mn_graph_leiden(g, .., MN_LEIDEN_BATCHED, batch, ..) returns on one GPU, bit for bit.  0 / -1. */
+int mn_graph_leiden_shared(mn_graph *g, mn_comm *c, double resolution, int use_both, int batch, int *community_out,
+                           double *modularity_out);
 
 /* ---- the same sharded index (BASELINE config 3) inside ONE process: a C host that owns several GPUs ----
  * rowid mod n -> shard; every shard is an ordinary mn_index on its own GPU (mn_shards_index gives access for persistence:

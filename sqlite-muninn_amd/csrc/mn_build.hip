@@ -109,12 +109,22 @@ DEVI int next_source(const unsigned *bm, int words, int after, int lane) { // sm
 //   * equal (or unordered) distances are where the mutual-neighbour count and the selection sort's mechanics decide
 //     (:613-639): such a step runs the reference's procedure verbatim (prune_ties) on the M_max + 1 candidates, and keeps
 //     doing so while equal distances remain in the row.
+#ifdef MN_LINK_DEBUG // diagnostics of the link step (scripts/probe builds only): where a straggler's time goes
+static __device__ unsigned long long mn_link_dbg[16];
+#define LD_ADD(k, v) (dbg[k] += (v))
+#else
+#define LD_ADD(k, v)
+#endif
 template <int ORDER, int NCH>
 __global__ void __launch_bounds__(64) k_link_reverse(MnDevIndex ix, MnLinkArgs a, int LW, int bm_words) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
     if ((int)blockIdx.x >= a.counters[1])
         return;
+#ifdef MN_LINK_DEBUG
+    unsigned long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#endif
     const int t = a.touched[blockIdx.x];
     const int W = a.level == 0 ? ix.W0 : ix.WU;
     const int M_max = a.M_max;
@@ -177,9 +187,12 @@ __global__ void __launch_bounds__(64) k_link_reverse(MnDevIndex ix, MnLinkArgs a
             bool present = false;
             for (int x0 = 0; x0 < nc; x0 += 64)
                 present |= __ballot(x0 + lane < nc && list[x0 + lane] == s) != 0;
-            if (present)
+            if (present) {
+                LD_ADD(0, 1);
                 continue;
+            }
             if (nc < M_max) { // room left: appended, nothing pruned
+                LD_ADD(1, 1);
                 __builtin_amdgcn_wave_barrier();
                 if (lane == 0) {
                     list[nc] = s;
@@ -203,8 +216,10 @@ __global__ void __launch_bounds__(64) k_link_reverse(MnDevIndex ix, MnLinkArgs a
                 have_nd = true;
             }
             if (clean && M_max <= 64 && ds == ds) {
-                if (ds > worst)
+                if (ds > worst) {
+                    LD_ADD(2, 1);
                     continue; // strictly the farthest of the M_max + 1 candidates: the prune drops it, the row stays as it is
+                }
                 const float di = lane < M_max ? nd[lane] : 3.0e38f;
                 const unsigned long long lt = __ballot(lane < M_max && di < ds), eq = __ballot(lane < M_max && di == ds);
                 if (!eq) { // lands between its neighbours in distance; the last entry falls off
@@ -221,6 +236,7 @@ __global__ void __launch_bounds__(64) k_link_reverse(MnDevIndex ix, MnLinkArgs a
                     }
                     __builtin_amdgcn_wave_barrier();
                     worst = nd[M_max - 1];
+                    LD_ADD(3, 1);
                     continue;
                 }
             }
@@ -258,7 +274,9 @@ __global__ void __launch_bounds__(64) k_link_reverse(MnDevIndex ix, MnLinkArgs a
                     }
                 __builtin_amdgcn_wave_barrier();
                 clean = true;
+                LD_ADD(4, 1);
             } else { // equal or unordered distances: mutual-neighbour counts and the reference's selection sort, verbatim
+                LD_ADD(5, 1);
                 __builtin_amdgcn_wave_barrier();
                 prune_ties<false>(ix, list, nd, mn, nc, M_max, a.level, lane);
                 bool dirty = false; // do equal / unordered distances remain among the kept entries?
@@ -274,7 +292,33 @@ __global__ void __launch_bounds__(64) k_link_reverse(MnDevIndex ix, MnLinkArgs a
     int *out = a.newrows + (size_t)blockIdx.x * ix.WX;
     for (int i = lane; i < W; i += 64)
         out[i] = i < nc ? list[i] : -1;
+#ifdef MN_LINK_DEBUG
+    if (lane == 0) {
+        const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t_start;
+        for (int k = 0; k < 6; k++)
+            atomicAdd(&mn_link_dbg[k], dbg[k]);
+        atomicAdd(&mn_link_dbg[6], 1ull);                          // targets
+        atomicAdd(&mn_link_dbg[7], (unsigned long long)nb);        // sources
+        atomicMax(&mn_link_dbg[8], (unsigned long long)nb);        // most sources of one target
+        atomicMax(&mn_link_dbg[9], dt);                            // slowest target (100 MHz ticks)
+        atomicAdd(&mn_link_dbg[10], dt);
+        if (nb > 1000)
+            atomicAdd(&mn_link_dbg[11], 1ull);
+    }
+#endif
 }
+
+#ifdef MN_LINK_DEBUG
+extern "C" int mn_debug_link_stats(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mn_link_dbg), 16 * sizeof(unsigned long long)) != hipSuccess)
+        return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(mn_link_dbg), z, sizeof(z));
+    }
+    return 0;
+}
+#endif
 
 __global__ void k_link_commit(MnDevIndex ix, MnLinkArgs a) {
     int i = blockIdx.x;

@@ -3,6 +3,7 @@
 #include "mn_comm.hpp"
 #include "mn_guard.hpp"
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -30,6 +31,10 @@ struct Rccl {
     int (*GetUniqueId)(RcclUniqueId *) = nullptr;
     int (*CommInitRank)(void **, int, RcclUniqueId, int) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
     int (*CommDestroy)(void *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
@@ -54,6 +59,10 @@ bool rccl_load() {
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
         r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(h, "ncclAllGather"));
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+        r.Send = reinterpret_cast<decltype(r.Send)>(dlsym(h, "ncclSend")); // (point-to-point: only the all-to-all needs them)
+        r.Recv = reinterpret_cast<decltype(r.Recv)>(dlsym(h, "ncclRecv"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(h, "ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
         if (r.GetUniqueId && r.CommInitRank && r.AllGather && r.CommDestroy && r.GetErrorString)
             g_rccl = r;
@@ -130,6 +139,10 @@ extern "C" void mn_comm_destroy(mn_comm *c) {
         (void)hipSetDevice(c->device);
         (void)hipFree(c->d_status);
     }
+    if (c->d_a2a) {
+        (void)hipSetDevice(c->device);
+        (void)hipFree(c->d_a2a);
+    }
     if (c->nccl && g_rccl.lib) {
         (void)hipSetDevice(c->device);
         (void)g_rccl.CommDestroy(c->nccl);
@@ -170,6 +183,90 @@ int mn_comm_allgather_dev(mn_comm *c, const void *d_send, void *d_recv, size_t b
         hipStreamSynchronize(st) != hipSuccess) {
         cset_err("mn_comm: staging from the host failed");
         return -1;
+    }
+    return 0;
+}
+
+int mn_comm_alltoallv_dev(mn_comm *c, const void *d_send, void *d_recv, const long long *cnt, size_t elem, hipStream_t st) {
+    const int W = c ? c->world : 1, me = c ? c->rank : 0;
+    const unsigned char *snd = static_cast<const unsigned char *>(d_send);
+    unsigned char *rcv = static_cast<unsigned char *>(d_recv);
+    // this rank's bucket for itself never leaves the device
+    size_t soff = 0, roff = 0;
+    for (int p = 0; p < me; p++)
+        soff += (size_t)cnt[(size_t)me * W + p];
+    for (int s = 0; s < me; s++)
+        roff += (size_t)cnt[(size_t)s * W + me];
+    const size_t self = (size_t)cnt[(size_t)me * W + me];
+    if (self && hipMemcpyAsync(rcv + roff * elem, snd + soff * elem, self * elem, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        cset_err("mn_comm: device copy failed");
+        return -1;
+    }
+    if (W == 1)
+        return 0;
+    if (c->nccl) {
+        if (!g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd) {
+            cset_err("mn_comm: this librccl has no ncclSend / ncclRecv");
+            return -1;
+        }
+        int rc = g_rccl.GroupStart();
+        size_t so = 0, ro = 0;
+        for (int p = 0; p < W && rc == 0; p++) {
+            const size_t ns = (size_t)cnt[(size_t)me * W + p], nr = (size_t)cnt[(size_t)p * W + me];
+            if (p != me && ns)
+                rc = g_rccl.Send(snd + so * elem, ns * elem, /* ncclChar */ 0, p, c->nccl, st);
+            if (p != me && nr && rc == 0)
+                rc = g_rccl.Recv(rcv + ro * elem, nr * elem, 0, p, c->nccl, st);
+            so += ns;
+            ro += nr;
+        }
+        const int rc2 = g_rccl.GroupEnd();
+        if (rc != 0 || rc2 != 0) {
+            cset_err("mn_comm all-to-all (ncclSend / ncclRecv): %s", g_rccl.GetErrorString(rc ? rc : rc2));
+            return -1;
+        }
+        return 0;
+    }
+    // host transport: every rank's whole send buffer, padded to the longest, goes through the all-gather; the pieces meant for
+    // this rank are copied out (a rehearsal path: it moves world times the bytes the RCCL path moves)
+    size_t longest = 0, mine = 0;
+    for (int s = 0; s < W; s++) {
+        size_t tot = 0;
+        for (int p = 0; p < W; p++)
+            tot += (size_t)cnt[(size_t)s * W + p];
+        longest = std::max(longest, tot);
+        if (s == me)
+            mine = tot;
+    }
+    if (longest == 0)
+        return 0;
+    const size_t slot = longest * elem;
+    if (c->a2a_bytes < slot * (size_t)(W + 1)) {
+        if (c->d_a2a)
+            (void)hipFree(c->d_a2a);
+        c->d_a2a = nullptr;
+        c->a2a_bytes = 0;
+        if (hipMalloc(&c->d_a2a, slot * (size_t)(W + 1)) != hipSuccess) {
+            cset_err("mn_comm: all-to-all staging allocation failed");
+            return -1;
+        }
+        c->a2a_bytes = slot * (size_t)(W + 1);
+    }
+    unsigned char *all = static_cast<unsigned char *>(c->d_a2a), *pad = all + slot * (size_t)W;
+    if ((mine && hipMemcpyAsync(pad, snd, mine * elem, hipMemcpyDeviceToDevice, st) != hipSuccess) ||
+        mn_comm_allgather_dev(c, pad, all, slot, st))
+        return -1;
+    size_t ro = 0;
+    for (int s = 0; s < W; s++) {
+        size_t so = 0;
+        for (int p = 0; p < me; p++)
+            so += (size_t)cnt[(size_t)s * W + p];
+        const size_t n = (size_t)cnt[(size_t)s * W + me];
+        if (s != me && n && hipMemcpyAsync(rcv + ro * elem, all + slot * (size_t)s + so * elem, n * elem, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            cset_err("mn_comm: device copy failed");
+            return -1;
+        }
+        ro += n;
     }
     return 0;
 }

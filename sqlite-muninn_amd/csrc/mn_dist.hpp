@@ -89,8 +89,9 @@ DEVI void sse_chunks(const float *__restrict__ row, const float *q_lds, int j, i
 }
 
 #ifndef MN_SSE_QUAD2
-#define MN_SSE_QUAD2 8 // float4 loads in flight per lane (0: the dword walk).  Same-box A/B, 1M x 768, ef 128, 10k queries
-                       // (scripts/ab_search2.sh): dword walk 28.85 ms, 4 in flight 27.83 ms, 8 in flight 27.43 ms per launch
+#define MN_SSE_QUAD2 12 // float4 loads in flight per lane (0: the dword walk).  Same box, 1M x 768, ef 128, 10k queries per launch,
+                        // three interleaved trials of each library (scripts/r04_call6.sh): 8 in flight 27.46 / 27.53 / 27.42 ms,
+                        // 12 in flight 25.80 / 25.82 / 25.88 ms, 16 in flight 27.41 / 27.64 ms; the dword walk 27.8 - 29.9 ms
 #endif
 // MN_SSE_QUAD2 (round 4): the SSE-order walk with 16-byte loads.  Quad lane q of a row fetches the float4 of chain position
 // 4t + q — the quad reads 64 contiguous bytes of the row with ONE load instruction where the dword walk needs four, and a
@@ -210,6 +211,12 @@ DEVI float sse_row(const float *__restrict__ row, const float *q_lds, int dim, i
         const int blocks = steps >> 2;
         int t = 0;
         sse_blocks_quad<L2, (MN_SSE_QUAD2 > 0 ? MN_SSE_QUAD2 : 1)>(row, q_lds, j, blocks, t, s);
+        if (MN_SSE_QUAD2 > 8) // (short rows — 128 floats are 8 blocks — and remainders still get their loads in flight together)
+            sse_blocks_quad<L2, 8>(row, q_lds, j, blocks, t, s);
+        if (MN_SSE_QUAD2 > 4)
+            sse_blocks_quad<L2, 4>(row, q_lds, j, blocks, t, s);
+        if (MN_SSE_QUAD2 > 2)
+            sse_blocks_quad<L2, 2>(row, q_lds, j, blocks, t, s);
         sse_blocks_quad<L2, 1>(row, q_lds, j, blocks, t, s);
         c = blocks << 2;
     }

@@ -29,6 +29,7 @@
 // All device buffers are allocated once per graph (LeiWork) and reused by later calls.
 #include "../../include/muninn_hip.h"
 #include "mn_guard.hpp"
+#include "mn_comm.hpp"
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -864,9 +865,9 @@ __global__ void k_wdeg(DevGraph g, int use_both, double *kdeg) {
     kdeg[v] = k;
 }
 
-__global__ void k_w2c_self(DevGraph g, int use_both, const int *label, double *out) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= g.n)
+__global__ void k_w2c_self(DevGraph g, int use_both, const int *label, double *out, int v0, int v1) {
+    const int v = v0 + blockIdx.x * blockDim.x + threadIdx.x; // nodes [v0, v1): one rank's share of the modularity's per-node terms
+    if (v >= v1)
         return;
     const int c = label[v];
     double s = 0.0;
@@ -1177,7 +1178,7 @@ static int lei_prepare(mn_graph *g, int mode, int batch, int use_both, int max_d
     hipStream_t st = g->stream;
     if (w.n != N) {
         if (wmalloc(&w.label, (size_t)N) || wmalloc(&w.refined, (size_t)N) || wmalloc(&w.sum_tot, (size_t)N) ||
-            wmalloc(&w.kdeg, (size_t)N) || wmalloc(&w.tmp, (size_t)N) || wmalloc(&w.out, 16) || wmalloc(&w.cmin, (size_t)N) ||
+            wmalloc(&w.kdeg, (size_t)N) || wmalloc(&w.tmp, (size_t)N + 64) || wmalloc(&w.out, 16) || wmalloc(&w.cmin, (size_t)N) ||
             wmalloc(&w.Jq, (size_t)N) || wmalloc(&w.Lq, (size_t)N) || wmalloc(&w.first, (size_t)N) || wmalloc(&w.flag, (size_t)N) ||
             wmalloc(&w.rank, (size_t)N) || wmalloc(&w.counts, 8) || wmalloc(&w.scal, 8) || wmalloc(&w.s_in, (size_t)N))
             return -1;
@@ -1222,7 +1223,7 @@ static int lei_prepare(mn_graph *g, int mode, int batch, int use_both, int max_d
         w.big_mode = use_both;
     }
     if (mode == MN_LEIDEN_BATCHED && batch > w.batch_cap) {
-        if (wmalloc(&w.dec, (size_t)batch) || wmalloc(&w.dk, (size_t)batch) || wmalloc(&w.win, (size_t)batch) || wmalloc(&w.mv, (size_t)batch))
+        if (wmalloc(&w.dec, (size_t)batch + 64) || wmalloc(&w.dk, (size_t)batch) || wmalloc(&w.win, (size_t)batch) || wmalloc(&w.mv, (size_t)batch))
             return -1;
         w.batch_cap = batch;
     }
@@ -1483,7 +1484,7 @@ static long long run_phase(mn_graph *g, LeiArgs a, int mode, int batch, int64_t 
 #define LEI_PICKLESS 3
 #define LEI_SYNC_CAP 48
 static int lei_round_default(int N) { return (int)std::min<long long>(16384, std::max<long long>(256, N / 32)); }
-static long long run_phase_sync(mn_graph *g, LeiArgs a, int period, int64_t *sweeps_out) {
+static long long run_phase_sync(mn_graph *g, mn_comm *c, LeiArgs a, int period, int64_t *sweeps_out) {
     hipStream_t st = g->stream;
     LeiWork &w = *g->work;
     const int N = g->n, nbN = (N + 255) / 256;
@@ -1492,11 +1493,16 @@ static long long run_phase_sync(mn_graph *g, LeiArgs a, int period, int64_t *swe
     int cap = LEI_SYNC_CAP;
     if (const char *e = getenv("MN_LEIDEN_SYNC_CAP")) // tuning knob (the oracle reads ORC_LEI_SYNC_CAP the same way)
         cap = atoi(e);
+    // Several GPUs (mn_graph_leiden_shared): every rank holds the graph and the whole state; the evaluation — four fifths of a
+    // sweep — is divided by node range, the decisions are all-gathered (N ints per sweep) and every replica applies ALL of them,
+    // so every rank walks through the same states as one GPU does and ends with its bits.
+    const int world = c ? c->world : 1, rank = c ? c->rank : 0;
+    const int per = (N + world - 1) / world;
+    const int v0 = std::min(N, rank * per), v1 = std::min(N, v0 + per);
+    const int bg0 = (int)(std::lower_bound(w.h_big.begin(), w.h_big.end(), v0) - w.h_big.begin());
+    const int bg1 = (int)(std::lower_bound(w.h_big.begin(), w.h_big.end(), v1) - w.h_big.begin());
+    int *const dec_all = a.dec;
     a.sync = 1;
-    a.b0 = 0;
-    a.b1 = N;
-    a.big0 = 0;
-    a.big1 = (int)w.h_big.size();
     a.parity = 0;
     long long total = 0;
     int sweeps = 0;
@@ -1507,7 +1513,31 @@ static long long run_phase_sync(mn_graph *g, LeiArgs a, int period, int64_t *swe
         // (table size is a matter of speed only: full-size while most neighbours still carry labels of their own)
         a.sg_log2h = sweeps <= 3 || getenv("MN_LEIDEN_FULL_TABLES") ? LEI_SG_LOG2H : LEI_SG_LOG2H - 1;
         GCHK(hipMemsetAsync(a.out, 0, sizeof(int), st));
-        lei_launch_eval(a, N, sg, hashed, st);
+        a.b0 = v0;
+        a.b1 = v1;
+        a.big0 = bg0;
+        a.big1 = bg1;
+        a.dec = dec_all + v0; // (the evaluation stores decision v at dec[v - b0])
+        if (v1 > v0)
+            lei_launch_eval(a, v1 - v0, sg, hashed, st);
+        if (world > 1) {
+            int failed = -1;
+            const int ag = mn_comm_agree(c, hipGetLastError() != hipSuccess ? 1 : 0, st, &failed);
+            if (ag != 0) {
+                if (ag < 0)
+                    gset_err("mn_graph_leiden_shared: %s", mn_comm_last_error_str());
+                else
+                    gset_err("mn_graph_leiden_shared: rank %d failed; all ranks stop", failed);
+                return -1;
+            }
+            if (mn_comm_allgather_dev(c, dec_all + (size_t)rank * per, dec_all, (size_t)per * sizeof(int), st)) {
+                gset_err("mn_graph_leiden_shared: %s", mn_comm_last_error_str());
+                return -1;
+            }
+        }
+        a.b0 = 0;
+        a.b1 = N;
+        a.dec = dec_all;
         if (!a.apply_on_device) {
             const int n_ops = 2 * N;
             hipLaunchKernelGGL(k_leiden_ops, dim3(nbN), dim3(256), 0, st, a, N, w.okeys);
@@ -1530,6 +1560,11 @@ static long long run_phase_sync(mn_graph *g, LeiArgs a, int period, int64_t *swe
             break;
         }
     }
+    a.b0 = 0;
+    a.b1 = N;
+    a.big0 = 0;
+    a.big1 = (int)w.h_big.size();
+    a.dec = dec_all;
     *sweeps_out += sweeps;
     if (!converged) {
         a.sync = 0;
@@ -1543,8 +1578,25 @@ static long long run_phase_sync(mn_graph *g, LeiArgs a, int period, int64_t *swe
     return total;
 }
 
-extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int mode, int batch, int *community_out,
-                               double *modularity_out) try {
+// compute_modularity's per-node terms weight_to_community(i, community[i]) (:131): each rank computes those of its node range
+// and the ranges are all-gathered — the modularity partials of several GPUs.  (Gathered per NODE rather than reduced per
+// community: the per-community f64 sums are then taken in the reference's node order on every rank, the same bits as one GPU.)
+static int lei_w2c_all(mn_graph *g, mn_comm *c, const DevGraph &dg, int use_both, const int *label, double *tmp) {
+    hipStream_t st = g->stream;
+    const int N = g->n, world = c ? c->world : 1, rank = c ? c->rank : 0;
+    const int per = (N + world - 1) / world;
+    const int v0 = std::min(N, rank * per), v1 = std::min(N, v0 + per);
+    if (v1 > v0)
+        hipLaunchKernelGGL(k_w2c_self, dim3((v1 - v0 + 255) / 256), dim3(256), 0, st, dg, use_both, label, tmp, v0, v1);
+    if (world > 1 && mn_comm_allgather_dev(c, tmp + (size_t)rank * per, tmp, (size_t)per * sizeof(double), st)) {
+        gset_err("mn_graph_leiden_shared: %s", mn_comm_last_error_str());
+        return -1;
+    }
+    return 0;
+}
+
+static int leiden_impl(mn_graph *g, mn_comm *c, double resolution, int use_both, int mode, int batch, int *community_out,
+                       double *modularity_out) {
     GCHK(hipSetDevice(g->device));
     const int N = g->n;
     memset(&g->stats, 0, sizeof(g->stats));
@@ -1649,7 +1701,7 @@ extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int
         a.label = d.label;
         a.sum_tot = d.sum_tot;
         a.elig_part = nullptr;
-        long long moves = period ? run_phase_sync(g, a, period, &g->stats.move_sweeps) : run_phase(g, a, mode, batch, &g->stats.move_sweeps);
+        long long moves = period ? run_phase_sync(g, c, a, period, &g->stats.move_sweeps) : run_phase(g, a, mode, batch, &g->stats.move_sweeps);
         if (moves < 0)
             return -1;
         g->stats.iterations++;
@@ -1667,7 +1719,7 @@ extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int
             for (int i = 0; i < N; i++)
                 refined[i] = i;
         }
-        if ((period ? run_phase_sync(g, a, period, &g->stats.refine_sweeps) : run_phase(g, a, mode, batch, &g->stats.refine_sweeps)) < 0)
+        if ((period ? run_phase_sync(g, c, a, period, &g->stats.refine_sweeps) : run_phase(g, a, mode, batch, &g->stats.refine_sweeps)) < 0)
             return -1;
         if (on_dev) {
             // :388-408 adopt the refinement iff it has no more communities than phase 1; then renumber (:317-331)
@@ -1706,7 +1758,8 @@ extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int
         if (dev_distinct(g, d.label, 0) || dev_renumber(g, d.label)) // :420
             return -1;
         // compute_modularity (:109-142): per-node terms and per-community sums (integers) on the device
-        hipLaunchKernelGGL(k_w2c_self, dim3(nbN), dim3(256), 0, st, dg, use_both, d.label, d.tmp);
+        if (lei_w2c_all(g, c, dg, use_both, d.label, d.tmp))
+            return -1;
         GCHK(hipMemsetAsync(d.s_in, 0, (size_t)N * sizeof(double), st));
         GCHK(hipMemsetAsync(d.sum_tot, 0, (size_t)N * sizeof(double), st));
         hipLaunchKernelGGL(k_scatter_add, dim3(nbN), dim3(256), 0, st, d.label, d.tmp, N, d.s_in);
@@ -1727,7 +1780,8 @@ extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int
         K = renumber(community); // :420
         // compute_modularity (:109-142): per-node terms on the device, accumulation in node order here
         GCHK(hipMemcpyAsync(d.label, community.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_w2c_self, dim3(nbN), dim3(256), 0, st, dg, use_both, d.label, d.tmp);
+        if (lei_w2c_all(g, c, dg, use_both, d.label, d.tmp))
+            return -1;
         std::vector<double> w2c((size_t)N);
         GCHK(hipMemcpyAsync(w2c.data(), d.tmp, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, st));
         GCHK(hipEventRecord(g->ev1, st));
@@ -1751,6 +1805,24 @@ extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int
     if (modularity_out)
         *modularity_out = Q;
     return 0;
+}
+
+extern "C" int mn_graph_leiden(mn_graph *g, double resolution, int use_both, int mode, int batch, int *community_out,
+                               double *modularity_out) try {
+    return leiden_impl(g, nullptr, resolution, use_both, mode, batch, community_out, modularity_out);
+} MN_GUARD_END(gset_err, MN_NOTHING, -1)
+
+// run_leiden on the GPUs of a communicator (north_star: the local-move sweep "partitioned across the GPUs ... modularity
+// partials").  Every rank holds the whole graph; the parallel schedule's sweeps are divided by node range
+// (run_phase_sync) and so are the modularity's per-node terms (lei_w2c_all).  Every rank returns the communities and Q that
+// mn_graph_leiden(MN_LEIDEN_BATCHED, batch) returns on one GPU, bit for bit.  batch as there (0: the default schedule).
+extern "C" int mn_graph_leiden_shared(mn_graph *g, mn_comm *c, double resolution, int use_both, int batch, int *community_out,
+                                      double *modularity_out) try {
+    if (c && c->world > 64) {
+        gset_err("mn_graph_leiden_shared: more than 64 ranks");
+        return -1;
+    }
+    return leiden_impl(g, c, resolution, use_both, MN_LEIDEN_BATCHED, batch, community_out, modularity_out);
 } MN_GUARD_END(gset_err, MN_NOTHING, -1)
 
 extern "C" int mn_graph_leiden_stats(mn_graph *g, mn_leiden_stats *out) try {

@@ -540,25 +540,53 @@ extern "C" int mn_node2vec_train_shared(mn_comm *c, int n, const int *off, const
         mn_n2v_end(S);
         return -1;
     }
-    int *lc = nullptr, *lt = nullptr, *lpc = nullptr, *gc = nullptr, *gt = nullptr, *gpc = nullptr;
-    float *le = nullptr, *lpn = nullptr, *ge = nullptr, *gpn = nullptr;
+    int *lc = nullptr, *lt = nullptr, *lpc = nullptr, *gc = nullptr, *gt = nullptr, *gpc = nullptr, *send_s = nullptr, *recv_s = nullptr,
+        *d_hist = nullptr;
+    float *le = nullptr, *lpn = nullptr, *ge = nullptr, *gpn = nullptr, *send_p = nullptr, *recv_p = nullptr;
+    long long *d_cnt = nullptr;
     auto cleanup = [&](int rc) {
         (void)hipDeviceSynchronize();
-        void *ps[] = {lc, lt, lpc, gc, gt, gpc, le, lpn, ge, gpn};
+        void *ps[] = {lc, lt, lpc, gc, gt, gpc, le, lpn, ge, gpn, send_s, recv_s, send_p, recv_p, d_hist, d_cnt};
         for (void *q : ps)
             (void)hipFree(q);
         mn_n2v_end(S);
         return rc;
     };
     const size_t ls = (size_t)per_max * cap, lp = (size_t)per_max * pcap;
-    if (hipMalloc(&lc, ls * 4) != hipSuccess || hipMalloc(&lt, ls * 4) != hipSuccess || hipMalloc(&le, ls * 4) != hipSuccess ||
-        hipMalloc(&lpc, lp * 4) != hipSuccess || hipMalloc(&lpn, lp * dim * 4) != hipSuccess ||
-        hipMalloc(&gc, ls * world * 4) != hipSuccess || hipMalloc(&gt, ls * world * 4) != hipSuccess ||
-        hipMalloc(&ge, ls * world * 4) != hipSuccess || hipMalloc(&gpc, lp * world * 4) != hipSuccess ||
-        hipMalloc(&gpn, lp * world * dim * 4) != hipSuccess) {
+    bool ok = hipMalloc(&lc, ls * 4) == hipSuccess && hipMalloc(&lt, ls * 4) == hipSuccess && hipMalloc(&le, ls * 4) == hipSuccess &&
+              hipMalloc(&lpc, lp * 4) == hipSuccess && hipMalloc(&lpn, lp * dim * 4) == hipSuccess;
+    if (ok && world > 1) // the exchange by destination shard: packed buckets out, packed buckets in, then the unpacked arrays
+        ok = hipMalloc(&send_s, ls * 12) == hipSuccess && hipMalloc(&recv_s, ls * world * 12) == hipSuccess &&
+             hipMalloc(&send_p, lp * (dim + 1) * 4) == hipSuccess && hipMalloc(&recv_p, lp * world * (dim + 1) * 4) == hipSuccess &&
+             hipMalloc(&gc, ls * world * 4) == hipSuccess && hipMalloc(&gt, ls * world * 4) == hipSuccess &&
+             hipMalloc(&ge, ls * world * 4) == hipSuccess && hipMalloc(&gpc, lp * world * 4) == hipSuccess &&
+             hipMalloc(&gpn, lp * world * dim * 4) == hipSuccess && hipMalloc(&d_hist, 2 * 65 * sizeof(int)) == hipSuccess &&
+             hipMalloc(&d_cnt, (size_t)(world + 1) * 2 * world * sizeof(long long)) == hipSuccess;
+    if (!ok) {
         nset_err("mn_node2vec_train_shared: out of device memory for the exchange buffers");
         return cleanup(-1);
     }
+    int shard_bits = 1;
+    while ((1 << shard_bits) <= world)
+        shard_bits++;
+    if (world > 1) { // the bucket sort's scratch (fewer key bits than the row sorts: its own size query)
+        size_t need = 0;
+        if (rocprim::radix_sort_pairs(nullptr, need, S->keys, S->keys_s, S->vals, S->vals_s, ls, 0, shard_bits, S->st) != hipSuccess) {
+            nset_err("rocprim::radix_sort_pairs (size query) failed");
+            return cleanup(-1);
+        }
+        if (need > S->tmp_bytes) {
+            (void)hipFree(S->tmp);
+            S->tmp = nullptr;
+            if (hipMalloc(&S->tmp, need) != hipSuccess) {
+                nset_err("mn_node2vec_train_shared: out of device memory for the sort scratch");
+                return cleanup(-1);
+            }
+            S->tmp_bytes = need;
+        }
+    }
+    std::vector<int> h_hist(2 * 65);
+    std::vector<long long> h_cnt((size_t)2 * world * world), h_row((size_t)2 * world);
     // A rank whose local step fails may not leave the loop on its own: its peers are in — or about to enter — the batch's
     // all-gathers and would wait for ever.  `status` carries a local failure (this batch's samples, or the previous batch's
     // apply) into the status exchange at the head of the next collective; all ranks stop together (mn_comm_agree).
@@ -612,20 +640,98 @@ extern "C" int mn_node2vec_train_shared(mn_comm *c, int n, const int *off, const
                 agree();
                 if (rc)
                     break;
-                if (mn_comm_allgather_dev(c, lc, gc, (size_t)per * cap * 4, S->st) ||
-                    mn_comm_allgather_dev(c, lt, gt, (size_t)per * cap * 4, S->st) ||
-                    mn_comm_allgather_dev(c, le, ge, (size_t)per * cap * 4, S->st) ||
-                    mn_comm_allgather_dev(c, lpc, gpc, (size_t)per * pcap * 4, S->st) ||
-                    mn_comm_allgather_dev(c, lpn, gpn, (size_t)per * pcap * dim * 4, S->st)) {
+                const int ls_n = per * cap, lp_n = per * pcap;
+                if (world == 1) {
+                    if (n2v_apply(S, lc, lt, le, ls_n, lpc, lpn, lp_n, 0, n)) {
+                        status = 1;
+                        mine = mn_node2vec_last_error();
+                    }
+                    continue;
+                }
+                // ── exchange by destination shard: a sample goes to the rank that owns its target row, a position to the one that
+                //    owns its centre row; each rank then sorts and applies only what is meant for its rows ──
+                bool xok = hipMemsetAsync(d_hist, 0, 2 * 65 * sizeof(int), S->st) == hipSuccess;
+                size_t tb = S->tmp_bytes;
+                if (xok) {
+                    hipLaunchKernelGGL(k_n2v_shard_keys, dim3((ls_n + 255) / 256), dim3(256), 0, S->st, lt, ls_n, rows_per, world, S->keys,
+                                       S->vals, d_hist);
+                    xok = rocprim::radix_sort_pairs(S->tmp, tb, S->keys, S->keys_s, S->vals, S->vals_s, (size_t)ls_n, 0, shard_bits, S->st) ==
+                          hipSuccess;
+                }
+                if (xok) {
+                    xok = hipMemcpyAsync(h_hist.data(), d_hist, 2 * 65 * sizeof(int), hipMemcpyDeviceToHost, S->st) == hipSuccess &&
+                          hipStreamSynchronize(S->st) == hipSuccess;
+                }
+                int nv_s = 0;
+                if (xok) {
+                    nv_s = ls_n - h_hist[(size_t)world];
+                    if (nv_s > 0)
+                        hipLaunchKernelGGL(k_n2v_pack_samples, dim3((nv_s + 255) / 256), dim3(256), 0, S->st, S->vals_s, nv_s, lc, lt, le, send_s);
+                    hipLaunchKernelGGL(k_n2v_shard_keys, dim3((lp_n + 255) / 256), dim3(256), 0, S->st, lpc, lp_n, rows_per, world, S->keys,
+                                       S->vals, d_hist + 65);
+                    tb = S->tmp_bytes;
+                    xok = rocprim::radix_sort_pairs(S->tmp, tb, S->keys, S->keys_c, S->vals, S->vals_s, (size_t)lp_n, 0, shard_bits, S->st) ==
+                              hipSuccess &&
+                          hipMemcpyAsync(h_hist.data() + 65, d_hist + 65, 65 * sizeof(int), hipMemcpyDeviceToHost, S->st) == hipSuccess &&
+                          hipStreamSynchronize(S->st) == hipSuccess;
+                }
+                int nv_p = 0;
+                if (xok) {
+                    nv_p = lp_n - h_hist[(size_t)65 + world];
+                    if (nv_p > 0)
+                        hipLaunchKernelGGL(k_n2v_pack_positions, dim3(nv_p), dim3(64), 0, S->st, S->vals_s, lpc, lpn, dim, send_p);
+                    xok = hipGetLastError() == hipSuccess;
+                }
+                // the bucket sizes of every rank; a rank whose preparation failed says so in its row (-1) instead of staying
+                // away from the collective its peers are about to enter
+                for (int p = 0; p < world; p++) {
+                    h_row[(size_t)p] = xok ? h_hist[(size_t)p] : -1;
+                    h_row[(size_t)world + p] = xok ? h_hist[(size_t)65 + p] : -1;
+                }
+                long long *d_row = d_cnt + (size_t)2 * world * world; // (send and receive areas do not overlap)
+                if (hipMemcpyAsync(d_row, h_row.data(), (size_t)2 * world * sizeof(long long), hipMemcpyHostToDevice, S->st) != hipSuccess ||
+                    hipStreamSynchronize(S->st) != hipSuccess ||
+                    mn_comm_allgather_dev(c, d_row, d_cnt, (size_t)2 * world * sizeof(long long), S->st) ||
+                    hipMemcpyAsync(h_cnt.data(), d_cnt, (size_t)2 * world * world * sizeof(long long), hipMemcpyDeviceToHost, S->st) != hipSuccess ||
+                    hipStreamSynchronize(S->st) != hipSuccess) {
+                    nset_err("mn_node2vec_train_shared: exchanging the bucket sizes failed (%s)", mn_comm_last_error_str());
+                    rc = -1;
+                    break;
+                }
+                int bad = -1;
+                for (int sr = 0; sr < world && bad < 0; sr++)
+                    if (h_cnt[(size_t)sr * 2 * world] < 0)
+                        bad = sr;
+                if (bad >= 0) {
+                    nset_err("mn_node2vec_train_shared: rank %d could not prepare its buckets; all ranks stop", bad);
+                    rc = -1;
+                    break;
+                }
+                std::vector<long long> cs((size_t)world * world), cp((size_t)world * world);
+                long long ns_recv = 0, np_recv = 0;
+                for (int sr = 0; sr < world; sr++)
+                    for (int p = 0; p < world; p++) {
+                        cs[(size_t)sr * world + p] = h_cnt[(size_t)sr * 2 * world + p];
+                        cp[(size_t)sr * world + p] = h_cnt[(size_t)sr * 2 * world + world + p];
+                        if (p == rank) {
+                            ns_recv += cs[(size_t)sr * world + p];
+                            np_recv += cp[(size_t)sr * world + p];
+                        }
+                    }
+                if (mn_comm_alltoallv_dev(c, send_s, recv_s, cs.data(), 12, S->st) ||
+                    mn_comm_alltoallv_dev(c, send_p, recv_p, cp.data(), (size_t)(dim + 1) * 4, S->st)) {
                     nset_err("mn_node2vec_train_shared: %s", mn_comm_last_error_str());
                     rc = -1;
                     break;
                 }
-                // every rank has the whole batch's samples; it applies them to ITS shard of the destination rows only (a row's
-                // additions are the same, in the same order, whoever owns it) and the updated shards of both matrices are
-                // all-gathered in place: the apply half — 38 % of a batch on one GPU — is divided by the rank count too
-                if (n2v_apply(S, gc, gt, ge, (int64_t)world * per * cap, gpc, gpn, (int64_t)world * per * pcap, rank * rows_per,
-                              (rank + 1) * rows_per)) {
+                if (ns_recv > 0)
+                    hipLaunchKernelGGL(k_n2v_unpack_samples, dim3((unsigned)((ns_recv + 255) / 256)), dim3(256), 0, S->st, recv_s, (int)ns_recv,
+                                       gc, gt, ge);
+                if (np_recv > 0)
+                    hipLaunchKernelGGL(k_n2v_unpack_positions, dim3((unsigned)np_recv), dim3(64), 0, S->st, recv_p, dim, gpc, gpn);
+                // this rank's rows receive exactly the additions, in exactly the order, one GPU gives them; the updated shards of
+                // both matrices are all-gathered in place
+                if (n2v_apply(S, gc, gt, ge, ns_recv, gpc, gpn, np_recv, rank * rows_per, (rank + 1) * rows_per)) {
                     status = 1; // (reported to the peers at the head of the next batch, or below after the last one)
                     mine = mn_node2vec_last_error();
                 }

@@ -127,120 +127,71 @@ DEVI int gen_walk(const N2vArgs &a, int n, unsigned &rng, int *walk, double *cum
     return a.walk_length;
 }
 
-// The samples of a walk are processed as a stream of CHUNKS: (position, context, s0) = samples s0 .. s0+PF-1 of the pair
-// (walk[position], walk[context]) (src/node2vec.c:353-386).  A chunk has two halves.  FETCH draws its targets (the walk's
-// xorshift32 stream is consumed in sample order, and by draws only) and requests their rows — and the centre row when the chunk
-// opens a position.  SCORE takes the dot products in order, writes the samples and folds err·row into the position's neu1e.
-// Round 4: the two halves are software-pipelined — chunk k+1 is fetched BEFORE chunk k is scored, so that the negative-table
-// gather and the row gather of the next pair overlap the butterflies, LUT look-ups and stores of this one (the per-pair chain
-// was draw → table gather → row gather → six reductions → stores, one after the other: 0.48 of the HBM roofline with only
-// 1.08x traffic).  Same operations on the same operands in the same order: same bits.
-struct N2vIt {
-    int pos, c, s0, cs, ce;
-    bool valid;
-};
-DEVI void n2v_it_seek(N2vIt &it, int pe, int wlen, int window) { // first chunk at or after position it.pos
-    for (; it.pos < pe; it.pos++) {
-        it.cs = it.pos - window < 0 ? 0 : it.pos - window;
-        it.ce = it.pos + window >= wlen ? wlen - 1 : it.pos + window;
-        it.c = it.cs == it.pos ? it.cs + 1 : it.cs;
-        if (it.c <= it.ce) {
-            it.s0 = 0;
-            it.valid = true;
-            return;
-        }
-    }
-    it.valid = false;
-}
-template <int PF> DEVI void n2v_it_next(N2vIt &it, int neg, int pe, int wlen, int window) {
-    it.s0 += PF;
-    if (it.s0 <= neg)
-        return;
-    it.s0 = 0;
-    it.c++;
-    if (it.c == it.pos)
-        it.c++;
-    if (it.c <= it.ce)
-        return;
-    it.pos++;
-    n2v_it_seek(it, pe, wlen, window);
-}
-template <int NR, int PF> struct N2vChunkBuf {
+// Samples s0 .. s0+nd-1 of one (centre, context) pair (src/node2vec.c:353-386): draw the targets (the stream is
+// consumed in sample order), fetch all their rows at once, then score them in order.  FULL (nd == PF) is the
+// branch-free path: a rejected negative (== centre or context, :361-363) still has its row fetched, but leaves no
+// sample and no contribution.  The sample slot is written before it is known to be kept; a rejected one is
+// overwritten by the next sample or by the walk's -1 tail fill.
+template <int NR, int PF, bool FULL>
+DEVI void n2v_score_chunk(const N2vArgs &a, const N2vBatchArgs &b, unsigned &rng, int s0, int nd, int center, int context,
+                          const float (&vc)[NR], float (&neu)[NR], float lr, size_t base, int &ns, int lane, const float *sig) {
+    const int dim = a.dim;
     int tg[PF];
     bool ok[PF];
-    float tr[PF][NR];
-    float vc[NR]; // the centre row, when the chunk opens its position
-};
-
-template <int NR, int PF>
-DEVI void n2v_chunk_fetch(const N2vArgs &a, unsigned &rng, const N2vIt &it, const int *walk, N2vChunkBuf<NR, PF> &f, int lane) {
-    const int dim = a.dim;
-    const int center = walk[it.pos], context = walk[it.c];
-    const int nd = a.neg + 1 - it.s0 < PF ? a.neg + 1 - it.s0 : PF;
 #pragma unroll
     for (int i = 0; i < PF; i++) {
-        f.tg[i] = context;
-        f.ok[i] = false;
-        if (i < nd) {
-            if (i == 0 && it.s0 == 0) {
-                f.ok[i] = true; // the positive sample
+        tg[i] = context;
+        ok[i] = false;
+        if (FULL || i < nd) {
+            if (i == 0 && s0 == 0) {
+                ok[i] = true; // the positive sample
             } else {
-                f.tg[i] = a.neg_table[xs32(rng) % N2V_NEG_TABLE];
-                f.ok[i] = f.tg[i] != center && f.tg[i] != context; // :361-363 (the draw is consumed either way)
+                tg[i] = a.neg_table[xs32(rng) % N2V_NEG_TABLE];
+                ok[i] = tg[i] != center && tg[i] != context;
             }
         }
     }
-#pragma unroll
-    for (int i = 0; i < PF; i++) { // (a slot past nd re-reads the context row: branch-free, contributes nothing)
-        const float *rowt = a.syn1neg + (size_t)f.tg[i] * dim;
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-            const int d = lane + 64 * r;
-            f.tr[i][r] = d < dim ? rowt[d] : 0.0f;
-        }
-    }
-    const bool opens = it.s0 == 0 && it.c == (it.cs == it.pos ? it.cs + 1 : it.cs);
-    if (opens) {
-        const float *rowc = a.syn0 + (size_t)center * dim;
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-            const int d = lane + 64 * r;
-            f.vc[r] = d < dim ? rowc[d] : 0.0f;
-        }
-    }
-}
-
-template <int NR, int PF>
-DEVI void n2v_chunk_score(const N2vArgs &a, const N2vBatchArgs &b, const N2vIt &it, const int *walk, const N2vChunkBuf<NR, PF> &f,
-                          const float (&vc)[NR], float (&neu)[NR], float lr, size_t base, int &ns, int lane, const float *sig) {
-    const int dim = a.dim;
-    const int center = walk[it.pos];
-    const int nd = a.neg + 1 - it.s0 < PF ? a.neg + 1 - it.s0 : PF;
+    float tr[PF][NR];
 #pragma unroll
     for (int i = 0; i < PF; i++)
-        if (i < nd) {
+        if (FULL || i < nd) {
+            const float *rowt = a.syn1neg + (size_t)tg[i] * dim;
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                int d = lane + 64 * r;
+                tr[i][r] = d < dim ? rowt[d] : 0.0f;
+            }
+        }
+#pragma unroll
+    for (int i = 0; i < PF; i++)
+        if (FULL || i < nd) {
             float acc = 0.0f;
 #pragma unroll
             for (int r = 0; r < NR; r++)
                 if (lane + 64 * r < dim)
-                    acc = fmaf(vc[r], f.tr[i][r], acc);
+                    acc = fmaf(vc[r], tr[i][r], acc);
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1)
                 acc = __fadd_rn(acc, __shfl_xor(acc, m));
-            const float label = (i == 0 && it.s0 == 0) ? 1.0f : 0.0f;
+            const float label = (i == 0 && s0 == 0) ? 1.0f : 0.0f;
             const float err = __fmul_rn(__fsub_rn(label, fast_sigmoid(sig, acc)), lr);
-            if (lane == 0) { // (written before it is known to be kept: a rejected one is overwritten by the next sample or the tail fill)
+            if (lane == 0) {
                 b.s_center[base + ns] = center;
-                b.s_target[base + ns] = f.tg[i];
+                b.s_target[base + ns] = tg[i];
                 b.s_err[base + ns] = err;
             }
-            ns += f.ok[i] ? 1 : 0;
+            ns += ok[i] ? 1 : 0;
 #pragma unroll
             for (int r = 0; r < NR; r++)
-                neu[r] = f.ok[i] ? fmaf(err, f.tr[i][r], neu[r]) : neu[r];
+                neu[r] = ok[i] ? fmaf(err, tr[i][r], neu[r]) : neu[r];
         }
 }
 
+// Round 4, measured and not kept (same box, one pass of 1M walks, scripts/ab_n2v.sh): (i) software-pipelining the chunks — the
+// next pair's targets drawn and its rows requested before this pair is scored — doubles the live registers (125 VGPRs, 4
+// wavefronts per SIMD instead of 8) and is twice as slow (18.7 vs 9.5 ms per batch); (ii) drawing only the next pair's targets
+// ahead, so that the negative-table gather leaves the per-pair chain, still costs 84 VGPRs (5 wavefronts per SIMD): 1.61 vs
+// 1.27 s.  What this kernel lives on is wavefronts in flight, not a shorter chain per wavefront.
 template <int NR> // NR = ceil(dim / 64) register slots per lane
 __global__ void __launch_bounds__(64) k_n2v_walk_grad(N2vBatchArgs b) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -297,66 +248,45 @@ __global__ void __launch_bounds__(64) k_n2v_walk_grad(N2vBatchArgs b) {
 #endif
     int ns = pairs_p0 * (1 + a.neg);
     unsigned long long pairs = 0;
-    float vc[NR], neu[NR];
-    int live = -1; // the position whose neu1e is being accumulated
-    auto close_position = [&]() {
-        if (live < 0)
-            return;
-        if (lane == 0)
-            b.p_center[pbase + live] = walk[live];
-#ifndef MN_N2V_NO_PNEU // timing experiments only
-        float *pn = b.p_neu + (pbase + live) * dim;
+    for (int pos = p0; pos < pe; pos++) {
+        const int center = walk[pos];
+        int cs = pos - a.window, ce = pos + a.window;
+        if (cs < 0)
+            cs = 0;
+        if (ce >= wlen)
+            ce = wlen - 1;
+        float vc[NR], neu[NR];
+        const float *rowc = a.syn0 + (size_t)center * dim;
 #pragma unroll
         for (int r = 0; r < NR; r++) {
-            const int d = lane + 64 * r;
+            int d = lane + 64 * r;
+            vc[r] = d < dim ? rowc[d] : 0.0f;
+            neu[r] = 0.0f;
+        }
+        for (int c = cs; c <= ce; c++) {
+            if (c == pos)
+                continue;
+            const int context = walk[c];
+            pairs++;
+            for (int s0 = 0; s0 <= a.neg; s0 += PF) {
+                const int nd = a.neg + 1 - s0 < PF ? a.neg + 1 - s0 : PF;
+                if (nd == PF)
+                    n2v_score_chunk<NR, PF, true>(a, b, rng, s0, nd, center, context, vc, neu, lr, base, ns, lane, sig_l);
+                else
+                    n2v_score_chunk<NR, PF, false>(a, b, rng, s0, nd, center, context, vc, neu, lr, base, ns, lane, sig_l);
+            }
+        }
+        if (lane == 0)
+            b.p_center[pbase + pos] = center;
+#ifndef MN_N2V_NO_PNEU // timing experiments only
+        float *pn = b.p_neu + (pbase + pos) * dim;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            int d = lane + 64 * r;
             if (d < dim)
                 pn[d] = neu[r];
         }
 #endif
-    };
-    if (wlen < 2) { // a start node without neighbours: its one position has no context, an all-zero neu1e
-        for (int pos = p0; pos < pe; pos++) {
-#pragma unroll
-            for (int r = 0; r < NR; r++)
-                neu[r] = 0.0f;
-            live = pos;
-            close_position();
-        }
-        live = -1;
-    } else {
-        N2vChunkBuf<NR, PF> bufA, bufB;
-        N2vIt cur;
-        cur.pos = p0;
-        n2v_it_seek(cur, pe, wlen, a.window);
-        if (cur.valid)
-            n2v_chunk_fetch<NR, PF>(a, rng, cur, walk, bufA, lane);
-        // one step: fetch the chunk after `cur` into N, then score `cur` out of C
-        auto step = [&](N2vChunkBuf<NR, PF> &C, N2vChunkBuf<NR, PF> &N) {
-            N2vIt nxt = cur;
-            n2v_it_next<PF>(nxt, a.neg, pe, wlen, a.window);
-            if (nxt.valid)
-                n2v_chunk_fetch<NR, PF>(a, rng, nxt, walk, N, lane);
-            if (cur.pos != live) { // this chunk opens its position: the centre row came with it
-                close_position();
-                live = cur.pos;
-#pragma unroll
-                for (int r = 0; r < NR; r++) {
-                    vc[r] = C.vc[r];
-                    neu[r] = 0.0f;
-                }
-            }
-            if (cur.s0 == 0)
-                pairs++;
-            n2v_chunk_score<NR, PF>(a, b, cur, walk, C, vc, neu, lr, base, ns, lane, sig_l);
-            cur = nxt;
-        };
-        while (cur.valid) {
-            step(bufA, bufB);
-            if (!cur.valid)
-                break;
-            step(bufB, bufA);
-        }
-        close_position();
     }
     for (int i = ns + lane; i < slot_end; i += 64) {
         b.s_center[base + i] = -1;
@@ -584,43 +514,106 @@ static int n2v_apply_t(mn_n2v_session *S, const int *d_center, const int *d_targ
     const int N = a.n, dim = a.dim;
     row1 = std::min(row1, N);
     const unsigned nrows = (unsigned)std::max(0, row1 - row0);
-    if (ns64 <= 0 || np64 <= 0)
+    if (ns64 <= 0 && np64 <= 0)
         return 0;
-    if ((size_t)ns64 > S->ns_max || (size_t)np64 > S->np_max) {
+    if ((size_t)std::max<int64_t>(ns64, 0) > S->ns_max || (size_t)std::max<int64_t>(np64, 0) > S->np_max) {
         nset_err("mn_n2v_apply: %lld samples / %lld positions exceed the session capacity %zu / %zu", (long long)ns64,
                  (long long)np64, S->ns_max, S->np_max);
         return -1;
     }
-    const int ns = (int)ns64, np = (int)np64;
+    const int ns = (int)std::max<int64_t>(ns64, 0), np = (int)std::max<int64_t>(np64, 0);
     const unsigned g256 = (unsigned)((ns + 255) / 256), p256 = (unsigned)((np + 255) / 256);
-    // centres: syn0[c] + Σ neu1e(position)  → staged (targets below still read the old centres)
-    hipLaunchKernelGGL(k_n2v_keys, dim3(p256), dim3(256), 0, S->st, d_pcenter, np, N, S->keys, S->vals);
-    if (rocprim::radix_sort_pairs(S->tmp, S->tmp_bytes, S->keys, S->keys_c, S->vals, S->vals_s, (size_t)np, 0, S->bits, S->st) !=
-        hipSuccess) {
-        nset_err("rocprim::radix_sort_pairs failed");
-        return -1;
+    // (a rank of the data-parallel mode may have received samples but no positions for its rows, or the reverse: two halves)
+    if (np > 0) {
+        // centres: syn0[c] + Σ neu1e(position)  → staged (targets below still read the old centres)
+        hipLaunchKernelGGL(k_n2v_keys, dim3(p256), dim3(256), 0, S->st, d_pcenter, np, N, S->keys, S->vals);
+        if (rocprim::radix_sort_pairs(S->tmp, S->tmp_bytes, S->keys, S->keys_c, S->vals, S->vals_s, (size_t)np, 0, S->bits, S->st) !=
+            hipSuccess) {
+            nset_err("rocprim::radix_sort_pairs failed");
+            return -1;
+        }
+        NCHK(hipMemsetAsync(S->seg_c, 0xFF, (size_t)N * sizeof(int), S->st));
+        hipLaunchKernelGGL(k_n2v_segments, dim3(p256), dim3(256), 0, S->st, S->keys_c, np, N, S->seg_c);
+        if (nrows)
+            hipLaunchKernelGGL((k_n2v_apply_centers<NR>), dim3(nrows), dim3(64), 0, S->st, S->keys_c, S->vals_s, S->seg_c, np, d_pneu,
+                               a.syn0, S->staged, dim, row0);
     }
-    NCHK(hipMemsetAsync(S->seg_c, 0xFF, (size_t)N * sizeof(int), S->st));
-    hipLaunchKernelGGL(k_n2v_segments, dim3(p256), dim3(256), 0, S->st, S->keys_c, np, N, S->seg_c);
-    if (nrows)
-        hipLaunchKernelGGL((k_n2v_apply_centers<NR>), dim3(nrows), dim3(64), 0, S->st, S->keys_c, S->vals_s, S->seg_c, np, d_pneu,
-                           a.syn0, S->staged, dim, row0);
-    // targets: syn1neg[t] += Σ err · syn0_old[c]  (syn0 is still the old one) → in place
-    hipLaunchKernelGGL(k_n2v_keys, dim3(g256), dim3(256), 0, S->st, d_target, ns, N, S->keys, S->vals);
-    if (rocprim::radix_sort_pairs(S->tmp, S->tmp_bytes, S->keys, S->keys_s, S->vals, S->vals_s, (size_t)ns, 0, S->bits, S->st) !=
-        hipSuccess) {
-        nset_err("rocprim::radix_sort_pairs failed");
-        return -1;
+    if (ns > 0) {
+        // targets: syn1neg[t] += Σ err · syn0_old[c]  (syn0 is still the old one) → in place
+        hipLaunchKernelGGL(k_n2v_keys, dim3(g256), dim3(256), 0, S->st, d_target, ns, N, S->keys, S->vals);
+        if (rocprim::radix_sort_pairs(S->tmp, S->tmp_bytes, S->keys, S->keys_s, S->vals, S->vals_s, (size_t)ns, 0, S->bits, S->st) !=
+            hipSuccess) {
+            nset_err("rocprim::radix_sort_pairs failed");
+            return -1;
+        }
+        NCHK(hipMemsetAsync(S->seg, 0xFF, (size_t)N * sizeof(int), S->st));
+        hipLaunchKernelGGL(k_n2v_segments, dim3(g256), dim3(256), 0, S->st, S->keys_s, ns, N, S->seg);
+        if (nrows)
+            hipLaunchKernelGGL((k_n2v_apply<NR>), dim3(nrows), dim3(64), 0, S->st, S->keys_s, S->vals_s, S->seg, ns, d_center, d_err,
+                               a.syn1neg, a.syn0, a.syn1neg, dim, row0);
     }
-    NCHK(hipMemsetAsync(S->seg, 0xFF, (size_t)N * sizeof(int), S->st));
-    hipLaunchKernelGGL(k_n2v_segments, dim3(g256), dim3(256), 0, S->st, S->keys_s, ns, N, S->seg);
-    if (nrows) {
-        hipLaunchKernelGGL((k_n2v_apply<NR>), dim3(nrows), dim3(64), 0, S->st, S->keys_s, S->vals_s, S->seg, ns, d_center, d_err,
-                           a.syn1neg, a.syn0, a.syn1neg, dim, row0);
+    if (np > 0 && nrows)
         hipLaunchKernelGGL(k_n2v_commit, dim3(nrows), dim3(64), 0, S->st, S->seg_c, S->staged, a.syn0, dim, row0);
-    }
     NCHK(hipGetLastError());
     return 0;
+}
+
+// ── data-parallel exchange by destination shard (mn_node2vec_train_shared) ──
+// A rank's samples are wanted by ONE rank each: the one that owns the sample's target row (positions: the centre row).  Instead of
+// all-gathering everything to everybody, a rank sorts its slots by destination shard — a stable one-pass radix sort, so every
+// bucket keeps the walk order —, packs the buckets and exchanges them all-to-all: 1 / world of the bytes on the links, and each
+// rank sorts and applies 1 / world of the samples.  Received buckets stand in source-rank order = the batch's walk order, so a
+// row's additions are the ones, in the order, that one GPU makes.
+__global__ void k_n2v_shard_keys(const int *dest, int n, int rows_per, int world, int *keys, int *vals, int *hist) {
+    __shared__ int h[65];
+    for (int i = threadIdx.x; i <= world; i += blockDim.x)
+        h[i] = 0;
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)n) {
+        const int d = dest[i];
+        const int k = d < 0 ? world : d / rows_per; // (unused slot: sorts to the end, is not sent)
+        keys[i] = k;
+        vals[i] = (int)i;
+        atomicAdd(&h[k], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= world; i += blockDim.x)
+        if (h[i])
+            atomicAdd(&hist[i], h[i]);
+}
+__global__ void k_n2v_pack_samples(const int *order, int n, const int *c, const int *t, const float *e, int *out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n)
+        return;
+    const int j = order[i];
+    out[3 * i] = c[j];
+    out[3 * i + 1] = t[j];
+    out[3 * i + 2] = __float_as_int(e[j]);
+}
+__global__ void k_n2v_unpack_samples(const int *in, int n, int *c, int *t, float *e) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n)
+        return;
+    c[i] = in[3 * i];
+    t[i] = in[3 * i + 1];
+    e[i] = __int_as_float(in[3 * i + 2]);
+}
+// a position travels as one record: its centre, then its neu1e vector
+__global__ void __launch_bounds__(64) k_n2v_pack_positions(const int *order, const int *pc, const float *pn, int dim, float *out) {
+    const int j = order[blockIdx.x];
+    float *o = out + (size_t)blockIdx.x * (dim + 1);
+    if (threadIdx.x == 0)
+        o[0] = __int_as_float(pc[j]);
+    for (int d = threadIdx.x; d < dim; d += 64)
+        o[1 + d] = pn[(size_t)j * dim + d];
+}
+__global__ void __launch_bounds__(64) k_n2v_unpack_positions(const float *in, int dim, int *pc, float *pn) {
+    const float *r = in + (size_t)blockIdx.x * (dim + 1);
+    if (threadIdx.x == 0)
+        pc[blockIdx.x] = __float_as_int(r[0]);
+    for (int d = threadIdx.x; d < dim; d += 64)
+        pn[(size_t)blockIdx.x * dim + d] = r[1 + d];
 }
 
 #define N2V_DISPATCH(fn, ...)                                         \

@@ -61,6 +61,7 @@ GRAPH_SYMBOLS = [
     ("mn_graph_last_error", C.c_char_p, []),
     ("mn_graph_leiden", C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, _i32p, C.POINTER(C.c_double)]),
     ("mn_graph_leiden_stats", C.c_int, [C.c_void_p, C.POINTER(LeidenStats)]),
+    ("mn_graph_leiden_shared", C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int, _i32p, C.POINTER(C.c_double)]),
     ("mn_graph_betweenness", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"),
                                        C.c_void_p]),
     ("mn_graph_last_ms", C.c_double, [C.c_void_p]),

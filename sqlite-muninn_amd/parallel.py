@@ -144,6 +144,30 @@ def node2vec_train_distributed(off, adj, dim, p=1.0, q=1.0, num_walks=10, walk_l
             comm.close()
 
 
+def leiden_distributed(graph, resolution=1.0, direction="both", batch=0, group=None, comm=None):
+    """run_leiden on the group's GPUs (mn_graph_leiden_shared): every rank holds `graph` (a graph.Graph of the SAME edges on
+    its own device); the sweeps' evaluation and the modularity's per-node terms are divided by node range and all-gathered;
+    every rank gets the communities and Q of a one-GPU MN_LEIDEN_BATCHED run, bit for bit.  → (community[n], Q, stats)."""
+    from .graph import LeidenStats, MuninnHipError, _gerr
+
+    own = comm is None
+    if own:
+        comm = Comm(0, group)
+    try:
+        comm_arr = np.empty(max(graph.n, 1), np.int32)
+        q = C.c_double(0.0)
+        rc = graph.L.mn_graph_leiden_shared(graph.h, comm.h, float(resolution), 1 if direction == "both" else 0, int(batch), comm_arr,
+                                            C.byref(q))
+        if rc != 0:
+            raise MuninnHipError(_gerr())
+        st = LeidenStats()
+        graph.L.mn_graph_leiden_stats(graph.h, C.byref(st))
+        return comm_arr[:graph.n], q.value, {n: getattr(st, n) for n, _ in LeidenStats._fields_}
+    finally:
+        if own:
+            comm.close()
+
+
 def allgather_merge_topk(ids: torch.Tensor, dists: torch.Tensor, counts: torch.Tensor, k: int, group=None):
     """The merge rule of the sharded index restated with torch ops — used by the CPU (gloo) rehearsal of the exchange step,
     where no HIP device exists; the product path is mn_hnsw_search_sharded (k_merge_topk on the device).

@@ -156,6 +156,56 @@ def test_node2vec_data_parallel_world2_bit_identical_to_one_gpu(gpu, world, n_no
         assert st["pairs"] == st1["pairs"]
 
 
+def _leiden_worker(rank, world, port, q, weighted):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import muninn_amd
+
+    pkg = muninn_amd.pkg
+    n = 20_003
+    s, d, _ = pkg.lfr.lfr_like(n, 20, 100, 0.3, seed=5)
+    w = (np.random.default_rng(9).random(len(s)) * 2 + 0.5) if weighted else None
+    g = pkg.graph.graph_from_edges(n, s, d, w)
+    comm, qq, st = pkg.parallel.leiden_distributed(g, 1.0, "both", 0)
+    q.put((rank, comm, qq, st))
+    g.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,weighted", [(2, False), (3, True), (4, False)])
+def test_leiden_divided_over_ranks_is_bit_identical_to_one_gpu(gpu, world, weighted):
+    """north_star: Leiden's local-move sweep partitioned across the GPUs with the modularity partials exchanged.  Several ranks
+    (gloo host transport, all on the box's one GPU) divide every synchronous sweep's evaluation and the modularity's per-node
+    terms by node range (20 003 nodes: nothing divides) — every rank must return the one-GPU communities, Q bits and sweep
+    counts, which are themselves the oracle's (tests/test_leiden.py)."""
+    n = 20_003
+    s, d, _ = gpu.lfr.lfr_like(n, 20, 100, 0.3, seed=5)
+    w = (np.random.default_rng(9).random(len(s)) * 2 + 0.5) if weighted else None
+    g = gpu.graph.graph_from_edges(n, s, d, w)
+    c1, q1, st1 = g.leiden(1.0, "both", gpu.LEIDEN_BATCHED)
+    g.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_leiden_worker, args=(r, world, port, q, weighted)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(_collect(procs, q, world, 300), key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, comm, qq, st in res:
+        assert np.array_equal(comm, c1), rank
+        assert np.float64(qq).view(np.int64) == np.float64(q1).view(np.int64), rank
+        assert (st["moves"], st["move_sweeps"], st["refine_sweeps"]) == (st1["moves"], st1["move_sweeps"], st1["refine_sweeps"]), rank
+
+
 def _build_worker(rank, world, port, q):
     import sys
 
