@@ -407,10 +407,13 @@ int mn_hnsw_search_sharded_dev(mn_index *idx, mn_comm *c, const float *d_queries
 /* the same with host buffers */
 int mn_hnsw_search_sharded(mn_index *idx, mn_comm *c, const float *queries, int64_t nq, int k, int ef_search, int64_t *out_ids,
                            float *out_dists, int *out_counts);
-/* MN_N2V_BATCHED data-parallel over the ranks (BASELINE config 4): every rank holds a replica of both matrices, computes
- * the samples of its contiguous slice of each batch's walks, the samples are all-gathered in rank order (= walk order) and
- * every replica applies the whole batch: the embeddings are bit-identical to mn_node2vec_train(.., MN_N2V_BATCHED) on
- * one GPU.  stats->pairs is this rank's share.  Returns n / -1. */
+/* MN_N2V_BATCHED data-parallel over the ranks (BASELINE config 4): every rank holds a replica of both matrices and computes
+ * the samples of its contiguous slice of each batch's walks.  A sample is then sent to the ONE rank that owns its target row
+ * (a position's neu1e to the owner of its centre row): buckets by destination shard, stable, exchanged all-to-all (ncclSend /
+ * ncclRecv over xGMI: 1 / world of the bytes an all-gather moves); every rank sorts and applies what it received to its rows
+ * — received buckets stand in rank order = walk order, so a row gets the additions, in the order, one GPU gives it — and the
+ * updated row shards of both matrices are all-gathered.  The embeddings are bit-identical to mn_node2vec_train(..,
+ * MN_N2V_BATCHED) on one GPU.  stats->pairs is this rank's share.  Returns n / -1. */
 int mn_node2vec_train_shared(mn_comm *c, int n_nodes, const int *off, const int *adj, const mn_n2v_params *prm, int device,
                              float *out, mn_n2v_stats *stats);
 /* run_leiden (src/graph_community.c:336-429) on the ranks' GPUs — north_star: the per-node local-move sweep "partitioned

@@ -162,6 +162,7 @@ __global__ void __launch_bounds__(64) k_link_reverse(MnDevIndex ix, MnLinkArgs a
     const bool may_overflow = nc + nb > M_max; // otherwise every source is appended and no distance is ever needed
     const int n_init = nc;                     // the row's own entries: their distances are computed at the first overflow
     bool have_nd = false, clean = false;       // clean: list[0..M_max) ascending by distance, all different, none unordered
+    bool settled = false; // equal distances remain in the row, but it is in the order the prune gives it from ITS OWN entries
     float worst = 0.0f;
     int last = -1;
     for (int c0 = 0; c0 < nb; c0 += 64) {
@@ -215,11 +216,17 @@ __global__ void __launch_bounds__(64) k_link_reverse(MnDevIndex ix, MnLinkArgs a
                 __builtin_amdgcn_wave_barrier();
                 have_nd = true;
             }
+            // A source strictly farther than every entry is what the prune drops.  With all distances different that is all the
+            // prune does.  With equal distances in the row the prune also re-sorts the tied entries by their mutual-neighbour
+            // counts |candidates ∩ N(entry)| (:613-639) — but a source is a node of this batch, and no row read here names one
+            // (new rows hold neighbours found in the frozen graph), so it adds nothing to any count: once the row has been put
+            // in order by a prune whose dropped candidate was such a source (`settled`), further drops find it in that order
+            // and leave it alone — one real prune per change of the row, not one per source of a hub.
+            if (M_max <= 64 && ds == ds && (clean || settled) && ds > worst) {
+                LD_ADD(2, 1);
+                continue;
+            }
             if (clean && M_max <= 64 && ds == ds) {
-                if (ds > worst) {
-                    LD_ADD(2, 1);
-                    continue; // strictly the farthest of the M_max + 1 candidates: the prune drops it, the row stays as it is
-                }
                 const float di = lane < M_max ? nd[lane] : 3.0e38f;
                 const unsigned long long lt = __ballot(lane < M_max && di < ds), eq = __ballot(lane < M_max && di == ds);
                 if (!eq) { // lands between its neighbours in distance; the last entry falls off
@@ -274,6 +281,7 @@ __global__ void __launch_bounds__(64) k_link_reverse(MnDevIndex ix, MnLinkArgs a
                     }
                 __builtin_amdgcn_wave_barrier();
                 clean = true;
+                settled = false;
                 LD_ADD(4, 1);
             } else { // equal or unordered distances: mutual-neighbour counts and the reference's selection sort, verbatim
                 LD_ADD(5, 1);
@@ -283,6 +291,7 @@ __global__ void __launch_bounds__(64) k_link_reverse(MnDevIndex ix, MnLinkArgs a
                 for (int e = lane; e + 1 < M_max; e += 64)
                     dirty |= !(nd[e] < nd[e + 1]);
                 clean = !__ballot(dirty);
+                settled = !clean && list[M_max] == s; // (the one candidate left over sits right behind the kept ones)
             }
             nc = M_max;
             worst = nd[M_max - 1];

@@ -207,11 +207,14 @@ DEVI float sse_row(const float *__restrict__ row, const float *q_lds, int dim, i
     c = blocks << 2;
 #endif
 #if MN_SSE_QUAD2 > 0
-    if (!LAT) { // (the lone-search kernels keep the dword walk: they run one wavefront against the instruction cache)
+    // (the lone-search kernels keep the dword walk: they run one wavefront against the instruction cache.  Short rows keep it
+    //  too: at 128 floats the kernels are not bound by the memory system and the transposes cost more than the loads save —
+    //  1M x 128, 10k queries: 7.8 ms per launch with the dword walk, 9.0 ms with quads)
+    if (!LAT && (steps >> 2) >= MN_SSE_QUAD2) {
         const int blocks = steps >> 2;
         int t = 0;
-        sse_blocks_quad<L2, (MN_SSE_QUAD2 > 0 ? MN_SSE_QUAD2 : 1)>(row, q_lds, j, blocks, t, s);
-        if (MN_SSE_QUAD2 > 8) // (short rows — 128 floats are 8 blocks — and remainders still get their loads in flight together)
+        sse_blocks_quad<L2, MN_SSE_QUAD2>(row, q_lds, j, blocks, t, s);
+        if (MN_SSE_QUAD2 > 8)
             sse_blocks_quad<L2, 8>(row, q_lds, j, blocks, t, s);
         if (MN_SSE_QUAD2 > 4)
             sse_blocks_quad<L2, 4>(row, q_lds, j, blocks, t, s);

@@ -109,6 +109,22 @@ __global__ void __launch_bounds__(PR_CHUNK)
             acc += d_sh[q];
         }
     }
+    // what is left of the in-list (all of it when the graph has no dangling node): the additions stay in list order, but eight
+    // sources and then their eight shares are requested together — the one-by-one walk was two dependent round trips per edge
+    // (round 3: 7.7 % of the HBM roofline at 1M nodes / 20M rows)
+    for (; p + 8 <= pe; p += 8) {
+        int sidx[8];
+        double sv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            sidx[u] = in_src[p + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            sv[u] = share[sidx[u]];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            acc += sv[u];
+    }
     while (p < pe) {
         acc += share[in_src[p]];
         p++;
@@ -244,6 +260,110 @@ __global__ void k_uf_init(int *parent, int *rnk, int *size, int n) {
     }
 }
 
+// EXACT without walking every edge through one lane (round 4: 158 ms for 10 000 nodes / 199 000 rows, 4.6x a 100-iteration
+// PageRank of the same graph).  The reference's component_id is the union-find ROOT, and roots and ranks change only at an
+// EFFECTIVE union — an edge whose ends are in different trees when its turn comes; every other edge only halves paths, which
+// moves no root.  Trees only ever merge, so an edge whose ends share a root at the start of a block of edges is ineffective
+// whatever happens inside the block: one workgroup tests 1 024 edges at once with read-only walks to the root and only the
+// survivors — a few per cent of the rows of a connected graph — are replayed in row order, verbatim (find with path halving,
+// union by rank, :1249-1273), by one wavefront.  Small graphs keep parent[] and rank[] in LDS (LDSV).
+#define UF_BLOCK 1024
+template <bool LDSV>
+__global__ void __launch_bounds__(UF_BLOCK) k_uf_blocks(const int *src, const int *dst, long long n_edges, int *parent_g, int *rnk_g, int n) {
+    extern __shared__ __align__(16) int uf_sm[];
+    int *ea = uf_sm, *eb = uf_sm + UF_BLOCK;                                   // the block's edges
+    unsigned long long *flag = reinterpret_cast<unsigned long long *>(uf_sm + 2 * UF_BLOCK); // one ballot per wavefront
+    int *parent = LDSV ? uf_sm + 2 * UF_BLOCK + 2 * (UF_BLOCK / 64) : parent_g;
+    unsigned char *rnk_l = reinterpret_cast<unsigned char *>(parent + (LDSV ? n : 0));
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    // (the table in global memory is read and written past the L1: the replaying wavefront's stores must be what the whole
+    //  workgroup's next look sees)
+    auto ldp = [&](int i) -> int { return LDSV ? parent[i] : __hip_atomic_load(parent + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto stp = [&](int i, int v) {
+        if (LDSV)
+            parent[i] = v;
+        else
+            __hip_atomic_store(parent + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    if (LDSV) {
+        for (int i = tid; i < n; i += UF_BLOCK) {
+            parent[i] = i;
+            rnk_l[i] = 0;
+        }
+    }
+    __syncthreads();
+    for (long long base = 0; base < n_edges; base += UF_BLOCK) {
+        const long long e = base + tid;
+        int a = 0, b = 0;
+        bool differ = false;
+        if (e < n_edges) {
+            a = src[e];
+            b = dst[e];
+            int ra = a, rb = b; // read-only walks: nothing is written while the whole workgroup looks
+            for (int p = ldp(ra); p != ra; p = ldp(ra))
+                ra = p;
+            for (int p = ldp(rb); p != rb; p = ldp(rb))
+                rb = p;
+            differ = ra != rb;
+        }
+        ea[tid] = a;
+        eb[tid] = b;
+        const unsigned long long m = __ballot(differ);
+        if (lane == 0)
+            flag[wv] = m;
+        __syncthreads();
+        if (wv == 0) { // the survivors, in row order; every lane runs the same steps on the same words
+            for (int w = 0; w < UF_BLOCK / 64; w++) {
+                unsigned long long mm = flag[w];
+                while (mm) {
+                    const int i = __ffsll((long long)mm) - 1;
+                    mm &= mm - 1;
+                    int x = ea[w * 64 + i], y = eb[w * 64 + i];
+                    for (int px = ldp(x); px != x; px = ldp(x)) { // uf_find: path halving (:1249-1256)
+                        const int gp = ldp(px);
+                        stp(x, gp);
+                        x = gp;
+                    }
+                    for (int py = ldp(y); py != y; py = ldp(y)) {
+                        const int gp = ldp(py);
+                        stp(y, gp);
+                        y = gp;
+                    }
+                    if (x == y)
+                        continue;
+                    int rx = LDSV ? rnk_l[x] : rnk_g[x], ry = LDSV ? rnk_l[y] : rnk_g[y];
+                    if (rx < ry) { // uf_union: by rank (:1258-1273)
+                        const int t = x;
+                        x = y;
+                        y = t;
+                        const int tr = rx;
+                        rx = ry;
+                        ry = tr;
+                    }
+                    stp(y, x);
+                    if (rx == ry) {
+                        if (LDSV)
+                            rnk_l[x] = (unsigned char)(rx + 1);
+                        else
+                            rnk_g[x] = rx + 1;
+                    }
+                    __builtin_amdgcn_s_waitcnt(0);
+                }
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (LDSV)
+        for (int i = tid; i < n; i += UF_BLOCK)
+            parent_g[i] = parent[i];
+}
+static size_t uf_lds_bytes(int n, bool ldsv) {
+    return (size_t)(2 * UF_BLOCK + 2 * (UF_BLOCK / 64)) * sizeof(int) + (ldsv ? (size_t)n * 5 + 16 : 0);
+}
+size_t mn_lds_optin_limit();                          // mn_kernels.hip: dynamic LDS a workgroup may ask for (64 KB, or what the device grants)
+bool mn_lds_grant(const void *kernel, size_t bytes);
+
 static __device__ __forceinline__ int uf_root(const int *parent, int x) { // read-only walk to the root
     while (true) {
         const int p = __hip_atomic_load(parent + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -327,7 +447,17 @@ extern "C" int mn_graph_components(int n, int64_t n_edges, const int *src, const
     hipLaunchKernelGGL(k_uf_init, dim3(nb), dim3(256), 0, nullptr, d_parent, d_rank, d_size, n);
     int rounds = 0;
     if (mode == MN_COMPONENTS_EXACT) {
-        hipLaunchKernelGGL(k_uf_seq, dim3(1), dim3(64), 0, nullptr, d_src, d_dst, (long long)n_edges, d_parent, d_rank);
+        const char *one = getenv("MN_COMPONENTS_ONE_LANE"); // (the round-3 replay, every edge through one lane: for A/B runs)
+        const size_t lds_v = uf_lds_bytes(n, true);
+        if (one && atoi(one) == 1) {
+            hipLaunchKernelGGL(k_uf_seq, dim3(1), dim3(64), 0, nullptr, d_src, d_dst, (long long)n_edges, d_parent, d_rank);
+        } else if (lds_v <= mn_lds_optin_limit() && mn_lds_grant(reinterpret_cast<const void *>(k_uf_blocks<true>), lds_v)) {
+            hipLaunchKernelGGL((k_uf_blocks<true>), dim3(1), dim3(UF_BLOCK), lds_v, nullptr, d_src, d_dst, (long long)n_edges, d_parent,
+                               d_rank, n);
+        } else {
+            hipLaunchKernelGGL((k_uf_blocks<false>), dim3(1), dim3(UF_BLOCK), uf_lds_bytes(n, false), nullptr, d_src, d_dst,
+                               (long long)n_edges, d_parent, d_rank, n);
+        }
         rounds = 1;
     } else if (n_edges) {
         for (int changed = 1; changed && rounds < 64; rounds++) { // (one round settles everything; the loop is the safety net)

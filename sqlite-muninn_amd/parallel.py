@@ -116,9 +116,10 @@ def search_sharded(g, comm, Q, k, ef):
 def node2vec_train_distributed(off, adj, dim, p=1.0, q=1.0, num_walks=10, walk_length=80, window=5, neg_samples=5,
                                learning_rate=0.025, epochs=1, batch_walks=0, device=0, group=None, comm=None):
     """Data-parallel Node2Vec (config 4, mn_node2vec_train_shared): every rank holds a replica of syn0/syn1neg; the walks
-    of each batch are split over the ranks, the (centre, target, err) samples and per-position neu1e vectors are
-    all-gathered in rank order (= walk order) and every rank applies the whole batch — the embeddings are bit-identical
-    to mn_node2vec_train(..., MN_N2V_BATCHED) on one GPU.  Returns (embeddings [n][dim] float32, stats)."""
+    of each batch are split over the ranks, every (centre, target, err) sample travels to the rank that owns its target row and
+    every per-position neu1e vector to the owner of its centre row (all-to-all by destination shard, buckets in walk order),
+    each rank applies what it received to its rows and the updated row shards are all-gathered — the embeddings are
+    bit-identical to mn_node2vec_train(..., MN_N2V_BATCHED) on one GPU.  Returns (embeddings [n][dim] float32, stats)."""
     from .graph import N2vParams, N2vStats, _glib
     from .hnsw import MuninnHipError
 

@@ -279,3 +279,21 @@ def test_betweenness_sql_equals_the_reference(gpu, ext_conn):
         edges = c.execute("SELECT src, dst, centrality FROM graph_edge_betweenness WHERE " + where, args).fetchall()
         assert [[r[0], r[1]] for r in edges] == z[name]["edges"], name
         assert np.array([r[2] for r in edges], np.float64).view(np.int64).tolist() == z[name]["eb_bits"], name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,deg", [(10_000, 20), (30_000, 3), (90_000, 4), (500, 1)])
+def test_components_exact_root_ids_by_blocks_equal_the_reference_order(gpu, n, deg):
+    """MN_COMPONENTS_EXACT (round 4): 1 024 rows are tested at once for "already in one tree" and only the others are replayed in
+    row order — the union-find ROOT ids must still be the ones the reference's row-by-row loop ends with (src/graph_tvf.c:
+    1249-1273, 1314-1360).  10 000 / 30 000 nodes run with the table in LDS, 90 000 in global memory; sparse graphs keep many
+    components and many effective unions, duplicates and self loops included."""
+    import bench_graph as bg
+
+    s, d = bg.er_rows(n, deg, seed=n)
+    extra = np.random.default_rng(n).integers(0, n, 200).astype(np.int32)
+    s = np.concatenate([s, extra, extra[:50]]).astype(np.int32)  # repeated rows and self loops
+    d = np.concatenate([d, extra[::-1], extra[:50]]).astype(np.int32)
+    want_id, want_sz = og.components(n, s, d)
+    got_id, got_sz, st = gpu.graph.components(n, s, d, gpu.graph.COMPONENTS_EXACT)
+    assert np.array_equal(got_id, want_id) and np.array_equal(got_sz, want_sz)
