@@ -150,7 +150,7 @@ DEVI void sse_blocks_quad(const float *__restrict__ row, const float *q_lds, int
     }
 }
 
-template <bool L2, bool LAT = false>
+template <bool L2, bool LAT = false, bool QUAD = false>
 DEVI float sse_row(const float *__restrict__ row, const float *q_lds, int dim, int lane) {
     const int j = lane & 3;
     const int steps = dim >> 2; // chain positions (one per group of 4 elements)
@@ -207,10 +207,12 @@ DEVI float sse_row(const float *__restrict__ row, const float *q_lds, int dim, i
     c = blocks << 2;
 #endif
 #if MN_SSE_QUAD2 > 0
-    // (the lone-search kernels keep the dword walk: they run one wavefront against the instruction cache.  Short rows keep it
-    //  too: at 128 floats the kernels are not bound by the memory system and the transposes cost more than the loads save —
-    //  1M x 128, 10k queries: 7.8 ms per launch with the dword walk, 9.0 ms with quads)
-    if (!LAT && (steps >> 2) >= MN_SSE_QUAD2) {
+    // QUAD is a property of the KERNEL (k_beam<SSE, 1>: the launcher picks it for rows of at least MN_SSE_QUAD2 blocks): the
+    // twelve float4 registers cost occupancy (98 VGPRs, 16 wavefronts per CU), which pays at 768 floats and does not at 128,
+    // where the kernels are latency-bound and keep the dword walk with 20 wavefronts per CU (1M x 128: 7.8 ms per 10k queries
+    // against 9.0 with quads — and 9.1 when the quad code merely shared the kernel).  The lone-search kernels (LAT) keep their
+    // LDS tiles.
+    if (QUAD && !LAT) {
         const int blocks = steps >> 2;
         int t = 0;
         sse_blocks_quad<L2, MN_SSE_QUAD2>(row, q_lds, j, blocks, t, s);
@@ -477,7 +479,7 @@ DEVI float rows_accumulate(const MnDevIndex &ix, const float *q_lds, int myslot,
         for (int t = 0; t < n; t += 16) {
             int r = t + (lane >> 2);
             int s = __shfl(myslot, r < n ? r : n - 1);
-            float v = sse_row<L2, LAT>(ix.vectors + (size_t)s * ix.ld, q_lds, ix.dim, lane);
+            float v = sse_row<L2, LAT, (NCH == 1)>(ix.vectors + (size_t)s * ix.ld, q_lds, ix.dim, lane); // (SSE order: NCH 1 = quad loads)
             // lane i in [t, t+16) fetches the sum from group (i - t)
             float got = __shfl(v, ((lane - t) & 15) << 2);
             if (lane >= t && lane < t + 16)

@@ -435,7 +435,13 @@ int mn_launch_search(const MnDevIndex &ix, const MnSearchArgs &a, bool build, hi
     if (a.nq <= 0)
         return 0;
     if (ix.order == MN_ORDER_SSE_V) {
-        launch_beam<MN_ORDER_SSE_V, 0>(ix, a, build, st);
+        // (NCH is the wave order's chunk count; in the reference's order it selects the row walk: 1 = float4 loads with the
+        //  in-quad transpose, for rows long enough to be bound by the memory system — mn_dist.hpp MN_SSE_QUAD2)
+        const char *qe = getenv("MN_SSE_QUAD"); // MN_SSE_QUAD=0: always the dword walk (A/B runs)
+        if (MN_SSE_QUAD2 > 0 && (ix.dim >> 4) >= MN_SSE_QUAD2 && !(qe && atoi(qe) == 0))
+            launch_beam<MN_ORDER_SSE_V, 1>(ix, a, build, st);
+        else
+            launch_beam<MN_ORDER_SSE_V, 0>(ix, a, build, st);
         return 0;
     }
     switch (pick_nch(ix.ld)) {
