@@ -31,7 +31,7 @@ while time.time() - t0 < budget:
             w = None if rng.random() < 0.5 else (rng.integers(1, 9, len(s)) * 0.25 if rng.random() < 0.5 else rng.random(len(s)) * 3 + 0.01)
             res = float(rng.choice([0.3, 1.0, 1.7]))
             csr = og.Csr(s, d, w, "both")
-            batch = int(rng.choice([1, 2, 7, 64, 1000, 100000]))
+            batch = int(rng.choice([1, 2, 7, 64, 1000, 100000, -2, -3, -3, -4]))  # < 0: whole-graph synchronous sweeps, pick-less period -batch
             tag = f"it={it} leiden n={csr.n} E={len(s)} {kind} weighted={w is not None} res={res} batch={batch}"
             oc, oq, ost = og.leiden(csr, res, batch)
             g = pkg.Graph(csr.n, csr.off_out, csr.tgt_out, csr.w_out if csr.weighted else None, csr.off_in, csr.tgt_in, csr.w_in if csr.weighted else None)

@@ -169,7 +169,9 @@ struct WaveCtx {
     int *rlog = nullptr;
     int rcap = 0, nr = 0;
     CoopCtx *coop = nullptr;
+    int no_spec_rows = 0; // MN_SPEC_ROWS=0 (host): the helpers' rows are requested only once the visited probe has answered (A/B runs)
 };
+DEVI bool getenv_spec_off(const WaveCtx &w) { return w.no_spec_rows != 0; }
 
 DEVI void log_row_read(const MnDevIndex &ix, WaveCtx &w, int node, int level, int lane) {
     if (!w.rlog)
@@ -600,23 +602,72 @@ DEVI bool beam_layer_regs(const MnDevIndex &ix, WaveCtx &w, WHeap &res, float *t
             const int c0 = WIDE ? ch << 6 : 0;
             int nb = (c0 + lane < W) ? ld_link<COH>(row + c0 + lane) : -1;
             bool todo = false;
-            if (nb >= 0) { // :403-409
-                int vi = level == 0 ? nb : ix.up_off[nb];
-                unsigned bit = 1u << (vi & 31);
-                unsigned old = atomicOr(&bitmap[vi >> 5], bit);
-                todo = !(old & bit) && !(ix.has_deleted && ix.deleted[nb]);
+            unsigned long long m;
+            int n, myslot = 0;
+            float d = 0.0f;
+            const unsigned long long m_all = __ballot(nb >= 0);
+            const int n_all = __popcll(m_all);
+            if (w.coop && w.coop->nw > 1 && n_all > 2 && !getenv_spec_off(w)) {
+                // Round 4: with helper wavefronts the rows of ALL the listed neighbours are requested before it is known which of
+                // them are new — the visited probe (a returning atomic: one more round trip) then runs next to the row loads
+                // instead of in front of them.  A wavefront's share is ≤ 4 rows either way (one pass of its tile), so the
+                // distances of already-visited neighbours cost no time; they are simply not looked at.  Same distances for the
+                // rows that count, same order.
+                const CoopCtx &c = *w.coop;
+                const int rank_all = __popcll(m_all & ((1ull << lane) - 1ull));
+                __builtin_amdgcn_wave_barrier();
+                if (nb >= 0)
+                    c.list[rank_all] = nb;
+                if (lane == 0)
+                    *c.n = n_all;
+                __syncthreads(); // the helpers start on their shares
+                unsigned old = 0, bit = 0;
+                if (nb >= 0) { // :403-409
+                    int vi = level == 0 ? nb : ix.up_off[nb];
+                    bit = 1u << (vi & 31);
+                    old = atomicOr(&bitmap[vi >> 5], bit);
+                }
+                coop_share<ORDER, NCH>(ix, w.q, c, n_all, lane);
+                __syncthreads();
+                todo = nb >= 0 && !(old & bit) && !(ix.has_deleted && ix.deleted[nb]);
+                const float d_mine = nb >= 0 ? c.dist[rank_all] : 0.0f;
+                m = __ballot(todo);
+                n = __popcll(m);
+                PH_ADD(w, 1);
+                if (n > 0) { // compact the new ones, in list order, with their distances
+                    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+                    float *dtmp = reinterpret_cast<float *>(c.list); // (the helpers are done with the list)
+                    __builtin_amdgcn_wave_barrier();
+                    if (todo) {
+                        w.scratch[rank] = nb;
+                        dtmp[rank] = d_mine;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    myslot = lane < n ? w.scratch[lane] : 0;
+                    d = lane < n ? dtmp[lane] : 0.0f;
+                    __builtin_amdgcn_wave_barrier();
+                }
+            } else {
+                if (nb >= 0) { // :403-409
+                    int vi = level == 0 ? nb : ix.up_off[nb];
+                    unsigned bit = 1u << (vi & 31);
+                    unsigned old = atomicOr(&bitmap[vi >> 5], bit);
+                    todo = !(old & bit) && !(ix.has_deleted && ix.deleted[nb]);
+                }
+                m = __ballot(todo);
+                n = __popcll(m);
+                PH_ADD(w, 1);
+                if (n > 0) {
+                    int rank = __popcll(m & ((1ull << lane) - 1ull));
+                    __builtin_amdgcn_wave_barrier();
+                    if (todo)
+                        w.scratch[rank] = nb;
+                    __builtin_amdgcn_wave_barrier();
+                    myslot = lane < n ? w.scratch[lane] : 0;
+                    d = ctx_distance<ORDER, NCH>(ix, w, myslot, n, lane);
+                }
             }
-            unsigned long long m = __ballot(todo);
-            int n = __popcll(m);
-            PH_ADD(w, 1);
             if (n > 0) {
-                int rank = __popcll(m & ((1ull << lane) - 1ull));
-                __builtin_amdgcn_wave_barrier();
-                if (todo)
-                    w.scratch[rank] = nb;
-                __builtin_amdgcn_wave_barrier();
-                int myslot = lane < n ? w.scratch[lane] : 0;
-                float d = ctx_distance<ORDER, NCH>(ix, w, myslot, n, lane);
                 w.n_dist += n;
                 PH_ADD(w, 2);
                 unsigned long long am; // (worst only falls while the row is worked through: pre-filter, as beam_layer does)

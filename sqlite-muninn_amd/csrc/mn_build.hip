@@ -126,6 +126,8 @@ __global__ void __launch_bounds__(64) k_link_reverse(MnDevIndex ix, MnLinkArgs a
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
 #endif
     const int t = a.touched[blockIdx.x];
+    if (a.world > 1 && t % a.world != a.rank)
+        return; // (divided link step: another rank replays this target and sends the row)
     const int W = a.level == 0 ? ix.W0 : ix.WU;
     const int M_max = a.M_max;
     int *list = reinterpret_cast<int *>(smem);        // [LW]  (the row, up to its full capacity, + the new link)
@@ -299,6 +301,16 @@ __global__ void __launch_bounds__(64) k_link_reverse(MnDevIndex ix, MnLinkArgs a
     }
     // stage the finished row
     int *out = a.newrows + (size_t)blockIdx.x * ix.WX;
+    if (a.world > 1) { // a record {target, row}: any order inside this rank's segment — every record names its row
+        int slot = 0;
+        if (lane == 0)
+            slot = atomicAdd(a.rec_count, 1);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        out = a.records + (size_t)slot * (1 + ix.WX);
+        if (lane == 0)
+            out[0] = t;
+        out++;
+    }
     for (int i = lane; i < W; i += 64)
         out[i] = i < nc ? list[i] : -1;
 #ifdef MN_LINK_DEBUG
@@ -343,6 +355,30 @@ __global__ void k_link_commit(MnDevIndex ix, MnLinkArgs a) {
         a.count[t] = 0;
 }
 
+// divided link step: touched targets per residue class (the all-gather's segment size), and the commit from the gathered records
+__global__ void k_link_classes(MnLinkArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.counters[1])
+        return;
+    atomicAdd(&a.cls_count[a.touched[i] % a.world], 1);
+}
+__global__ void k_link_commit_records(MnDevIndex ix, MnLinkArgs a, const int *all, int seg) {
+    const int r = blockIdx.y, k = blockIdx.x; // record k of rank r's segment
+    if (k >= a.cls_count[r])
+        return;
+    const int *rec = all + ((size_t)r * seg + k) * (1 + ix.WX);
+    const int t = rec[0];
+    const int W = a.level == 0 ? ix.W0 : ix.WU;
+    int *row = row_ptr(ix, t, a.level);
+    for (int j = threadIdx.x; j < W; j += blockDim.x)
+        row[j] = rec[1 + j];
+}
+__global__ void k_link_reset_counts(MnLinkArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.counters[1])
+        a.count[a.touched[i]] = 0;
+}
+
 static int pick_nch_b(int ld) {
     int need = (ld + 255) / 256;
     if (need <= 1) return 1;
@@ -364,6 +400,22 @@ static void launch_reverse(const MnDevIndex &ix, const MnLinkArgs &a, int max_tu
     hipLaunchKernelGGL((k_link_reverse<ORDER, NCH>), dim3(max_tuples), dim3(64), lds, st, ix, a, LW, bm_words);
 }
 
+static void launch_reverse_any(const MnDevIndex &ix, const MnLinkArgs &a, int max_tuples, hipStream_t st) {
+    if (ix.order == MN_ORDER_SSE_V) {
+        launch_reverse<MN_ORDER_SSE_V, 0>(ix, a, max_tuples, st);
+        return;
+    }
+    switch (pick_nch_b(ix.ld)) {
+    case 1: launch_reverse<MN_ORDER_WAVE_V, 1>(ix, a, max_tuples, st); break;
+    case 2: launch_reverse<MN_ORDER_WAVE_V, 2>(ix, a, max_tuples, st); break;
+    case 3: launch_reverse<MN_ORDER_WAVE_V, 3>(ix, a, max_tuples, st); break;
+    case 4: launch_reverse<MN_ORDER_WAVE_V, 4>(ix, a, max_tuples, st); break;
+    case 6: launch_reverse<MN_ORDER_WAVE_V, 6>(ix, a, max_tuples, st); break;
+    case 8: launch_reverse<MN_ORDER_WAVE_V, 8>(ix, a, max_tuples, st); break;
+    default: launch_reverse<MN_ORDER_WAVE_V, 0>(ix, a, max_tuples, st); break;
+    }
+}
+
 void mn_launch_link(const MnDevIndex &ix, const MnLinkArgs &a, int max_tuples, hipStream_t st) {
     if (a.nq <= 0)
         return;
@@ -371,18 +423,28 @@ void mn_launch_link(const MnDevIndex &ix, const MnLinkArgs &a, int max_tuples, h
     hipLaunchKernelGGL(k_link_forward, dim3((a.nq + 255) / 256), dim3(256), 0, st, ix, a, max_tuples);
     hipLaunchKernelGGL(k_link_offsets, dim3((max_tuples + 255) / 256), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_link_scatter, dim3((max_tuples + 255) / 256), dim3(256), 0, st, a, max_tuples);
-    if (ix.order == MN_ORDER_SSE_V) {
-        launch_reverse<MN_ORDER_SSE_V, 0>(ix, a, max_tuples, st);
-    } else {
-        switch (pick_nch_b(ix.ld)) {
-        case 1: launch_reverse<MN_ORDER_WAVE_V, 1>(ix, a, max_tuples, st); break;
-        case 2: launch_reverse<MN_ORDER_WAVE_V, 2>(ix, a, max_tuples, st); break;
-        case 3: launch_reverse<MN_ORDER_WAVE_V, 3>(ix, a, max_tuples, st); break;
-        case 4: launch_reverse<MN_ORDER_WAVE_V, 4>(ix, a, max_tuples, st); break;
-        case 6: launch_reverse<MN_ORDER_WAVE_V, 6>(ix, a, max_tuples, st); break;
-        case 8: launch_reverse<MN_ORDER_WAVE_V, 8>(ix, a, max_tuples, st); break;
-        default: launch_reverse<MN_ORDER_WAVE_V, 0>(ix, a, max_tuples, st); break;
-        }
-    }
+    launch_reverse_any(ix, a, max_tuples, st);
     hipLaunchKernelGGL(k_link_commit, dim3(max_tuples), dim3(64), 0, st, ix, a);
+}
+
+// divided link step, first half: everything up to this rank's share of the replay (a.world > 1; rec_count and cls_count zeroed here)
+void mn_launch_link_first(const MnDevIndex &ix, const MnLinkArgs &a, int max_tuples, hipStream_t st) {
+    if (a.nq <= 0)
+        return;
+    hipMemsetAsync(a.counters, 0, 3 * sizeof(int), st);
+    hipMemsetAsync(a.rec_count, 0, sizeof(int), st);
+    hipMemsetAsync(a.cls_count, 0, (size_t)a.world * sizeof(int), st);
+    hipLaunchKernelGGL(k_link_forward, dim3((a.nq + 255) / 256), dim3(256), 0, st, ix, a, max_tuples);
+    hipLaunchKernelGGL(k_link_offsets, dim3((max_tuples + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_link_scatter, dim3((max_tuples + 255) / 256), dim3(256), 0, st, a, max_tuples);
+    hipLaunchKernelGGL(k_link_classes, dim3((max_tuples + 255) / 256), dim3(256), 0, st, a);
+    launch_reverse_any(ix, a, max_tuples, st);
+}
+void mn_launch_link_commit_records(const MnDevIndex &ix, const MnLinkArgs &a, int max_tuples, const int *all_records, int seg,
+                                   hipStream_t st) {
+    if (a.nq <= 0)
+        return;
+    if (seg > 0)
+        hipLaunchKernelGGL(k_link_commit_records, dim3((unsigned)seg, (unsigned)a.world), dim3(64), 0, st, ix, a, all_records, seg);
+    hipLaunchKernelGGL(k_link_reset_counts, dim3((max_tuples + 255) / 256), dim3(256), 0, st, a);
 }

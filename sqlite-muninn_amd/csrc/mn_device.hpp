@@ -77,6 +77,7 @@ struct MnSearchArgs {
     // lat_tile_off for its share of a distance request (sse_rows_lat_tiled, mn_dist.hpp); 0 rows = none
     int lat_tile_rows;
     unsigned lat_tile_off;
+    int no_spec_rows; // k_beam_coop: 1 = request a neighbour's row only after the visited probe has answered (MN_SPEC_ROWS=0, A/B runs)
 };
 // dynamic LDS a workgroup of this process may ask for: 64 KB, or what the device grants on request (mn_kernels.hip)
 size_t mn_lds_optin_limit();
@@ -128,8 +129,20 @@ struct MnLinkArgs {
     int *touched;   // [max_tuples]
     int *bins;      // [max_tuples]
     int *newrows;   // [max_tuples][WX]
+    // jointly built graph (mn_hnsw_build_shared), link half divided over the ranks: rank r replays only the targets t with
+    // t % world == r and writes each finished row as a record {t, row[W]} (rec_count = records written); the records of all
+    // ranks are all-gathered and committed by every replica
+    int world, rank;
+    int *rec_count; // [1]
+    int *records;   // [this rank's targets][1 + WX]
+    int *cls_count; // [world] touched targets per residue class (the same on every rank: every rank runs the forward half)
 };
 void mn_launch_link(const MnDevIndex &ix, const MnLinkArgs &a, int max_tuples, hipStream_t st);
+// the same in two halves around the exchange of the divided link step: forward + bins + this rank's share of the replay, then —
+// once the records of all ranks are in `all_records` ([world][seg][1 + WX], cls_count valid ones per segment) — the commit
+void mn_launch_link_first(const MnDevIndex &ix, const MnLinkArgs &a, int max_tuples, hipStream_t st);
+void mn_launch_link_commit_records(const MnDevIndex &ix, const MnLinkArgs &a, int max_tuples, const int *all_records, int seg,
+                                   hipStream_t st);
 
 // exact sequential inserts (mn_seq.hip); LDS of the one workgroup (must stay within MN_LDS_LIMIT)
 #define MN_LDS_LIMIT (64 * 1024)

@@ -216,18 +216,6 @@ DEVI int best_move(const DevGraph &g, int v, const int *label, const double *sum
 }
 
 
-// best_move for SG-lane sub-groups (weighted graphs): the same decisions (staging in list order, in-order f64 sums,
-// strict-gain first-seen rule), 64/SG nodes per wavefront.  All lane exchange stays inside the aligned sub-group, so
-// sub-groups may diverge freely.  lane = absolute lane, sl = lane % SG.  Degree must be <= LEI_SG_CAP.
-// Round 4: (i) every load whose address is known goes out at once — head (lei_head), then all targets and weights, then all
-// labels and partitions, then the candidates' sum_tot while the list is scanned: four round trips where the guarded loop made
-// two per SG edges; (ii) ONE scan of the staged list serves all of a lane's LEI_SG_CAP / SG candidate edges (and
-// weight_to_community(v, old)): a third of the LDS reads of one scan per pass; (iii) the closing reduction runs on DPP.
-struct LeiHead;
-template <int SG>
-DEVI int best_move_sg(const DevGraph &g, const LeiHead &hd, const int *label, const double *sum_tot, double m, double resolution,
-                      const int *elig_part, int *ec, double *ew, unsigned char *el, int lane, int sl, double *dk_out, int pickless);
-
 // ── unweighted graphs: O(degree) evaluation ──
 // Every weight is 1.0, so weight_to_community(v, c) (:75-90) is the NUMBER of v's edges into c — an integer, exact in
 // any order — and the O(deg · #neighbour communities) rescans of the reference (and of best_move above, which keeps
@@ -284,105 +272,6 @@ template <int STEP> DEVI void lei_best_step(LeiBest &b) {
         b.c = oc;
         b.dk = od;
     }
-}
-
-template <int SG>
-DEVI int best_move_sg(const DevGraph &g, const LeiHead &hd, const int *label, const double *sum_tot, double m, double resolution,
-                      const int *elig_part, int *ec, double *ew, unsigned char *el, int lane, int sl, double *dk_out, int pickless) {
-    constexpr int PER = LEI_SG_CAP / SG; // candidate edges per lane
-    const int o0 = hd.o0, d_out = hd.d_out, i0 = hd.i0, d_in = hd.d_in;
-    const int d = d_out + d_in;
-    const int d4 = (d + 3) & ~3;
-    const int old = hd.old;
-    const int mypart = elig_part ? hd.mypart : 0;
-    const double k_v = hd.k_v;
-    if (d == 0) { // (uniform over the sub-group; the clamped loads below need one edge to clamp to)
-        *dk_out = 0.0;
-        return old;
-    }
-    const double st_old = sum_tot[old];
-    int t[PER], c[PER], part[PER];
-    double w[PER];
-#pragma unroll
-    for (int j = 0; j < PER; j++) {
-        const int ecl = max(0, min(j * SG + sl, d - 1));
-        const bool out = ecl < d_out;
-        t[j] = *(out ? g.tgt_out + o0 + ecl : g.tgt_in + i0 + (ecl - d_out));
-        const double *pw = out ? g.w_out : g.w_in;
-        w[j] = pw ? pw[out ? o0 + ecl : i0 + (ecl - d_out)] : 1.0;
-    }
-#pragma unroll
-    for (int j = 0; j < PER; j++)
-        c[j] = label[t[j]];
-#pragma unroll
-    for (int j = 0; j < PER; j++)
-        part[j] = elig_part ? elig_part[t[j]] : mypart;
-    double stc[PER];
-#pragma unroll
-    for (int j = 0; j < PER; j++) {
-        const int e = j * SG + sl;
-        if (e < d4) {
-            const bool in = e < d;
-            ec[e] = in ? c[j] : -2; // padding never matches a community
-            ew[e] = in ? w[j] : 0.0;
-            el[e] = in && part[j] == mypart ? 1 : 0;
-        }
-        stc[j] = sum_tot[c[j]]; // consumed after the scan
-    }
-    __builtin_amdgcn_wave_barrier();
-    const int4 *ec4 = reinterpret_cast<const int4 *>(ec);
-    const double2 *ew2 = reinterpret_cast<const double2 *>(ew);
-    const uchar4 *el4 = reinterpret_cast<const uchar4 *>(el);
-    double k_v_to_old = 0.0, sacc[PER];
-    bool dup[PER];
-#pragma unroll
-    for (int p = 0; p < PER; p++) {
-        sacc[p] = 0.0;
-        dup[p] = false;
-    }
-    // one pass over the list: weight_to_community(v, old) (:163), and for each of the lane's candidate edges the in-order
-    // weight sum of its community (:206) and "an eligible earlier edge already carries it" (the dedup scan of :173-199)
-    for (int q = 0; q < (d4 >> 2); q++) {
-        const int4 cj = ec4[q];
-        const double2 wa = ew2[2 * q], wb = ew2[2 * q + 1];
-        const uchar4 ej = el4[q];
-        const int j = q << 2;
-        if (cj.x == old) k_v_to_old += wa.x;
-        if (cj.y == old) k_v_to_old += wa.y;
-        if (cj.z == old) k_v_to_old += wb.x;
-        if (cj.w == old) k_v_to_old += wb.y;
-#pragma unroll
-        for (int p = 0; p < PER; p++) {
-            const int e = p * SG + sl;
-            if (cj.x == c[p]) { sacc[p] += wa.x; dup[p] |= (j < e) && ej.x; }
-            if (cj.y == c[p]) { sacc[p] += wa.y; dup[p] |= (j + 1 < e) && ej.y; }
-            if (cj.z == c[p]) { sacc[p] += wb.x; dup[p] |= (j + 2 < e) && ej.z; }
-            if (cj.w == c[p]) { sacc[p] += wb.y; dup[p] |= (j + 3 < e) && ej.w; }
-        }
-    }
-    // max gain, lowest edge position on ties == the first candidate with the strictly largest gain (:212)
-    LeiBest b = {-1.0, 0.0, 0x7fffffff, old};
-#pragma unroll
-    for (int p = 0; p < PER; p++) {
-        const int e = p * SG + sl;
-        if (e >= d || part[p] != mypart || c[p] == old || dup[p] || (pickless && c[p] > old))
-            continue;
-        const double gain = (sacc[p] - k_v_to_old) / m + resolution * k_v * (st_old - k_v - stc[p]) / (2.0 * m * m); // :209-210
-        if (gain > 0.0 && gain > b.gain) { // (also drops NaN)
-            b.gain = gain;
-            b.pos = e;
-            b.c = c[p];
-            b.dk = sacc[p] - k_v_to_old;
-        }
-    }
-    lei_best_step<0>(b);
-    lei_best_step<1>(b);
-    lei_best_step<2>(b);
-    lei_best_step<3>(b);
-    if (SG > 16)
-        lei_best_step<4>(b);
-    *dk_out = b.gain > 0.0 ? b.dk : 0.0;
-    return b.gain > 0.0 ? b.c : old;
 }
 
 // Round 4 (the kernel is bound by the LDS pipe): (i) only the KEYS are cleared, four per ds_write_b128 — whoever inserts a key
@@ -488,6 +377,160 @@ DEVI int best_move_hash(const DevGraph &g, const LeiHead &hd, const int *label, 
         const double sacc = (double)tc[slot];
         const double st_c = sum_tot[c];
         double gain = (sacc - k_v_to_old) / m + resolution * k_v * (st_old - k_v - st_c) / (2.0 * m * m); // :209-210
+        if (!(gain > 0.0))
+            continue;
+        if (gain > b.gain || (gain == b.gain && pos < b.pos)) {
+            b.gain = gain;
+            b.pos = pos;
+            b.c = c;
+            b.dk = sacc - k_v_to_old;
+        }
+    }
+    lei_best_step<0>(b);
+    lei_best_step<1>(b);
+    lei_best_step<2>(b);
+    lei_best_step<3>(b);
+    if (SG > 16)
+        lei_best_step<4>(b);
+    if (SG > 32)
+        lei_best_step<5>(b);
+    *dk_out = b.gain > 0.0 ? b.dk : 0.0;
+    return b.gain > 0.0 ? b.c : old;
+}
+
+// ── weighted graphs: O(degree · distinct communities / lanes) evaluation (round 4) ──
+// weight_to_community(v, c) (:75-90) is an f64 sum in LIST ORDER, so the hash-and-count shortcut of the unweighted path does not
+// apply — but the sum does not have to be taken once per EDGE (best_move: every lane sums the community of its own edge, most of
+// them the same few communities: O(degree²) compare-and-add steps, 70 % of a weighted run).  Here every edge is hashed to its
+// community's table slot (as in best_move_hash; the slot remembers the first eligible position), communities are numbered in
+// the order they were inserted, and lane p OWNS community number p: one walk over the staged list in order, adding the weights
+// of the edges whose community number is p — the reference's additions in the reference's order, once per distinct community.
+// Sixteen lanes cover sixteen communities per walk; once communities have formed a node's neighbours lie in a handful.
+DEVI size_t lei_wslots_bytes(int cap, int log2h) { return (size_t)20 * cap + (size_t)10 * (1 << log2h) + 16; }
+template <int SG>
+DEVI int best_move_wslots(const DevGraph &g, const LeiHead &hd, const int *label, const double *sum_tot, double m, double resolution,
+                          const int *elig_part, unsigned char *area, int cap, int log2h, int lane, int sl, double *dk_out,
+                          int pickless) {
+    const int H = 1 << log2h;
+    double *ew = reinterpret_cast<double *>(area);           // [cap] weights in list order (padding 0.0)
+    double *ssum = ew + cap;                                  // [cap] in-order weight sum of community number p
+    int *tk = reinterpret_cast<int *>(ssum + cap);            // [H] community of a slot
+    int *tp = tk + H;                                         // [H] first eligible position
+    unsigned short *tpos = reinterpret_cast<unsigned short *>(tp + H); // [H] slot -> community number
+    unsigned short *spos = tpos + H;                          // [cap] community number -> slot
+    unsigned short *es = spos + cap;                          // [cap] edge -> slot, then edge -> community number (padding 0xFFFF)
+    int *cnt = reinterpret_cast<int *>(es + cap);
+    const int o0 = hd.o0, d_out = hd.d_out, i0 = hd.i0, d_in = hd.d_in;
+    const int d = d_out + d_in;
+    const int d4 = (d + 3) & ~3;
+    const int old = hd.old;
+    const int mypart = elig_part ? hd.mypart : 0;
+    const double k_v = hd.k_v;
+    *dk_out = 0.0;
+    if (d == 0)
+        return old;
+    const double st_old = sum_tot[old];
+    for (int j = 4 * sl; j < H; j += 4 * SG)
+        *reinterpret_cast<int4 *>(tk + j) = make_int4(LEI_EMPTY, LEI_EMPTY, LEI_EMPTY, LEI_EMPTY);
+    if (sl == 0)
+        cnt[0] = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (int e0 = 0; e0 < d4; e0 += 4 * SG) { // four edges per lane in flight: targets + weights, then labels (+ partitions)
+        int t[4], c[4], part[4];
+        double w[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int ecl = min(e0 + j * SG + sl, d - 1);
+            const bool out = ecl < d_out;
+            t[j] = *(out ? g.tgt_out + o0 + ecl : g.tgt_in + i0 + (ecl - d_out));
+            const double *pw = out ? g.w_out : g.w_in;
+            w[j] = pw ? pw[out ? o0 + ecl : i0 + (ecl - d_out)] : 1.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            c[j] = label[t[j]];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            part[j] = elig_part ? elig_part[t[j]] : mypart;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int e = e0 + j * SG + sl;
+            if (e >= d4)
+                continue;
+            if (e >= d) {
+                ew[e] = 0.0;
+                es[e] = 0xFFFF;
+                continue;
+            }
+            ew[e] = w[j];
+            unsigned h = lei_hash(c[j], log2h);
+            for (;;) {
+                int prev = tk[h];
+                if (prev == LEI_EMPTY) {
+                    prev = atomicCAS(&tk[h], LEI_EMPTY, c[j]);
+                    if (prev == LEI_EMPTY) { // (the inserter numbers the community; LDS operations of a wavefront run in order)
+                        const int p = atomicAdd(&cnt[0], 1);
+                        tpos[h] = (unsigned short)p;
+                        spos[p] = (unsigned short)h;
+                        tp[h] = 0x7fffffff;
+                    }
+                }
+                if (prev == LEI_EMPTY || prev == c[j])
+                    break;
+                h = (h + 1) & (H - 1);
+            }
+            es[e] = (unsigned short)h;
+            if (part[j] == mypart)
+                atomicMin(&tp[h], e);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    for (int e = sl; e < d; e += SG) // slot -> community number
+        es[e] = tpos[es[e]];
+    __builtin_amdgcn_wave_barrier();
+    const int ncomm = cnt[0];
+    const ushort4 *es4 = reinterpret_cast<const ushort4 *>(es);
+    const double2 *ew2 = reinterpret_cast<const double2 *>(ew);
+    for (int p0 = 0; p0 < ncomm; p0 += SG) { // lane p walks the list for community number p: list-order f64 sum (:75-90)
+        const int p = p0 + sl;
+        const unsigned short my = p < ncomm ? (unsigned short)p : (unsigned short)0xFFFE;
+        double acc = 0.0;
+        for (int q = 0; q < (d4 >> 2); q++) {
+            const ushort4 e4 = es4[q];
+            const double2 wa = ew2[2 * q], wb = ew2[2 * q + 1];
+            if (e4.x == my) acc += wa.x;
+            if (e4.y == my) acc += wa.y;
+            if (e4.z == my) acc += wb.x;
+            if (e4.w == my) acc += wb.y;
+        }
+        if (p < ncomm)
+            ssum[p] = acc;
+    }
+    __builtin_amdgcn_wave_barrier();
+    double k_v_to_old = 0.0; // weight_to_community(v, old), :163
+    {
+        unsigned h = lei_hash(old, log2h);
+        for (int probe = 0; probe < H; probe++) {
+            const int key = tk[h];
+            if (key == old) {
+                k_v_to_old = ssum[tpos[h]];
+                break;
+            }
+            if (key == LEI_EMPTY)
+                break;
+            h = (h + 1) & (H - 1);
+        }
+    }
+    LeiBest b = {-1.0, 0.0, 0x7fffffff, old};
+    for (int p = sl; p < ncomm; p += SG) { // max gain, ties to the lowest first eligible position = the first-seen rule (:212)
+        const int h = spos[p];
+        const int c = tk[h], pos = tp[h];
+        if (c == old || pos == 0x7fffffff || (pickless && c > old))
+            continue;
+        const double sacc = ssum[p];
+        const double st_c = sum_tot[c];
+        const double gain = (sacc - k_v_to_old) / m + resolution * k_v * (st_old - k_v - st_c) / (2.0 * m * m); // :209-210
         if (!(gain > 0.0))
             continue;
         if (gain > b.gain || (gain == b.gain && pos < b.pos)) {
@@ -640,11 +683,9 @@ __global__ void __launch_bounds__(64 * LEI_WPB) k_leiden_eval(LeiArgs a, int nsm
             if (hd.d_out + hd.d_in > LEI_SG_CAP)
                 return;
             old = hd.old;
-            double *lds_w = reinterpret_cast<double *>(lei_smem);
-            int *lds_c = reinterpret_cast<int *>(lds_w + NG * LEI_SG_CAP);
-            unsigned char *lds_e = reinterpret_cast<unsigned char *>(lds_c + NG * LEI_SG_CAP);
-            best = best_move_sg<SG>(a.g, hd, a.label, a.sum_tot, a.m, a.resolution, a.elig_part, lds_c + grp * LEI_SG_CAP,
-                                    lds_w + grp * LEI_SG_CAP, lds_e + grp * LEI_SG_CAP, lane, sl, &dk, a.pickless);
+            unsigned char *area = lei_smem + (size_t)grp * lei_wslots_bytes(LEI_SG_CAP, LEI_SG_LOG2H - 1);
+            best = best_move_wslots<SG>(a.g, hd, a.label, a.sum_tot, a.m, a.resolution, a.elig_part, area, LEI_SG_CAP, LEI_SG_LOG2H - 1,
+                                        lane, sl, &dk, a.pickless);
         }
         if (sl == 0)
             lei_tally(a, v, old, best, dk);
@@ -667,11 +708,9 @@ __global__ void __launch_bounds__(64 * LEI_WPB) k_leiden_eval(LeiArgs a, int nsm
         best = best_move_hash<64>(a.g, hd, a.label, a.sum_tot, a.m, a.resolution, a.elig_part, tk, tk + H, tk + 2 * H, tk + 3 * H,
                                   lg, lane, lane, &dk, a.pickless);
     } else if (deg <= a.lds_cap) {
-        double *lds_w = reinterpret_cast<double *>(lei_smem);
-        int *lds_c = reinterpret_cast<int *>(lds_w + a.lds_cap);
-        unsigned char *lds_e = reinterpret_cast<unsigned char *>(lds_c + a.lds_cap);
-        best = best_move<false>(a.g, v, a.label, a.sum_tot, a.kdeg, a.m, a.resolution, a.use_both, a.elig_part, lds_c, lds_w,
-                                lds_e, lane, &dk, a.pickless);
+        const LeiHead hd = lei_head(a.g, v, a.label, a.kdeg, a.use_both, a.elig_part);
+        best = best_move_wslots<64>(a.g, hd, a.label, a.sum_tot, a.m, a.resolution, a.elig_part, lei_smem, a.lds_cap, a.big_log2h, lane,
+                                    lane, &dk, a.pickless);
     } else { // more edges than fit in LDS: global scratch, list-order sums
         const size_t o = (size_t)a.bigoff[a.big0 + bi]; // this node's own region (only nodes past LEI_CAP have one)
         best = best_move<false>(a.g, v, a.label, a.sum_tot, a.kdeg, a.m, a.resolution, a.use_both, a.elig_part, a.scratch_c + o,
@@ -681,13 +720,14 @@ __global__ void __launch_bounds__(64 * LEI_WPB) k_leiden_eval(LeiArgs a, int nsm
         lei_tally(a, v, a.label[v], best, dk);
 }
 
+static size_t lei_wslots_bytes_h(int cap, int log2h) { return (size_t)20 * cap + (size_t)10 * ((size_t)1 << log2h) + 16; }
 // LDS bytes of one k_leiden_eval workgroup
 static size_t lei_eval_lds(int sg, bool hash, int lds_cap, int big_log2h, int sg_log2h) {
     const int ng = 64 / sg;
-    const size_t small = hash ? (size_t)ng * LEI_SG_AREA_OF(sg_log2h) * sizeof(int) : (size_t)ng * LEI_SG_CAP * 13;
+    const size_t small = hash ? (size_t)ng * LEI_SG_AREA_OF(sg_log2h) * sizeof(int) : (size_t)ng * lei_wslots_bytes_h(LEI_SG_CAP, LEI_SG_LOG2H - 1);
     // table (3 ints per entry) + occupied-entry list: a counter (16 B) and one 16-bit slot per edge
     const size_t big = hash ? (size_t)3 * ((size_t)1 << big_log2h) * sizeof(int) + 16 + (((size_t)lds_cap * 2 + 15) & ~(size_t)15)
-                            : (size_t)lds_cap * 13;
+                            : lei_wslots_bytes_h(lds_cap, big_log2h);
     return small > big ? small : big;
 }
 

@@ -142,6 +142,7 @@ struct mn_index {
     DevBuf<long long> ws_outi;
     DevBuf<int> ws_outc, ws_qslots, ws_sel, ws_nsel, ws_upidx;
     DevBuf<int> lk_target, lk_src, lk_counters, lk_count, lk_fill, lk_binoff, lk_touched, lk_bins, lk_newrows;
+    DevBuf<int> lk_rec, lk_rec_all, lk_cls; // divided link step of the jointly built graph: this rank's records, everybody's, class counts
     DevBuf<unsigned long long> ws_counters;
     DevBuf<int> ws_state;
     DevBuf<int> er_slot, er_level, er_nbr;
@@ -671,6 +672,7 @@ extern "C" void mn_hnsw_destroy(mn_index *x) {
     x->ws_nsel.release(); x->ws_upidx.release(); x->lk_target.release(); x->lk_src.release(); x->lk_counters.release();
     x->lk_count.release(); x->lk_fill.release(); x->lk_binoff.release(); x->lk_touched.release(); x->lk_bins.release();
     x->lk_newrows.release(); x->ws_counters.release(); x->ws_state.release();
+    x->lk_rec.release(); x->lk_rec_all.release(); x->lk_cls.release();
     x->er_slot.release(); x->er_level.release(); x->er_nbr.release(); x->er_dist.release();
     x->d_staged.release();
     x->sh_sel.release(); x->sh_nsel.release(); x->sh_gcnt.release(); x->sh_lcnt.release(); x->sh_ovf.release(); x->ws_chlog.release(); x->sh_gids.release();
@@ -733,6 +735,12 @@ static int prepare_search_ws(mn_index *x, int64_t nq, int ef, MnSearchArgs &a, b
     a.bitmap_up = nullptr;
     a.bmu_words = 0;
     {
+        // the latency kernels request the rows of ALL listed neighbours next to the visited probe only when the vectors do not
+        // fit the 256 MB Infinity Cache (a row is then an HBM round trip worth hiding: 1M x 768, one query 1.575 -> 1.52 ms);
+        // on a cache-resident index the extra rows cost more than the probe (10k x 768: 0.58 -> 0.61 ms).  MN_SPEC_ROWS=0 / 1 forces.
+        const char *sr = getenv("MN_SPEC_ROWS");
+        const bool big = (size_t)x->n_slots * x->ld * sizeof(float) > ((size_t)256 << 20);
+        a.no_spec_rows = sr ? (atoi(sr) == 0 ? 1 : 0) : (big ? 0 : 1);
 #ifdef MN_SSE_TILE_PATH
         const char *e = getenv("MN_SSE_TILE"); // tuning knob of the opt-in tiled SSE path
         a.use_tile = e ? atoi(e) : 1;
@@ -1001,7 +1009,7 @@ static int build_search(mn_index *x, const int *slots, int nq, MnSearchArgs &a, 
 // link half of a group of inserts: nq batch nodes (device array of their slots) with their selected lists; then the
 // entry point / top layer update in batch order (src/hnsw_algo.c:660-663)
 static int link_batch(mn_index *x, const std::vector<int> &slots, const int *d_slots, int nlev, const int *d_sel,
-                      const int *d_nsel) {
+                      const int *d_nsel, mn_comm *c = nullptr) {
     hipStream_t st = x->stream;
     const int nq = (int)slots.size();
     MnDevIndex v = dev_view(x);
@@ -1031,11 +1039,61 @@ static int link_batch(mn_index *x, const std::vector<int> &slots, const int *d_s
     la.touched = x->lk_touched.p;
     la.bins = x->lk_bins.p;
     la.newrows = x->lk_newrows.p;
-    for (int l = 0; l < nlev; l++) {
-        la.level = l;
-        la.M_max = l == 0 ? x->M_max0 : x->M;
-        int mt = l == 0 ? max_tuples : nq * x->M;
-        mn_launch_link(v, la, mt, st);
+    const int world = c ? c->world : 1, rank = c ? c->rank : 0;
+    if (world > 1) {
+        // Jointly built graph: the replay of the reverse edges — the bulk of the link half — is divided over the ranks by
+        // target (slot mod world).  Every rank runs the cheap forward half, so it knows every class's target count; it replays
+        // its own class, the finished rows travel as {target, row} records in one all-gather per layer, and every replica
+        // commits all of them: the same rows as a one-GPU build, whoever computed them.
+        const int recsz = 1 + std::max(x->W0, x->WU);
+        if (x->lk_rec.reserve((size_t)max_tuples * recsz, false, st) || x->lk_cls.reserve((size_t)world + 1, false, st))
+            return -1;
+        la.world = world;
+        la.rank = rank;
+        la.records = x->lk_rec.p;
+        la.cls_count = x->lk_cls.p;
+        la.rec_count = x->lk_cls.p + world;
+        std::vector<int> cls((size_t)world);
+        for (int l = 0; l < nlev; l++) {
+            la.level = l;
+            la.M_max = l == 0 ? x->M_max0 : x->M;
+            const int mt = l == 0 ? max_tuples : nq * x->M;
+            mn_launch_link_first(v, la, mt, st);
+            int status = hipGetLastError() != hipSuccess ||
+                         hipMemcpyAsync(cls.data(), x->lk_cls.p, (size_t)world * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                         hipStreamSynchronize(st) != hipSuccess;
+            int seg = 0;
+            for (int r = 0; r < world && !status; r++)
+                seg = std::max(seg, cls[(size_t)r]);
+            if (!status && seg > 0 && x->lk_rec_all.reserve((size_t)world * seg * recsz, false, st))
+                status = 1;
+            int failed = -1;
+            const int ag = mn_comm_agree(c, status, st, &failed); // (a rank that cannot go on says so before the collective)
+            if (ag) {
+                if (ag < 0)
+                    set_err("mn_hnsw_build_shared: %s", mn_comm_last_error_str());
+                else
+                    set_err("mn_hnsw_build_shared: rank %d failed in the link step; all ranks stop", failed);
+                return -1;
+            }
+            if (seg > 0) {
+                int *mine = x->lk_rec_all.p + (size_t)rank * seg * recsz;
+                if (cls[(size_t)rank] > 0)
+                    HIPCHK(hipMemcpyAsync(mine, x->lk_rec.p, (size_t)cls[(size_t)rank] * recsz * sizeof(int), hipMemcpyDeviceToDevice, st));
+                if (mn_comm_allgather_dev(c, mine, x->lk_rec_all.p, (size_t)seg * recsz * sizeof(int), st)) {
+                    set_err("mn_hnsw_build_shared: %s", mn_comm_last_error_str());
+                    return -1;
+                }
+            }
+            mn_launch_link_commit_records(v, la, mt, x->lk_rec_all.p, seg, st);
+        }
+    } else {
+        for (int l = 0; l < nlev; l++) {
+            la.level = l;
+            la.M_max = l == 0 ? x->M_max0 : x->M;
+            int mt = l == 0 ? max_tuples : nq * x->M;
+            mn_launch_link(v, la, mt, st);
+        }
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(x->ev2, st));
@@ -1570,13 +1628,16 @@ extern "C" int mn_hnsw_batch_search(mn_index *x, int lo, int hi, int *d_sel, int
     return 0;
 } MN_GUARD_END(set_err, if (x) x->broken = true, -1)
 
-extern "C" int mn_hnsw_batch_link(mn_index *x, const int *d_sel, const int *d_nsel) try {
+static int batch_link_impl(mn_index *x, const int *d_sel, const int *d_nsel, mn_comm *c) {
     MN_STAGE_CHECK(x)
     std::vector<int> slots;
     slots.swap(x->staged);
     if (slots.empty())
         return 0;
-    return link_batch(x, slots, x->d_staged.p, x->max_level + 1, d_sel, d_nsel);
+    return link_batch(x, slots, x->d_staged.p, x->max_level + 1, d_sel, d_nsel, c);
+}
+extern "C" int mn_hnsw_batch_link(mn_index *x, const int *d_sel, const int *d_nsel) try {
+    return batch_link_impl(x, d_sel, d_nsel, nullptr);
 } MN_GUARD_END(set_err, if (x) x->broken = true, -1)
 
 // ───────────────────────── multi-GPU: shared build, sharded search ─────────────────────────
@@ -1660,7 +1721,8 @@ extern "C" int mn_hnsw_build_shared(mn_index *x, mn_comm *c, const int64_t *ids,
                 return -1;
             }
         }
-        if (mn_hnsw_batch_link(x, x->sh_sel.p, x->sh_nsel.p)) { // every replica links the whole batch
+        // every replica links the whole batch; with a divided batch the reverse edges' replay is divided too (link_batch)
+        if (batch_link_impl(x, x->sh_sel.p, x->sh_nsel.p, split && !getenv("MN_SHARED_LINK_REPLICATED") ? c : nullptr)) {
             x->broken = true;
             return -1;
         }

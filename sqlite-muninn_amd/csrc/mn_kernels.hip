@@ -182,6 +182,7 @@ DEVI void beam_query(const MnDevIndex &ix, const MnSearchArgs &a, const long lon
         w.qnorm = BUILD ? ix.norms[qslot] : lds_self_norm<ORDER>(q, ix.dim, ix.ld, lane);
     if (coop) {
         w.coop = coop;
+        w.no_spec_rows = a.no_spec_rows;
         if (lane == 0)
             *coop->qnorm = w.qnorm;
     }

@@ -163,59 +163,19 @@ DEVI void n2v_score_chunk(const N2vArgs &a, const N2vBatchArgs &b, unsigned &rng
             }
         }
     float tot[PF];
-#ifdef MN_N2V_MULTI_REDUCE
-    if (FULL && PF == 6) {
-        // The six dot products of a pair reduced TOGETHER (round 4).  Six xor butterflies are 36 lane exchanges; here a lane
-        // keeps half of its values at each of the first steps and gives the other half to its partner — after xor 32 it holds
-        // three pair sums, after xor 16 two or one, after xor 8 one — and the last three steps run on that one value: 3 + 2 +
-        // 1 + 3 = 9 exchanges.  Every kept sum is own + partner's of the same two operands the butterfly adds at that step
-        // (addition commutes), so each total has the butterfly's association and bits; value k ends in lane {0, 8, 16, 32, 40,
-        // 48}[k] and is broadcast from there.
-        float a6[6];
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
+    for (int i = 0; i < PF; i++)
+        if (FULL || i < nd) {
             float acc = 0.0f;
 #pragma unroll
             for (int r = 0; r < NR; r++)
                 if (lane + 64 * r < dim)
-                    acc = fmaf(vc[r], tr[i < PF ? i : 0][r], acc);
-            a6[i] = acc;
+                    acc = fmaf(vc[r], tr[i][r], acc);
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1)
+                acc = __fadd_rn(acc, __shfl_xor(acc, m));
+            tot[i] = acc;
         }
-        const bool h = lane & 32, g = lane & 16, f = lane & 8;
-        float k0 = h ? a6[3] : a6[0], k1 = h ? a6[4] : a6[1], k2 = h ? a6[5] : a6[2];
-        const float g0 = h ? a6[0] : a6[3], g1 = h ? a6[1] : a6[4], g2 = h ? a6[2] : a6[5];
-        k0 = __fadd_rn(k0, __shfl_xor(g0, 32));
-        k1 = __fadd_rn(k1, __shfl_xor(g1, 32));
-        k2 = __fadd_rn(k2, __shfl_xor(g2, 32));
-        const float ra = __shfl_xor(g ? k0 : k2, 16), rb = __shfl_xor(k1, 16);
-        const float u0 = __fadd_rn(g ? k2 : k0, ra), u1 = __fadd_rn(k1, rb); // (bit 4 set: u0 is value 2 of the half, u1 unused)
-        const float r8 = __shfl_xor(g ? u0 : (f ? u0 : u1), 8);
-        float tt = __fadd_rn(g ? u0 : (f ? u1 : u0), r8);
-        tt = __fadd_rn(tt, __shfl_xor(tt, 4));
-        tt = __fadd_rn(tt, __shfl_xor(tt, 2));
-        tt = __fadd_rn(tt, __shfl_xor(tt, 1));
-        const int ti = __float_as_int(tt);
-        const int src[6] = {0, 8, 16, 32, 40, 48};
-#pragma unroll
-        for (int i = 0; i < 6; i++)
-            tot[i < PF ? i : 0] = __int_as_float(__builtin_amdgcn_readlane(ti, src[i]));
-    } else
-#endif
-    {
-#pragma unroll
-        for (int i = 0; i < PF; i++)
-            if (FULL || i < nd) {
-                float acc = 0.0f;
-#pragma unroll
-                for (int r = 0; r < NR; r++)
-                    if (lane + 64 * r < dim)
-                        acc = fmaf(vc[r], tr[i][r], acc);
-#pragma unroll
-                for (int m = 32; m >= 1; m >>= 1)
-                    acc = __fadd_rn(acc, __shfl_xor(acc, m));
-                tot[i] = acc;
-            }
-    }
 #pragma unroll
     for (int i = 0; i < PF; i++)
         if (FULL || i < nd) {
@@ -238,7 +198,9 @@ DEVI void n2v_score_chunk(const N2vArgs &a, const N2vBatchArgs &b, unsigned &rng
 // next pair's targets drawn and its rows requested before this pair is scored — doubles the live registers (125 VGPRs, 4
 // wavefronts per SIMD instead of 8) and is twice as slow (18.7 vs 9.5 ms per batch); (ii) drawing only the next pair's targets
 // ahead, so that the negative-table gather leaves the per-pair chain, still costs 84 VGPRs (5 wavefronts per SIMD): 1.61 vs
-// 1.27 s.  What this kernel lives on is wavefronts in flight, not a shorter chain per wavefront.
+// 1.27 s; (iii) reducing a pair's six dot products together (a lane keeps half of its values at each of the first butterfly steps:
+// 9 lane exchanges instead of 36, same association and bits) is 1.24 vs 1.26 s — the reductions are not what bounds it.  What
+// this kernel lives on is wavefronts in flight, not a shorter chain per wavefront.
 template <int NR> // NR = ceil(dim / 64) register slots per lane
 __global__ void __launch_bounds__(64) k_n2v_walk_grad(N2vBatchArgs b) {
     extern __shared__ __align__(16) unsigned char smem[];

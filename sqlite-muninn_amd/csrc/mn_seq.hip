@@ -40,6 +40,7 @@ struct MnSeqArgs {
     // every wavefront's own LDS scratch, wave_floats each: the owner vector of a precomputed prune, and (SSE order) the
     // mn_lat_tile_floats(ld, lat_tile_rows) tile of its share of a search's distance request (sse_rows_lat_tiled) — never both at once
     int wave_floats, lat_tile_rows;
+    int no_spec_rows; // MN_SPEC_ROWS=0: see MnSearchArgs
 };
 #define MN_CH_INTS 5
 
@@ -172,6 +173,7 @@ __global__ void __launch_bounds__(MN_SEQ_WAVES * 64) k_insert_seq(MnDevIndex ix,
 
     WaveCtx w;
     w.coop = &coop; // (works alone too: with one wavefront a request is simply its own share)
+    w.no_spec_rows = a.no_spec_rows;
     w.q = q;
     w.scratch = scratch;
     w.n_dist = 0;
@@ -421,6 +423,11 @@ void mn_launch_insert_seq(const MnDevIndex &ix, const int *d_slots, int n, int e
     if (pe && atoi(pe) == 0)
         pre = 0;
     a.pre_rows = a.pre_w = a.wave_floats = a.lat_tile_rows = 0;
+    {
+        const char *sr = getenv("MN_SPEC_ROWS"); // (see prepare_search_ws, mn_index.hip: only for indexes beyond the Infinity Cache)
+        const bool big = (size_t)ix.n_slots * ix.ld * sizeof(float) > ((size_t)256 << 20);
+        a.no_spec_rows = sr ? (atoi(sr) == 0 ? 1 : 0) : (big ? 0 : 1);
+    }
     const size_t lds0 = lds;
     const char *te = getenv("MN_LAT_TILE"); // MN_LAT_TILE=0: no distance tiles
     for (int rows = ix.order == MN_ORDER_SSE_V && ix.ld >= 256 && !(te && atoi(te) == 0) ? 4 : 0; rows >= 0; rows = rows == 4 ? 2 : rows == 2 ? 0 : -1) {

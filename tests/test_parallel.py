@@ -227,16 +227,18 @@ def _build_worker(rank, world, port, q):
 
 
 @pytest.mark.gpu
-def test_build_shared_by_two_ranks_equals_one_gpu_build(gpu):
-    """parallel.build_distributed: two replicas (gloo exchange, both on the box's one GPU) split the search half of
-    every batch and all-gather the selected lists; each must end with exactly the graph mn_hnsw_build makes alone."""
+@pytest.mark.parametrize("world", [2, 4])
+def test_build_shared_by_two_ranks_equals_one_gpu_build(gpu, world):
+    """parallel.build_distributed: 2 and 4 replicas (gloo exchange, all on the box's one GPU) split the search half of
+    every batch and all-gather the selected lists, and (round 4) divide the link half too — each rank replays the reverse edges
+    of the targets with slot mod world == rank and the finished rows travel as records; each must end with exactly the graph
+    mn_hnsw_build makes alone (layer 0 and layer 1 rows, entry point, top layer)."""
     X = np.random.default_rng(77).standard_normal((6000, 24)).astype(np.float32)
     ids = np.arange(5, 6005, dtype=np.int64)
     g = gpu.HnswIndex(24, "cosine", 8, 60)
     assert g.build(ids, X, 16, 1024) == 0
     want = (g.export_links(0), g.export_links(1), g.entry_point, g.max_level)
     g.close()
-    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
