@@ -419,157 +419,65 @@ DEVI void beam_layer(const MnDevIndex &ix, WaveCtx &w, WHeap &cand, WHeap &res, 
 
 
 
-// ───────────────────────── the same search with its two queues in registers ─────────────────────────
+// ───────────────────────── the same search with its queues in registers ─────────────────────────
 // One search is a latency chain, and with the binary heaps above most of a link of that chain is heap maintenance
 // (MN_PHASE_TIMING, 10k x 128: of 7.7 us per expansion, 1.5 us is the candidates' pop — the heap's deeper levels live
 // in global memory — and 4.6 us are ≈ 4 × {push, pop, push}, against 1.3 us for the distances).  Where latency is what
-// counts — one query per launch (the SQL surface), one insert, a window of speculative inserts — the two queues are
-// kept as UNSORTED arrays spread over the wavefront's registers (element e in register e / 64 of lane e % 64, empty
-// places hold NaN) with the one element each queue is asked for cached: the nearest candidate, the worst result.
-//   insert          = one v_writelane per word at the end of the array (+ compare with the cached element)
-//   pop the nearest = move the last element into its place, then a DPP min-reduction over the wavefront finds the next
-//   replace worst   = overwrite it in place, then a max-reduction finds the next worst
-// No memory is touched.  A priority queue's answers do not depend on its shape as long as no two keys in it are equal;
-// the reference's binary heap decides ties by its shape (src/priority_queue.c:56-80).  So every insert first tests the
-// queue for an equal key (four compares) and for NaN: at the first one the layer is searched again from the start by
-// beam_layer with the real heaps.  Results are ranked once at the end and handed over as the result heap the callers
-// drain (a descending array is a heap; `sorted` tells them they may read it directly).
-// ef ≤ 256 (4 registers per lane and queue).  When more than 256 candidates are alive the farthest is overwritten,
-// which is exact: with more than ef candidates alive it is farther than the worst result and could only ever end the
-// loop (checked; otherwise → the heaps).
+// counts — one query per launch (the SQL surface), one insert, a window of speculative inserts — the queues live in the
+// wavefront's registers.
+//
+// Round 4: ONE sorted array serves as both queues.  A priority queue's answers do not depend on its shape as long as no
+// two keys in it are equal (the reference's binary heap decides ties by its shape, src/priority_queue.c:56-80), so while
+// keys are distinct the loop of src/hnsw_algo.c:376-433 can be restated on sets:
+//   * the results W are the ef nearest of everything evaluated so far;
+//   * a candidate that is not in W is farther than W's worst, and the worst only falls: popping it could only ever end
+//     the loop (:382-386) — it is "dead".  The live candidates are exactly the members of W that have not been expanded.
+// So W is kept sorted by distance, rank r in register r / 64 of lane r % 64 (≤ 4 registers per lane: ef ≤ 256), with an
+// "expanded" flag in the sign bit of the slot word:
+//   pop the nearest candidate = the first member without the flag (one ballot per register in use); none → the loop ends
+//                               as the reference's does (candidates empty, or only dead ones left);
+//   a row's new distances     = ONE merge for all of them instead of a push / pop / push per element: every new distance
+//                               below the worst result is counted against the array (two compares and two popcounts per
+//                               register in use: members before it, members after it — which shift up by one) and against
+//                               the other new ones; then members and newcomers are written to their new ranks in LDS and
+//                               read back rank-major.  Whatever lands at rank ≥ ef is gone (dead, see above).
+// "before + after ≠ everybody" means an equal key (or a NaN): the layer is then searched again from its start by
+// beam_layer with the real heaps (beam_layer_auto), exactly as before.  The patience counter (:428-432) needs to know
+// whether ANY push happened in a row: the first new distance below the row's initial worst is always pushed, and if there
+// is none nothing is, so "any" = "a merge took place".
+// Measured against round 3's two unsorted arrays with cached extremes (same box, interleaved): DESIGN §4.
 
 #define MN_SA_R 4
 #define MN_SA_CAP (64 * MN_SA_R)
-
-// (named registers, not arrays: an array indexed by anything but a literal ends up in scratch memory)
-struct UArr {
-    float k0, k1, k2, k3;
-    int v0, v1, v2, v3;
-    int n;    // elements 0..n-1 are in use
-    float bk; // the cached element's key (candidates: smallest, results: largest) ...
-    int bp;   // ... and its place
-};
-#define MN_SA_EACH(X) X(0, k0, v0) X(1, k1, v1) X(2, k2, v2) X(3, k3, v3)
-
-DEVI void ua_init(UArr &a, float none) {
-    a.k0 = a.k1 = a.k2 = a.k3 = __builtin_nanf("");
-    a.v0 = a.v1 = a.v2 = a.v3 = 0;
-    a.n = 0;
-    a.bk = none;
-    a.bp = 0;
-}
-
-DEVI void ua_get(const UArr &a, int e, float &key, int &val) { // e uniform
-    const int sl = __builtin_amdgcn_readfirstlane(e >> 6), l = __builtin_amdgcn_readfirstlane(e & 63);
-    // (the empty asm statements keep the compiler from turning the selection into a table on the stack)
-    int kk = __float_as_int(a.k0), vv = a.v0;
-    if (sl == 1) {
-        kk = __float_as_int(a.k1);
-        vv = a.v1;
-    }
-    asm volatile("" : "+v"(kk), "+v"(vv));
-    if (sl == 2) {
-        kk = __float_as_int(a.k2);
-        vv = a.v2;
-    }
-    asm volatile("" : "+v"(kk), "+v"(vv));
-    if (sl == 3) {
-        kk = __float_as_int(a.k3);
-        vv = a.v3;
-    }
-    asm volatile("" : "+v"(kk), "+v"(vv));
-    key = __int_as_float(__builtin_amdgcn_readlane(kk, l));
-    val = __builtin_amdgcn_readlane(vv, l);
-}
-
-DEVI void ua_put(UArr &a, int e, float key, int val, int lane) { // e, key, val uniform
-    const int sl = __builtin_amdgcn_readfirstlane(e >> 6);
-    const bool here = lane == (e & 63);
-    // (the empty asm statements keep the compiler from turning the four cases into an indexed array on the stack)
-#define MN_SA_PUT(T, K, V)                                                                                                       \
-    if (sl == T) {                                                                                                               \
-        a.K = here ? key : a.K;                                                                                                  \
-        a.V = here ? val : a.V;                                                                                                  \
-    }                                                                                                                            \
-    asm volatile("" : "+v"(a.K), "+v"(a.V));
-    MN_SA_EACH(MN_SA_PUT)
-#undef MN_SA_PUT
-}
-
-DEVI bool ua_holds(const UArr &a, float key) { // an equal key is in the queue (empty places are NaN: never equal)
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(a.k0 == key) | __builtin_amdgcn_ballot_w64(a.k1 == key) |
-                                 __builtin_amdgcn_ballot_w64(a.k2 == key) | __builtin_amdgcn_ballot_w64(a.k3 == key);
-    return m != 0;
-}
-
-// wavefront-wide min / max by DPP: xor 1, xor 2 inside the quads, the mirrored half row, the mirrored row, then row 0 → 1,
-// 2 → 3 and rows 0-1 → 2-3 by row broadcast; lane 63 ends up with the result.  NaN operands are ignored (v_min / v_max).
-template <bool MAXQ> DEVI float ua_op(float x, float y) { return MAXQ ? __builtin_fmaxf(x, y) : __builtin_fminf(x, y); }
-template <bool MAXQ> DEVI float wave_extreme(float x) {
-#define MN_DPP(ctrl, rmask) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), ctrl, rmask, 0xf, false))
-    x = ua_op<MAXQ>(x, MN_DPP(0xB1, 0xf));
-    x = ua_op<MAXQ>(x, MN_DPP(0x4E, 0xf));
-    x = ua_op<MAXQ>(x, MN_DPP(0x141, 0xf)); // row_half_mirror
-    x = ua_op<MAXQ>(x, MN_DPP(0x140, 0xf)); // row_mirror
-    x = ua_op<MAXQ>(x, MN_DPP(0x142, 0xa)); // row_bcast:15 into rows 1 and 3
-    x = ua_op<MAXQ>(x, MN_DPP(0x143, 0xc)); // row_bcast:31 into rows 2 and 3
-#undef MN_DPP
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
-}
-
-// recompute the cached element (n > 0, keys pairwise different)
-template <bool MAXQ> DEVI void ua_refresh(UArr &a) {
-    const float m = ua_op<MAXQ>(ua_op<MAXQ>(a.k0, a.k1), ua_op<MAXQ>(a.k2, a.k3));
-    const float ext = wave_extreme<MAXQ>(m);
-    a.bk = ext;
-    int pos = 0;
-#define MN_SA_FIND(T, K, V)                                                                                                      \
-    {                                                                                                                            \
-        const unsigned long long mm = __builtin_amdgcn_ballot_w64(a.K == ext);                                                   \
-        if (mm)                                                                                                                  \
-            pos = T * 64 + (__ffsll((long long)mm) - 1);                                                                         \
-    }
-    MN_SA_EACH(MN_SA_FIND)
-#undef MN_SA_FIND
-    a.bp = __builtin_amdgcn_readfirstlane(pos);
-}
-
-// take the cached element out (the last element moves into its place)
-template <bool MAXQ> DEVI void ua_remove_best(UArr &a, int lane) {
-    const int last = a.n - 1;
-    float lk;
-    int lv;
-    ua_get(a, last, lk, lv);
-    ua_put(a, last, __builtin_nanf(""), 0, lane);
-    if (a.bp != last)
-        ua_put(a, a.bp, lk, lv, lane);
-    a.n = last;
-    if (last > 0)
-        ua_refresh<MAXQ>(a);
-    else
-        a.bk = MAXQ ? -__builtin_inff() : __builtin_inff();
-}
+#define MN_SA_EACH(X) X(0, k0, v0, s0) X(1, k1, v1, s1) X(2, k2, v2, s2) X(3, k3, v3, s3)
+#define MN_SA_DONE ((int)0x80000000)
 
 // beam_layer with the queues in registers.  true: `res` holds the results as beam_layer would have left them (and
-// res.sorted = 1: position i is the (size - i)-th nearest).  false: a tie (or something else the arrays cannot decide) came
+// res.sorted = 1: position i is the (size - i)-th nearest).  false: a tie (or something else the array cannot decide) came
 // up; nothing but the bitmap, the read log and the counters has been touched, and the caller redoes the layer with
-// beam_layer.  `tmp`: LDS, MN_SA_CAP floats (the unused candidate heap).
+// beam_layer.  `perm`: LDS, MN_SA_CAP items (the unused candidate heap).
 template <int ORDER, int NCH, bool COH, bool WIDE>
-DEVI bool beam_layer_regs(const MnDevIndex &ix, WaveCtx &w, WHeap &res, float *tmp, unsigned *bitmap, int entry, int level,
+DEVI bool beam_layer_regs(const MnDevIndex &ix, WaveCtx &w, WHeap &res, uint2 *perm, unsigned *bitmap, int entry, int level,
                           int ef, int lane) {
-    UArr ca, ra; // candidates (cached: the nearest), results (cached: the worst)
-    ua_init(ca, __builtin_inff());
-    ua_init(ra, -__builtin_inff());
+    // (named registers, not arrays: an array indexed by anything but a literal ends up in scratch memory)
+    float k0, k1, k2, k3;
+    int v0, v1, v2, v3;
+    k0 = k1 = k2 = k3 = __builtin_nanf("");
+    v0 = v1 = v2 = v3 = -1; // (an empty place counts as expanded: never popped)
+    int rn = 0;             // members, ranks 0..rn-1
+    float wk = 0.0f;        // the worst member's key once rn == ef
     bool ok = true;
     if (!(ix.has_deleted && ix.deleted[entry])) { // :360-366
         float d = ctx_distance<ORDER, NCH>(ix, w, entry, 1, lane);
         d = u2f(rflu(f2u(d)));
         w.n_dist += 1;
         ok = d == d;
-        ua_put(ca, 0, d, entry, lane);
-        ua_put(ra, 0, d, entry, lane);
-        ca.n = ra.n = 1;
-        ca.bk = ra.bk = d;
+        if (lane == 0) {
+            k0 = d;
+            v0 = entry;
+        }
+        rn = 1;
+        wk = d;
         if (lane == 0) {
             int vi = level == 0 ? entry : ix.up_off[entry];
             atomicOr(&bitmap[vi >> 5], 1u << (vi & 31));
@@ -579,16 +487,35 @@ DEVI bool beam_layer_regs(const MnDevIndex &ix, WaveCtx &w, WHeap &res, float *t
     if (patience_max < 10)
         patience_max = 10;
     int stale = 0;
-    while (ok && ca.n > 0) {
+    while (ok) {
         PH_DECL;
-        const float cd = ca.bk;
-        float ck_;
-        int node;
-        ua_get(ca, ca.bp, ck_, node);
-        ua_remove_best<false>(ca, lane);
-        if (ra.n >= ef && cd > ra.bk) // :382-386
+        // the nearest candidate = the first member that has not been expanded
+        unsigned long long pm = __builtin_amdgcn_ballot_w64(v0 >= 0);
+        int pt = 0;
+        if (!pm && rn > 64) {
+            pm = __builtin_amdgcn_ballot_w64(v1 >= 0);
+            pt = 1;
+        }
+        if (!pm && rn > 128) {
+            pm = __builtin_amdgcn_ballot_w64(v2 >= 0);
+            pt = 2;
+        }
+        if (!pm && rn > 192) {
+            pm = __builtin_amdgcn_ballot_w64(v3 >= 0);
+            pt = 3;
+        }
+        if (!pm) // no candidate, or only dead ones: :377 / :382-386
             break;
-        if (stale >= patience_max && ra.n >= ef) // :391
+        const int pl = __builtin_amdgcn_readfirstlane(__ffsll((long long)pm) - 1);
+        int node = 0;
+#define MN_SA_POP(T, K, V, S)                                                                                                    \
+    if (pt == T) {                                                                                                               \
+        node = __builtin_amdgcn_readlane(V, pl);                                                                                 \
+        V = lane == pl ? (V | MN_SA_DONE) : V;                                                                                   \
+    }
+        MN_SA_EACH(MN_SA_POP)
+#undef MN_SA_POP
+        if (stale >= patience_max && rn >= ef) // :391
             break;
         int W;
         const int *row = link_row(ix, node, level, W);
@@ -670,60 +597,68 @@ DEVI bool beam_layer_regs(const MnDevIndex &ix, WaveCtx &w, WHeap &res, float *t
             if (n > 0) {
                 w.n_dist += n;
                 PH_ADD(w, 2);
-                unsigned long long am; // (worst only falls while the row is worked through: pre-filter, as beam_layer does)
-                if (ra.n >= ef)
-                    am = __ballot(lane < n && d < ra.bk);
-                else
-                    am = __ballot(lane < n);
-                if (__ballot(lane < n && !(d == d)))
+                if (__ballot(lane < n && !(d == d))) {
                     ok = false; // a NaN distance: the heaps' business
-                PH_CNT(w, 4, __popcll(am));
-                while (am && ok) { // :413-425, in list order
-                    int i = __ffsll((long long)am) - 1;
-                    am &= am - 1;
-                    i = __builtin_amdgcn_readfirstlane(i);
-                    const float di = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), i));
-                    const int si = __builtin_amdgcn_readlane(myslot, i);
-                    const bool full = ra.n >= ef;
-                    if (full && !(di < ra.bk))
-                        continue;
-                    if (ua_holds(ca, di) || ua_holds(ra, di)) {
-                        ok = false;
-                        break;
-                    }
-                    // results first: either one more, or the worst is overwritten and the next worst looked up
-                    if (!full) {
-                        ua_put(ra, ra.n, di, si, lane);
-                        if (di > ra.bk) {
-                            ra.bk = di;
-                            ra.bp = ra.n;
-                        }
-                        ra.n++;
-                    } else {
-                        ua_put(ra, ra.bp, di, si, lane);
-                        ua_refresh<true>(ra);
-                    }
-                    if (ca.n == MN_SA_CAP) { // more candidates alive than the array holds: the farthest goes — it must be dead
-                        UArr far = ca;
-                        ua_refresh<true>(far);
-                        if (!(ra.n >= ef && far.bk > ra.bk)) {
+                    break;
+                }
+                // (:413-425) what can enter: everything while there is room, else what is nearer than the worst result
+                const bool acc = lane < n && (rn < ef || d < wk);
+                const unsigned long long am = __ballot(acc);
+                const int na = __popcll(am);
+                PH_CNT(w, 4, na);
+                if (na > 0) {
+                    improved = 1;
+                    int s0 = 0, s1 = 0, s2 = 0, s3 = 0; // how far each member moves up
+                    int mypos = 0;                      // (lane j < n) the rank of new distance j
+                    unsigned long long rem = am;
+                    while (rem) {
+                        const int j = __builtin_amdgcn_readfirstlane(__ffsll((long long)rem) - 1);
+                        rem &= rem - 1;
+                        const float y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), j));
+                        int before = 0, after = 0;
+#define MN_SA_CNT(T, K, V, S)                                                                                                    \
+    if (rn > T * 64) {                                                                                                           \
+        const bool gt = y < K;                                                                                                   \
+        before += __popcll(__builtin_amdgcn_ballot_w64(K < y));                                                                  \
+        after += __popcll(__builtin_amdgcn_ballot_w64(gt));                                                                      \
+        S += gt ? 1 : 0;                                                                                                         \
+    }
+                        MN_SA_EACH(MN_SA_CNT)
+#undef MN_SA_CNT
+                        const int nb_before = __popcll(__builtin_amdgcn_ballot_w64(acc && d < y));
+                        const int nb_after = __popcll(__builtin_amdgcn_ballot_w64(acc && y < d));
+                        if (before + after != rn || nb_before + nb_after != na - 1) { // an equal key somewhere
                             ok = false;
                             break;
                         }
-                        ua_put(ca, far.bp, di, si, lane);
-                        if (di < ca.bk) {
-                            ca.bk = di;
-                            ca.bp = far.bp;
-                        }
-                    } else {
-                        ua_put(ca, ca.n, di, si, lane);
-                        if (di < ca.bk) {
-                            ca.bk = di;
-                            ca.bp = ca.n;
-                        }
-                        ca.n++;
+                        mypos = lane == j ? before + nb_before : mypos;
                     }
-                    improved = 1;
+                    if (!ok)
+                        break;
+                    __builtin_amdgcn_wave_barrier();
+#define MN_SA_OUT(T, K, V, S)                                                                                                    \
+    if (rn > T * 64) {                                                                                                           \
+        const int r = T * 64 + lane, p = r + S;                                                                                  \
+        if (r < rn && p < ef)                                                                                                    \
+            perm[p] = make_uint2(f2u(K), (unsigned)V);                                                                           \
+    }
+                    MN_SA_EACH(MN_SA_OUT)
+#undef MN_SA_OUT
+                    if (acc && mypos < ef)
+                        perm[mypos] = make_uint2(f2u(d), (unsigned)myslot);
+                    __builtin_amdgcn_wave_barrier();
+                    rn = rn + na < ef ? rn + na : ef;
+#define MN_SA_IN(T, K, V, S)                                                                                                     \
+    if (rn > T * 64) {                                                                                                           \
+        const int r = T * 64 + lane;                                                                                             \
+        const uint2 it = perm[r < rn ? r : 0];                                                                                   \
+        K = r < rn ? u2f(it.x) : __builtin_nanf("");                                                                             \
+        V = r < rn ? (int)it.y : -1;                                                                                             \
+    }
+                    MN_SA_EACH(MN_SA_IN)
+#undef MN_SA_IN
+                    wk = u2f(rflu(perm[rn - 1].x));
+                    __builtin_amdgcn_wave_barrier();
                 }
                 PH_ADD(w, 3);
             }
@@ -739,37 +674,17 @@ DEVI bool beam_layer_regs(const MnDevIndex &ix, WaveCtx &w, WHeap &res, float *t
 #endif
     if (!ok)
         return false;
-    // rank the results (keys pairwise different): element e goes to heap position n - rank(e); keys -distance, root = worst
-    const int n = ra.n;
-    __builtin_amdgcn_wave_barrier();
-    tmp[lane] = ra.k0;
-    tmp[64 + lane] = ra.k1;
-    tmp[128 + lane] = ra.k2;
-    tmp[192 + lane] = ra.k3;
-    __builtin_amdgcn_wave_barrier();
-    int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-    for (int j = 0; j < n; j += 4) { // (broadcast reads; NaN = empty never counts)
-        const float4 kk = *reinterpret_cast<const float4 *>(tmp + j);
-        r0 += (kk.x < ra.k0) + (kk.y < ra.k0) + (kk.z < ra.k0) + (kk.w < ra.k0);
-        if (n > 64)
-            r1 += (kk.x < ra.k1) + (kk.y < ra.k1) + (kk.z < ra.k1) + (kk.w < ra.k1);
-        if (n > 128) {
-            r2 += (kk.x < ra.k2) + (kk.y < ra.k2) + (kk.z < ra.k2) + (kk.w < ra.k2);
-            r3 += (kk.x < ra.k3) + (kk.y < ra.k3) + (kk.z < ra.k3) + (kk.w < ra.k3);
-        }
-    }
+    // hand the results over as the heap array the callers expect: keys -distance, root (position 1) = the worst
+    const int n = rn;
     __builtin_amdgcn_wave_barrier();
     res.size = n;
     res.ovf = 0;
     res.sorted = 1;
-    if (lane < n)
-        hset(res, n - r0, make_uint2(f2u(-ra.k0), (unsigned)ra.v0));
-    if (64 + lane < n)
-        hset(res, n - r1, make_uint2(f2u(-ra.k1), (unsigned)ra.v1));
-    if (128 + lane < n)
-        hset(res, n - r2, make_uint2(f2u(-ra.k2), (unsigned)ra.v2));
-    if (192 + lane < n)
-        hset(res, n - r3, make_uint2(f2u(-ra.k3), (unsigned)ra.v3));
+#define MN_SA_RES(T, K, V, S)                                                                                                    \
+    if (T * 64 + lane < n)                                                                                                       \
+        hset(res, n - (T * 64 + lane), make_uint2(f2u(-K), (unsigned)(V & 0x7fffffff)));
+    MN_SA_EACH(MN_SA_RES)
+#undef MN_SA_RES
     __builtin_amdgcn_wave_barrier();
     return true;
 }
@@ -778,10 +693,10 @@ DEVI bool beam_layer_regs(const MnDevIndex &ix, WaveCtx &w, WHeap &res, float *t
 template <int ORDER, int NCH, bool COH, bool WIDE>
 DEVI void beam_layer_auto(const MnDevIndex &ix, WaveCtx &w, WHeap &cand, WHeap &res, unsigned *bitmap, long long bm_words,
                           int entry, int level, int ef, int lane) {
-    if (ef <= MN_SA_CAP && ef >= 1 && ef + 1 < res.lcap + res.gcap) {
+    if (ef <= MN_SA_CAP && ef >= 1 && ef + 1 < res.lcap + res.gcap && cand.lcap >= MN_SA_CAP) {
         const unsigned long long nd0 = w.n_dist, ne0 = w.n_exp;
         const int nr0 = w.nr;
-        if (beam_layer_regs<ORDER, NCH, COH, WIDE>(ix, w, res, reinterpret_cast<float *>(cand.l), bitmap, entry, level, ef, lane))
+        if (beam_layer_regs<ORDER, NCH, COH, WIDE>(ix, w, res, cand.l, bitmap, entry, level, ef, lane))
             return;
         w.n_dist = nd0;
         w.n_exp = ne0;

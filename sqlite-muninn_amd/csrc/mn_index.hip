@@ -69,12 +69,16 @@ extern "C" long long mn_debug_fault_alloc(long long nth) {
 template <typename T> struct DevBuf {
     T *p = nullptr;
     size_t cap = 0; // elements
-    int reserve(size_t n, bool keep, hipStream_t st, int fill_byte = -1) {
+    // `want` (> n, optional): a size the caller knows the buffer will reach (a bulk build) — taken exactly, in ONE allocation,
+    // instead of the geometric steps and their 1.5x slack
+    int reserve(size_t n, bool keep, hipStream_t st, int fill_byte = -1, size_t want = 0) {
         if (n <= cap)
             return 0;
         size_t nc = cap ? cap : 1024;
         while (nc < n)
             nc = nc + nc / 2 + 1024;
+        if (want > n)
+            nc = want;
         T *np = nullptr;
         HIPCHK(hipMalloc(&np, nc * sizeof(T)));
         if (fill_byte >= 0)
@@ -110,6 +114,7 @@ struct mn_index {
     unsigned rng_state = 42;
     int node_count = 0;
     int n_deleted = 0; // soft-deleted nodes among the slots
+    int64_t slot_hint = 0; // slots a running bulk build will reach (sync_meta sizes the device tables for it at once)
     // host metadata, slot-indexed
     std::vector<int64_t> ids;
     std::vector<signed char> levels;
@@ -403,15 +408,16 @@ static size_t pin_insert_bytes(const mn_index *x) {
 static int sync_meta(mn_index *x) {
     hipStream_t st = x->stream;
     size_t ns = (size_t)x->n_slots;
-    if (x->d_vectors.reserve(ns * x->ld, true, st)) return -1;
-    if (x->d_norms.reserve(ns, true, st)) return -1;
-    if (x->d_links0.reserve(ns * x->W0, true, st, 0xFF)) return -1;
+    size_t hs = std::max(ns, (size_t)x->slot_hint); // a bulk build has announced its final slot count
+    if (x->d_vectors.reserve(ns * x->ld, true, st, -1, hs * x->ld)) return -1;
+    if (x->d_norms.reserve(ns, true, st, -1, hs)) return -1;
+    if (x->d_links0.reserve(ns * x->W0, true, st, 0xFF, hs * x->W0)) return -1;
     if (x->d_links_up.reserve((size_t)std::max(1, x->n_pool_rows) * x->WU, true, st, 0xFF)) return -1;
-    if (x->d_up_off.reserve(ns, true, st)) return -1;
-    if (x->d_levels.reserve(ns, true, st)) return -1;
-    if (x->d_deleted.reserve(ns, true, st)) return -1;
-    if (x->d_dirty.reserve(ns, true, st, 0)) return -1;
-    if (x->d_ids.reserve(ns, true, st)) return -1;
+    if (x->d_up_off.reserve(ns, true, st, -1, hs)) return -1;
+    if (x->d_levels.reserve(ns, true, st, -1, hs)) return -1;
+    if (x->d_deleted.reserve(ns, true, st, -1, hs)) return -1;
+    if (x->d_dirty.reserve(ns, true, st, 0, hs)) return -1;
+    if (x->d_ids.reserve(ns, true, st, -1, hs)) return -1;
     int a = x->meta_uploaded, n = x->n_slots - a;
     unsigned char *pin = n == 1 ? pin_reserve(x, pin_insert_bytes(x)) : nullptr;
     if (n == 1 && pin) { // one insert: staged in the pinned block — four truly asynchronous copies, nothing to wait for
@@ -1547,6 +1553,8 @@ static int build_impl(mn_index *x, const int64_t *ids, const float *vectors, int
         grow_div = 16;
     if (max_batch <= 0)
         max_batch = 8192;
+    if (!getenv("MN_BUILD_NO_RESERVE"))
+        x->slot_hint = (int64_t)x->n_slots + n; // the slot-indexed device tables are allocated once, at their final size
     int64_t pos = 0;
     while (pos < n) {
         int64_t b = std::max<int64_t>(1, x->node_count / grow_div);
@@ -1653,6 +1661,8 @@ extern "C" int mn_hnsw_build_shared(mn_index *x, mn_comm *c, const int64_t *ids,
         min_split = 256;
     const int world = c ? c->world : 1, rank = c ? c->rank : 0;
     hipStream_t st = x->stream;
+    if (!getenv("MN_BUILD_NO_RESERVE"))
+        x->slot_hint = (int64_t)x->n_slots + n;
     int64_t pos = 0;
     while (pos < n) {
         int64_t b = std::max<int64_t>(1, x->node_count / grow_div); // the batches of mn_hnsw_build
