@@ -38,6 +38,19 @@ def run(n, d, metric, ef, nq=300, nins=300):
     g.close()
     print(f"{n} x {d} {metric} ef={ef}:", out, flush=True)
 
+def floor():
+    # an index of one node: the search kernel has nothing to do — what is left is the call itself (ctypes, launch, dispatch, the
+    # kernel's prologue and epilogue, the wait)
+    g = pkg.HnswIndex(128, "l2", 16, 200)
+    X = np.random.default_rng(1).standard_normal((2, 128), dtype=np.float32)
+    assert g.insert(1, X[0]) == 0
+    ts = []
+    for i in range(400):
+        t = time.perf_counter(); g.search(X[1], 10, 64); ts.append((time.perf_counter() - t) * 1e3)
+    g.close()
+    print("one-node index, ms per query:", round(float(np.median(ts[50:])), 4), flush=True)
+
+floor()
 run(3000, 128, "l2", 64)
 run(10000, 128, "l2", 64)
 run(10000, 768, "l2", 64)

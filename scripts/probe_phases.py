@@ -22,7 +22,7 @@ def show(tag, p, wall_ms, n):
     nexp = max(p[5], 1)
     print(f"{tag}: {wall_ms / n:.3f} ms each; expansions {p[5] / n:.0f}, pushes {p[4] / n:.0f}; per expansion: pop {us[0] / nexp:.2f} us, "
           f"row+visited {us[1] / nexp:.2f}, distances {us[2] / nexp:.2f}, pushes {us[3] / nexp:.2f}  (sum {us.sum() / nexp:.2f} us; "
-          f"in-search total {us.sum() / n / 1e3:.3f} ms; link phase {p[6] / 100.0 / n / 1e3:.3f} ms)", flush=True)
+          f"in-search total {us.sum() / n / 1e3:.3f} ms; link phase {p[6] / 100.0 / n / 1e3:.3f} ms; pops of the previous runner-up {p[7] / nexp:.2f})", flush=True)
 X = np.random.default_rng(42).standard_normal((N + 400, D), dtype=np.float32)
 Q = np.random.default_rng(43).standard_normal((200, D), dtype=np.float32)
 g = pkg.HnswIndex(D, metric, 16, 200)

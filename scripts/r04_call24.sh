@@ -1,0 +1,15 @@
+#!/bin/bash
+# round-4 GPU call 24: pipelined batch loads in the latency kernels' SSE-order walk: lone-search tests, then A/B against the
+# previous library (build/ab/pair_v1.so), interleaved
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd "$R" || exit 1
+O=$R/gpurun_out
+timeout -k 10 600 python -m pytest tests/test_gpu_hnsw.py -m gpu -x -q -k "lone or latency or golden or tie or sequential" > $O/t_call24.log 2>&1; rc=$?; echo "hnsw rc=$rc"; tail -3 $O/t_call24.log
+[ $rc -eq 0 ] || exit 1
+for V in v1 v2 v1 v2; do
+  echo "== $V"
+  if [ "$V" = v1 ]; then MN_AB_LIB=build/ab/pair_v1.so timeout -k 10 300 python scripts/probe_latency3.py small 2>&1 | tail -4
+  else timeout -k 10 300 python scripts/probe_latency3.py small 2>&1 | tail -4; fi
+done > $O/ab_pipe.log 2>&1
+cat $O/ab_pipe.log

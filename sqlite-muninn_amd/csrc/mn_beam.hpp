@@ -171,26 +171,51 @@ struct WaveCtx {
     CoopCtx *coop = nullptr;
     int no_spec_rows = 0; // MN_SPEC_ROWS=0 (host): the helpers' rows are requested only once the visited probe has answered (A/B runs)
 };
-DEVI bool getenv_spec_off(const WaveCtx &w) { return w.no_spec_rows != 0; }
+DEVI bool getenv_spec_off(const WaveCtx &w) { return (w.no_spec_rows & 1) != 0; }
 
+// A log entry is MN_RLOG_INTS ints: [0] the row (level 0: the node's slot, upper: -(pool row) - 2); [1] the worst result's
+// distance when the row was opened (float bits: what a neighbour had to beat to be pushed; +inf while the results had room);
+// [2..3] the positions of the row whose neighbour was new AND nearer than that — everything that could have been pushed.
+// The commit step of a speculative window (mn_spec.hip) uses [1..3] to decide whether a rewrite of the row by an earlier insert
+// of the window would have changed this search at all.  The defaults written here say "anything would have" (-inf, all
+// positions): greedy descents, rows of more than 64 links and searches that fell back to the heaps keep them.
 DEVI void log_row_read(const MnDevIndex &ix, WaveCtx &w, int node, int level, int lane) {
     if (!w.rlog)
         return;
-    if (lane == 0 && w.nr < w.rcap)
-        w.rlog[w.nr] = level == 0 ? node : -(ix.up_off[node] + level - 1) - 2;
+    if (lane == 0 && w.nr < w.rcap) {
+        int *e = w.rlog + (size_t)w.nr * MN_RLOG_INTS;
+        e[0] = level == 0 ? node : -(ix.up_off[node] + level - 1) - 2;
+        e[1] = (int)0xff800000u; // -inf
+        e[2] = e[3] = -1;
+    }
     w.nr++;
+}
+// the detail of the entry log_row_read has just written (beam_layer_regs, a row of one chunk)
+DEVI void log_row_detail(WaveCtx &w, float worst, unsigned long long could_push, int lane) {
+    if (!w.rlog)
+        return;
+    if (lane == 0 && w.nr >= 1 && w.nr <= w.rcap) {
+        int *e = w.rlog + (size_t)(w.nr - 1) * MN_RLOG_INTS;
+        e[1] = __float_as_int(worst);
+        e[2] = (int)(unsigned)(could_push & 0xffffffffull);
+        e[3] = (int)(unsigned)(could_push >> 32);
+    }
 }
 
 // this wavefront's share of the posted candidate list: entries wv, wv+nw, wv+2nw, ...
+#define MN_COOP_NO_LEADER 0x10000 // flag in a request's count: the leader is busy elsewhere, the helpers divide the list among themselves
 template <int ORDER, int NCH>
-DEVI void coop_share(const MnDevIndex &ix, const float *q, const CoopCtx &c, int n, int lane) {
-    const int cnt = n > c.wv ? (n - c.wv + c.nw - 1) / c.nw : 0;
+DEVI void coop_share(const MnDevIndex &ix, const float *q, const CoopCtx &c, int n_req, int lane) {
+    const bool alone = (n_req & MN_COOP_NO_LEADER) != 0; // (never seen by the leader itself)
+    const int n = n_req & (MN_COOP_NO_LEADER - 1);
+    const int nw = alone ? c.nw - 1 : c.nw, wv = alone ? c.wv - 1 : c.wv;
+    const int cnt = n > wv ? (n - wv + nw - 1) / nw : 0;
     if (cnt == 0)
         return;
-    const int myslot = lane < cnt ? c.list[c.wv + lane * c.nw] : 0;
+    const int myslot = lane < cnt ? c.list[wv + lane * nw] : 0;
     const float d = rows_distance<ORDER, NCH, true>(ix, q, *c.qnorm, myslot, cnt, lane, c.tile, c.tile_rows);
     if (lane < cnt)
-        c.dist[c.wv + lane * c.nw] = d;
+        c.dist[wv + lane * nw] = d;
 }
 
 // the helpers' whole life: wait for a request, do the share, repeat until the leader signals the end
@@ -452,6 +477,128 @@ DEVI void beam_layer(const MnDevIndex &ix, WaveCtx &w, WHeap &cand, WHeap &res, 
 #define MN_SA_EACH(X) X(0, k0, v0, s0) X(1, k1, v1, s1) X(2, k2, v2, s2) X(3, k3, v3, s3)
 #define MN_SA_DONE ((int)0x80000000)
 
+// (named registers, not arrays: an array indexed by anything but a literal ends up in scratch memory)
+struct SQueue {
+    float k0, k1, k2, k3;
+    int v0, v1, v2, v3; // slot, sign bit = expanded; an empty place is -1 (counts as expanded: never popped)
+    int rn;             // members, ranks 0..rn-1
+    float wk;           // the worst member's key once rn == ef
+};
+
+DEVI void sq_init(SQueue &s) {
+    s.k0 = s.k1 = s.k2 = s.k3 = __builtin_nanf("");
+    s.v0 = s.v1 = s.v2 = s.v3 = -1;
+    s.rn = 0;
+    s.wk = 0.0f;
+}
+
+// the first member that has not been expanded (the nearest candidate), or -1; MARK: it becomes expanded
+template <bool MARK> DEVI int sq_first(SQueue &s, int lane) {
+    unsigned long long pm = __builtin_amdgcn_ballot_w64(s.v0 >= 0);
+    int pt = 0;
+    if (!pm && s.rn > 64) {
+        pm = __builtin_amdgcn_ballot_w64(s.v1 >= 0);
+        pt = 1;
+    }
+    if (!pm && s.rn > 128) {
+        pm = __builtin_amdgcn_ballot_w64(s.v2 >= 0);
+        pt = 2;
+    }
+    if (!pm && s.rn > 192) {
+        pm = __builtin_amdgcn_ballot_w64(s.v3 >= 0);
+        pt = 3;
+    }
+    if (!pm)
+        return -1;
+    const int pl = __builtin_amdgcn_readfirstlane(__ffsll((long long)pm) - 1);
+    int node = 0;
+#define MN_SA_POP(T, K, V, S)                                                                                                    \
+    if (pt == T) {                                                                                                               \
+        node = __builtin_amdgcn_readlane(s.V, pl);                                                                               \
+        if (MARK)                                                                                                                \
+            s.V = lane == pl ? (s.V | MN_SA_DONE) : s.V;                                                                         \
+    }
+    MN_SA_EACH(MN_SA_POP)
+#undef MN_SA_POP
+    return node;
+}
+
+// (:413-425) the new distances of a row (lanes with `fresh`: d, slot — any lanes, the merge is a set operation) enter the array
+// in one merge.  false: an equal key somewhere (the heaps' business).  `any`: something was pushed.
+DEVI bool sq_merge(SQueue &s, uint2 *perm, float d, int myslot, bool fresh, int ef, int lane, int &any,
+                   unsigned long long &entering) {
+    // what can enter: everything while there is room, else what is nearer than the worst result
+    const bool acc = fresh && (s.rn < ef || d < s.wk);
+    const unsigned long long am = __ballot(acc);
+    entering = am;
+    const int na = __popcll(am);
+    if (na == 0)
+        return true;
+    any = 1;
+    const int rn = s.rn;
+    int s0 = 0, s1 = 0, s2 = 0, s3 = 0; // how far each member moves up
+    int mypos = 0;                      // (an entering lane) the rank of its distance
+    const float dm = acc ? d : __builtin_nanf(""); // (a NaN compares false both ways: lanes that do not enter count nowhere)
+    int pairs = 0; // every (new, member) and (new, new) pair must be ordered one way or the other: counted, checked once
+    unsigned long long rem = am;
+    while (rem) {
+        const int j = __builtin_amdgcn_readfirstlane(__ffsll((long long)rem) - 1);
+        rem &= rem - 1;
+        const float y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), j));
+        int before = 0;
+#define MN_SA_CNT(T, K, V, S)                                                                                                    \
+    if (rn > T * 64) {                                                                                                           \
+        const bool gt = y < s.K;                                                                                                 \
+        before += __popcll(__builtin_amdgcn_ballot_w64(s.K < y));                                                                \
+        pairs += __popcll(__builtin_amdgcn_ballot_w64(gt));                                                                      \
+        S += gt ? 1 : 0;                                                                                                         \
+    }
+        MN_SA_EACH(MN_SA_CNT)
+#undef MN_SA_CNT
+        before += __popcll(__builtin_amdgcn_ballot_w64(dm < y));
+        pairs += before + __popcll(__builtin_amdgcn_ballot_w64(y < dm));
+        mypos = lane == j ? before : mypos;
+    }
+    if (pairs != na * (rn + na - 1)) // an equal key somewhere
+        return false;
+    __builtin_amdgcn_wave_barrier();
+#define MN_SA_OUT(T, K, V, S)                                                                                                    \
+    if (rn > T * 64) {                                                                                                           \
+        const int r = T * 64 + lane, p = r + S;                                                                                  \
+        if (r < rn && p < ef)                                                                                                    \
+            perm[p] = make_uint2(f2u(s.K), (unsigned)s.V);                                                                       \
+    }
+    MN_SA_EACH(MN_SA_OUT)
+#undef MN_SA_OUT
+    if (acc && mypos < ef)
+        perm[mypos] = make_uint2(f2u(d), (unsigned)myslot);
+    __builtin_amdgcn_wave_barrier();
+    const int nn = rn + na < ef ? rn + na : ef;
+    s.rn = nn;
+#define MN_SA_IN(T, K, V, S)                                                                                                     \
+    if (nn > T * 64) {                                                                                                           \
+        const int r = T * 64 + lane;                                                                                             \
+        const uint2 it = perm[r < nn ? r : 0];                                                                                   \
+        s.K = r < nn ? u2f(it.x) : __builtin_nanf("");                                                                           \
+        s.V = r < nn ? (int)it.y : -1;                                                                                           \
+    }
+    MN_SA_EACH(MN_SA_IN)
+#undef MN_SA_IN
+    s.wk = u2f(rflu(perm[nn - 1].x));
+    __builtin_amdgcn_wave_barrier();
+    return true;
+}
+
+// this lane's neighbour (or -1) of a row that is being expanded: the visited probe (:403-409); true = new and alive
+template <bool COH> DEVI bool probe_new(const MnDevIndex &ix, unsigned *bitmap, int level, int nb) {
+    if (nb < 0)
+        return false;
+    const int vi = level == 0 ? nb : ix.up_off[nb];
+    const unsigned bit = 1u << (vi & 31);
+    const unsigned old = atomicOr(&bitmap[vi >> 5], bit);
+    return !(old & bit) && !(ix.has_deleted && ix.deleted[nb]);
+}
+
 // beam_layer with the queues in registers.  true: `res` holds the results as beam_layer would have left them (and
 // res.sorted = 1: position i is the (size - i)-th nearest).  false: a tie (or something else the array cannot decide) came
 // up; nothing but the bitmap, the read log and the counters has been touched, and the caller redoes the layer with
@@ -459,13 +606,8 @@ DEVI void beam_layer(const MnDevIndex &ix, WaveCtx &w, WHeap &cand, WHeap &res, 
 template <int ORDER, int NCH, bool COH, bool WIDE>
 DEVI bool beam_layer_regs(const MnDevIndex &ix, WaveCtx &w, WHeap &res, uint2 *perm, unsigned *bitmap, int entry, int level,
                           int ef, int lane) {
-    // (named registers, not arrays: an array indexed by anything but a literal ends up in scratch memory)
-    float k0, k1, k2, k3;
-    int v0, v1, v2, v3;
-    k0 = k1 = k2 = k3 = __builtin_nanf("");
-    v0 = v1 = v2 = v3 = -1; // (an empty place counts as expanded: never popped)
-    int rn = 0;             // members, ranks 0..rn-1
-    float wk = 0.0f;        // the worst member's key once rn == ef
+    SQueue s;
+    sq_init(s);
     bool ok = true;
     if (!(ix.has_deleted && ix.deleted[entry])) { // :360-366
         float d = ctx_distance<ORDER, NCH>(ix, w, entry, 1, lane);
@@ -473,11 +615,11 @@ DEVI bool beam_layer_regs(const MnDevIndex &ix, WaveCtx &w, WHeap &res, uint2 *p
         w.n_dist += 1;
         ok = d == d;
         if (lane == 0) {
-            k0 = d;
-            v0 = entry;
+            s.k0 = d;
+            s.v0 = entry;
         }
-        rn = 1;
-        wk = d;
+        s.rn = 1;
+        s.wk = d;
         if (lane == 0) {
             int vi = level == 0 ? entry : ix.up_off[entry];
             atomicOr(&bitmap[vi >> 5], 1u << (vi & 31));
@@ -487,43 +629,30 @@ DEVI bool beam_layer_regs(const MnDevIndex &ix, WaveCtx &w, WHeap &res, uint2 *p
     if (patience_max < 10)
         patience_max = 10;
     int stale = 0;
+#ifdef MN_PHASE_TIMING
+    int ph_second = -1;
+#endif
     while (ok) {
         PH_DECL;
-        // the nearest candidate = the first member that has not been expanded
-        unsigned long long pm = __builtin_amdgcn_ballot_w64(v0 >= 0);
-        int pt = 0;
-        if (!pm && rn > 64) {
-            pm = __builtin_amdgcn_ballot_w64(v1 >= 0);
-            pt = 1;
-        }
-        if (!pm && rn > 128) {
-            pm = __builtin_amdgcn_ballot_w64(v2 >= 0);
-            pt = 2;
-        }
-        if (!pm && rn > 192) {
-            pm = __builtin_amdgcn_ballot_w64(v3 >= 0);
-            pt = 3;
-        }
-        if (!pm) // no candidate, or only dead ones: :377 / :382-386
+        const int node = sq_first<true>(s, lane); // the nearest candidate = the first member that has not been expanded
+        if (node < 0)                             // no candidate, or only dead ones: :377 / :382-386
             break;
-        const int pl = __builtin_amdgcn_readfirstlane(__ffsll((long long)pm) - 1);
-        int node = 0;
-#define MN_SA_POP(T, K, V, S)                                                                                                    \
-    if (pt == T) {                                                                                                               \
-        node = __builtin_amdgcn_readlane(V, pl);                                                                                 \
-        V = lane == pl ? (V | MN_SA_DONE) : V;                                                                                   \
-    }
-        MN_SA_EACH(MN_SA_POP)
-#undef MN_SA_POP
-        if (stale >= patience_max && rn >= ef) // :391
+#ifdef MN_PHASE_TIMING
+        { // (probe builds) counter 7 = pops of the previous pop's runner-up
+            if (ph_second == node)
+                PH_CNT(w, 7, 1);
+            ph_second = sq_first<false>(s, lane);
+        }
+#endif
+        if (stale >= patience_max && s.rn >= ef) // :391
             break;
-        int W;
-        const int *row = link_row(ix, node, level, W);
         w.n_exp++;
         log_row_read(ix, w, node, level, lane);
+        int improved = 0;
+        int W;
+        const int *row = link_row(ix, node, level, W);
         PH_ADD(w, 0);
         PH_CNT(w, 5, 1);
-        int improved = 0;
         const int nchunk = WIDE ? (W + 63) >> 6 : 1;
         for (int ch = 0; ch < nchunk && ok; ch++) {
             const int c0 = WIDE ? ch << 6 : 0;
@@ -532,55 +661,40 @@ DEVI bool beam_layer_regs(const MnDevIndex &ix, WaveCtx &w, WHeap &res, uint2 *p
             unsigned long long m;
             int n, myslot = 0;
             float d = 0.0f;
+            bool compacted = false, nb_todo = false; // (for the read log: where the new neighbours sit)
+            int nb_rank = 0;
             const unsigned long long m_all = __ballot(nb >= 0);
             const int n_all = __popcll(m_all);
-            if (w.coop && w.coop->nw > 1 && n_all > 2 && !getenv_spec_off(w)) {
+            if (w.coop && w.coop->nw > 1 && n_all > 2 && (!getenv_spec_off(w) || !w.coop->tile)) {
                 // Round 4: with helper wavefronts the rows of ALL the listed neighbours are requested before it is known which of
                 // them are new — the visited probe (a returning atomic: one more round trip) then runs next to the row loads
-                // instead of in front of them.  A wavefront's share is ≤ 4 rows either way (one pass of its tile), so the
-                // distances of already-visited neighbours cost no time; they are simply not looked at.  Same distances for the
-                // rows that count, same order.
+                // instead of in front of them.  Long rows in a cache-resident index are the exception (a helper's tile pass takes
+                // 4 rows: the extra rows cost a second pass, 10k x 768: 0.58 -> 0.61 ms; MN_SPEC_ROWS forces either way).  With
+                // more than two wavefronts the leader leaves the rows to the helpers altogether (≤ 5 short rows each: one pass):
+                // a lone search is bound by the LEADER's instruction stream (≈ 1 000 instructions per expansion; its
+                // instruction-cache hit rate is 99.9 %, profiles/r04_lone_query_counters.txt), and its share of the rows was a
+                // fifth of that.  Nor are the new ones compacted any more: the merge is a set operation, it takes them where they
+                // are.  Same distances for the rows that count, same sets: same bits.
                 const CoopCtx &c = *w.coop;
                 const int rank_all = __popcll(m_all & ((1ull << lane) - 1ull));
+                const bool alone = c.nw > 2 && !c.tile;
                 __builtin_amdgcn_wave_barrier();
                 if (nb >= 0)
                     c.list[rank_all] = nb;
                 if (lane == 0)
-                    *c.n = n_all;
+                    *c.n = n_all | (alone ? MN_COOP_NO_LEADER : 0);
                 __syncthreads(); // the helpers start on their shares
-                unsigned old = 0, bit = 0;
-                if (nb >= 0) { // :403-409
-                    int vi = level == 0 ? nb : ix.up_off[nb];
-                    bit = 1u << (vi & 31);
-                    old = atomicOr(&bitmap[vi >> 5], bit);
-                }
-                coop_share<ORDER, NCH>(ix, w.q, c, n_all, lane);
+                todo = probe_new<COH>(ix, bitmap, level, nb);
+                if (!alone)
+                    coop_share<ORDER, NCH>(ix, w.q, c, n_all, lane);
                 __syncthreads();
-                todo = nb >= 0 && !(old & bit) && !(ix.has_deleted && ix.deleted[nb]);
-                const float d_mine = nb >= 0 ? c.dist[rank_all] : 0.0f;
+                d = nb >= 0 ? c.dist[rank_all] : 0.0f;
+                myslot = nb;
                 m = __ballot(todo);
                 n = __popcll(m);
                 PH_ADD(w, 1);
-                if (n > 0) { // compact the new ones, in list order, with their distances
-                    const int rank = __popcll(m & ((1ull << lane) - 1ull));
-                    float *dtmp = reinterpret_cast<float *>(c.list); // (the helpers are done with the list)
-                    __builtin_amdgcn_wave_barrier();
-                    if (todo) {
-                        w.scratch[rank] = nb;
-                        dtmp[rank] = d_mine;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    myslot = lane < n ? w.scratch[lane] : 0;
-                    d = lane < n ? dtmp[lane] : 0.0f;
-                    __builtin_amdgcn_wave_barrier();
-                }
             } else {
-                if (nb >= 0) { // :403-409
-                    int vi = level == 0 ? nb : ix.up_off[nb];
-                    unsigned bit = 1u << (vi & 31);
-                    unsigned old = atomicOr(&bitmap[vi >> 5], bit);
-                    todo = !(old & bit) && !(ix.has_deleted && ix.deleted[nb]);
-                }
+                todo = probe_new<COH>(ix, bitmap, level, nb);
                 m = __ballot(todo);
                 n = __popcll(m);
                 PH_ADD(w, 1);
@@ -592,75 +706,30 @@ DEVI bool beam_layer_regs(const MnDevIndex &ix, WaveCtx &w, WHeap &res, uint2 *p
                     __builtin_amdgcn_wave_barrier();
                     myslot = lane < n ? w.scratch[lane] : 0;
                     d = ctx_distance<ORDER, NCH>(ix, w, myslot, n, lane);
+                    compacted = true;
+                    nb_todo = todo;
+                    nb_rank = rank;
+                    todo = lane < n; // (compacted: the rows whose distances were asked for)
                 }
             }
             if (n > 0) {
                 w.n_dist += n;
                 PH_ADD(w, 2);
-                if (__ballot(lane < n && !(d == d))) {
+                if (__ballot(todo && !(d == d))) {
                     ok = false; // a NaN distance: the heaps' business
                     break;
                 }
-                // (:413-425) what can enter: everything while there is room, else what is nearer than the worst result
-                const bool acc = lane < n && (rn < ef || d < wk);
-                const unsigned long long am = __ballot(acc);
-                const int na = __popcll(am);
-                PH_CNT(w, 4, na);
-                if (na > 0) {
-                    improved = 1;
-                    int s0 = 0, s1 = 0, s2 = 0, s3 = 0; // how far each member moves up
-                    int mypos = 0;                      // (lane j < n) the rank of new distance j
-                    unsigned long long rem = am;
-                    while (rem) {
-                        const int j = __builtin_amdgcn_readfirstlane(__ffsll((long long)rem) - 1);
-                        rem &= rem - 1;
-                        const float y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), j));
-                        int before = 0, after = 0;
-#define MN_SA_CNT(T, K, V, S)                                                                                                    \
-    if (rn > T * 64) {                                                                                                           \
-        const bool gt = y < K;                                                                                                   \
-        before += __popcll(__builtin_amdgcn_ballot_w64(K < y));                                                                  \
-        after += __popcll(__builtin_amdgcn_ballot_w64(gt));                                                                      \
-        S += gt ? 1 : 0;                                                                                                         \
-    }
-                        MN_SA_EACH(MN_SA_CNT)
-#undef MN_SA_CNT
-                        const int nb_before = __popcll(__builtin_amdgcn_ballot_w64(acc && d < y));
-                        const int nb_after = __popcll(__builtin_amdgcn_ballot_w64(acc && y < d));
-                        if (before + after != rn || nb_before + nb_after != na - 1) { // an equal key somewhere
-                            ok = false;
-                            break;
-                        }
-                        mypos = lane == j ? before + nb_before : mypos;
-                    }
-                    if (!ok)
-                        break;
-                    __builtin_amdgcn_wave_barrier();
-#define MN_SA_OUT(T, K, V, S)                                                                                                    \
-    if (rn > T * 64) {                                                                                                           \
-        const int r = T * 64 + lane, p = r + S;                                                                                  \
-        if (r < rn && p < ef)                                                                                                    \
-            perm[p] = make_uint2(f2u(K), (unsigned)V);                                                                           \
-    }
-                    MN_SA_EACH(MN_SA_OUT)
-#undef MN_SA_OUT
-                    if (acc && mypos < ef)
-                        perm[mypos] = make_uint2(f2u(d), (unsigned)myslot);
-                    __builtin_amdgcn_wave_barrier();
-                    rn = rn + na < ef ? rn + na : ef;
-#define MN_SA_IN(T, K, V, S)                                                                                                     \
-    if (rn > T * 64) {                                                                                                           \
-        const int r = T * 64 + lane;                                                                                             \
-        const uint2 it = perm[r < rn ? r : 0];                                                                                   \
-        K = r < rn ? u2f(it.x) : __builtin_nanf("");                                                                             \
-        V = r < rn ? (int)it.y : -1;                                                                                             \
-    }
-                    MN_SA_EACH(MN_SA_IN)
-#undef MN_SA_IN
-                    wk = u2f(rflu(perm[rn - 1].x));
-                    __builtin_amdgcn_wave_barrier();
+                const float worst0 = s.rn >= ef ? s.wk : __builtin_inff();
+                unsigned long long entering;
+                ok = sq_merge(s, perm, d, myslot, todo, ef, lane, improved, entering);
+                if (!WIDE && w.rlog) { // (speculative windows) what this row's expansion depended on
+                    // lanes → positions of the row: the compacted path numbered the new neighbours in list order
+                    const bool e_here = compacted ? (nb_todo && ((entering >> nb_rank) & 1ull)) : ((entering >> lane) & 1ull) != 0;
+                    log_row_detail(w, worst0, __ballot(e_here), lane);
                 }
                 PH_ADD(w, 3);
+            } else if (!WIDE && w.rlog) {
+                log_row_detail(w, s.rn >= ef ? s.wk : __builtin_inff(), 0ull, lane); // nothing new in the row: nothing could be pushed
             }
         }
         stale = improved ? 0 : stale + 1; // :428-432
@@ -675,14 +744,14 @@ DEVI bool beam_layer_regs(const MnDevIndex &ix, WaveCtx &w, WHeap &res, uint2 *p
     if (!ok)
         return false;
     // hand the results over as the heap array the callers expect: keys -distance, root (position 1) = the worst
-    const int n = rn;
+    const int n = s.rn;
     __builtin_amdgcn_wave_barrier();
     res.size = n;
     res.ovf = 0;
     res.sorted = 1;
 #define MN_SA_RES(T, K, V, S)                                                                                                    \
     if (T * 64 + lane < n)                                                                                                       \
-        hset(res, n - (T * 64 + lane), make_uint2(f2u(-K), (unsigned)(V & 0x7fffffff)));
+        hset(res, n - (T * 64 + lane), make_uint2(f2u(-s.K), (unsigned)(s.V & 0x7fffffff)));
     MN_SA_EACH(MN_SA_RES)
 #undef MN_SA_RES
     __builtin_amdgcn_wave_barrier();

@@ -448,3 +448,10 @@ void mn_launch_link_commit_records(const MnDevIndex &ix, const MnLinkArgs &a, in
         hipLaunchKernelGGL(k_link_commit_records, dim3((unsigned)seg, (unsigned)a.world), dim3(64), 0, st, ix, a, all_records, seg);
     hipLaunchKernelGGL(k_link_reset_counts, dim3((max_tuples + 255) / 256), dim3(256), 0, st, a);
 }
+
+// HIP loads a translation unit's code object on the first use of one of its kernels (several milliseconds for these units): an
+// index asks for all of them when it is created (mn_index.hip), so that the first query or insert of a process does not pay.
+void mn_module_touch_build() {
+    hipFuncAttributes fa;
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_link_offsets));
+}

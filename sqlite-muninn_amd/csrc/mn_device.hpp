@@ -66,6 +66,8 @@ struct MnSearchArgs {
     uint2 *res_ovf;          // [nq][res_gcap]
     int res_gcap;
     unsigned long long *counters; // [0] n_dist [1] n_expanded [2] overflowed queries
+    unsigned long long *q_counters; // or, when not null: [nq][4] the same per query, plain stores (a few queries answered into the
+                                    // index's pinned host block: no counter memset before the launch, no copy after it)
     int use_tile;                 // SSE order: stage candidate rows through the LDS tile (coalesced loads)
     int lds_bitmap;               // k_beam_coop, search: the layer-0 visited bitmap lives in LDS (small indexes: one query's
                                   // bitmap fits, and the visited probe stops being a global-memory round trip per expansion)
@@ -92,6 +94,11 @@ bool mn_lds_grant(const void *kernel, size_t bytes); // asks once per kernel and
 #endif
 
 // host-callable launchers (mn_kernels.hip)
+// force the load of each translation unit's code object (see the definitions)
+void mn_module_touch_kernels();
+void mn_module_touch_seq();
+void mn_module_touch_spec();
+void mn_module_touch_build();
 void mn_launch_norms(const MnDevIndex &ix, int first_slot, int n, float *norms_out, hipStream_t st);
 void mn_launch_dist_batch(int metric, int order, const float *d_query, const float *d_rows, long long n, int dim, int ld,
                           float *d_out, hipStream_t st);
@@ -155,9 +162,11 @@ void mn_launch_insert_seq(const MnDevIndex &ix, const int *d_slots, int n, int e
 #define MN_CHLOG_INTS 5
 
 // speculative exact inserts (mn_spec.hip): commit a window of searched inserts in order, stop at the first stale one
+#define MN_RLOG_INTS 4      // ints per entry of a search's read log (mn_beam.hpp log_row_read)
+#define MN_SPEC_SAVE_CAP 4096 // rows a speculative window may rewrite with their old lists kept (more: those rows invalidate as before)
 void mn_launch_spec_commit(const MnDevIndex &ix, const int *d_slots, int W, int nlev, const int *sel, const int *nsel,
-                           const int *readlog, int readcap, const int *nread, int *stamp0, int *stampU, int epoch, int *d_ncommit,
-                           hipStream_t st);
+                           const int *readlog, int readcap, const int *nread, int *stamp0, int *stampU, int *sidx0, int *sidxU,
+                           int *saved_rows, int epoch, int *d_ncommit, hipStream_t st);
 
 // rows[r] = (slot, level): writes the row's neighbour slots and dist(slot, neighbour) (mn_kernels.hip)
 void mn_launch_edge_rows(const MnDevIndex &ix, const int *d_row_slot, const int *d_row_level, int n_rows, int *d_out_nbr,

@@ -230,6 +230,9 @@ DEVI float sse_row(const float *__restrict__ row, const float *q_lds, int dim, i
     // loads are the only parallelism there is.  (Batches of 64 and 32 positions for the lone-search kernels were tried: 768-d
     // distances 7.7 -> 6.5 us, but the code they add slows every other step of those kernels by 5-8 % — they run one
     // wavefront against the instruction cache; the LDS tile of sse_rows_lat_tiled does the same job better.)
+    // (round 4: issuing batch k+1's loads before batch k's sums — one round trip per 128-float row instead of two — made a lone
+    // query SLOWER, 0.272 -> 0.303 ms at 3k x 128, same box, interleaved: these kernels are bound by instruction issue and fetch,
+    // not by the loads; profiles/r04_ab_pipelined_loads.txt)
     sse_chunks<L2, MN_SSE_UNROLL>(row, q_lds, j, steps, c, s);
 #pragma unroll 4
     for (; c < steps; c++) {
@@ -410,6 +413,8 @@ DEVI float sse_rows_lat_tiled(const MnDevIndex &ix, const float *q_lds, float *t
         const float *tp = tile + gr * RS + j * P; // row gr, plane j
         const float *qp = qT + j * P;
         int c = 0;
+        // (round 4: two register sets in turn, the LDS reads of the next 16 positions issued before the sums of these: a lone
+        // query at 10k x 768 went from 0.538 to 0.580 ms, same box, interleaved — profiles/r04_ab_latency_variants.txt; not kept)
 #pragma unroll 4
         for (; c + 4 <= steps; c += 4) {
             const float4 b = *reinterpret_cast<const float4 *>(tp + c);

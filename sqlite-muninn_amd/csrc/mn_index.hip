@@ -15,6 +15,7 @@
 #include <cstring>
 #include <string>
 #include <unordered_map>
+#include <mutex>
 #include <vector>
 
 #define MN_MAX_M 512        // longest supported M (lists of 2M + 1 entries are pruned in LDS)
@@ -114,6 +115,7 @@ struct mn_index {
     unsigned rng_state = 42;
     int node_count = 0;
     int n_deleted = 0; // soft-deleted nodes among the slots
+    bool last_on_host = false; // `last` already holds the counters of the last search (the few-queries path)
     int64_t slot_hint = 0; // slots a running bulk build will reach (sync_meta sizes the device tables for it at once)
     // host metadata, slot-indexed
     std::vector<int64_t> ids;
@@ -153,7 +155,7 @@ struct mn_index {
     DevBuf<int> er_slot, er_level, er_nbr;
     DevBuf<float> er_dist;
     // speculative exact build: read logs of a window's searches, per-row rewrite epochs
-    DevBuf<int> ws_readlog, ws_nread, ws_ncommit, d_stamp0, d_stampU;
+    DevBuf<int> ws_readlog, ws_nread, ws_ncommit, d_stamp0, d_stampU, d_sidx0, d_sidxU, d_saved_rows;
     int spec_epoch = 0;
     std::vector<int> staged; // mn_hnsw_batch_stage: slots added but not yet searched / linked
     DevBuf<int> d_staged;
@@ -658,6 +660,18 @@ extern "C" mn_index *mn_hnsw_create_on(int dim, int metric, int M, int ef_constr
         delete x;
         return nullptr;
     }
+    { // once per process and device: the kernels' code objects are loaded now, not under the first query (MN_LAZY_MODULES=1: as before)
+        static std::mutex mu;
+        static unsigned long long touched = 0;
+        std::lock_guard<std::mutex> lk(mu);
+        if (device < 64 && !(touched >> device & 1ull) && !getenv("MN_LAZY_MODULES")) {
+            touched |= 1ull << device;
+            mn_module_touch_kernels();
+            mn_module_touch_seq();
+            mn_module_touch_spec();
+            mn_module_touch_build();
+        }
+    }
     return x;
 } MN_GUARD_END(set_err, MN_NOTHING, nullptr)
 
@@ -685,6 +699,7 @@ extern "C" void mn_hnsw_destroy(mn_index *x) {
     if (x->pin) { (void)hipHostFree(x->pin); x->pin = nullptr; x->pin_cap = 0; }
     x->sh_lids.release(); x->sh_gd.release(); x->sh_ld.release();
     x->ws_readlog.release(); x->ws_nread.release(); x->ws_ncommit.release(); x->d_stamp0.release(); x->d_stampU.release();
+    x->d_sidx0.release(); x->d_sidxU.release(); x->d_saved_rows.release();
     if (x->ev0) (void)hipEventDestroy(x->ev0);
     if (x->ev1) (void)hipEventDestroy(x->ev1);
     if (x->ev2) (void)hipEventDestroy(x->ev2);
@@ -772,8 +787,10 @@ static int fetch_counters(mn_index *x) {
     return 0;
 }
 
-extern "C" int mn_hnsw_search_batch_dev(mn_index *x, const float *d_queries, int64_t nq, int k, int ef, int64_t *d_ids,
-                                        float *d_dists, int *d_counts) try {
+// q_counters: see MnSearchArgs (the few-queries path: the stream then carries the search kernel and nothing else — no counter
+// memset, no event records, no copy back)
+static int search_batch_dev_impl(mn_index *x, const float *d_queries, int64_t nq, int k, int ef, int64_t *d_ids, float *d_dists,
+                                 int *d_counts, unsigned long long *q_counters) {
     if (use_device(x))
         return -1;
     if (nq <= 0)
@@ -802,15 +819,20 @@ extern "C" int mn_hnsw_search_batch_dev(mn_index *x, const float *d_queries, int
     // every allocation happens here, for the largest chunk: nothing between the two event records can fail half-way
     if (reserve_search_ws(x, chunk, ef))
         return -1;
-    HIPCHK(hipEventRecord(x->ev0, st));
+    if (!q_counters) {
+        HIPCHK(hipEventRecord(x->ev0, st));
+        x->last_on_host = false;
+    }
     for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
         const int64_t m = std::min<int64_t>(chunk, nq - q0);
         MnSearchArgs a;
         memset(&a, 0, sizeof(a));
-        if (prepare_search_ws(x, m, ef, a, q0 == 0, true)) { // (sized above: memsets only)
-            (void)hipEventRecord(x->ev1, st);
+        if (prepare_search_ws(x, m, ef, a, q0 == 0 && !q_counters, true)) { // (sized above: memsets only)
+            if (!q_counters)
+                (void)hipEventRecord(x->ev1, st);
             return -1;
         }
+        a.q_counters = q_counters ? q_counters + (size_t)q0 * 4 : nullptr;
         a.queries = d_queries + (size_t)q0 * x->dim;
         a.nq = m;
         a.k = k;
@@ -822,9 +844,15 @@ extern "C" int mn_hnsw_search_batch_dev(mn_index *x, const float *d_queries, int
         a.out_counts = d_counts + q0;
         mn_launch_search(v, a, false, st);
     }
-    HIPCHK(hipEventRecord(x->ev1, st));
+    if (!q_counters)
+        HIPCHK(hipEventRecord(x->ev1, st));
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+extern "C" int mn_hnsw_search_batch_dev(mn_index *x, const float *d_queries, int64_t nq, int k, int ef, int64_t *d_ids,
+                                        float *d_dists, int *d_counts) try {
+    return search_batch_dev_impl(x, d_queries, nq, k, ef, d_ids, d_dists, d_counts, nullptr);
 } MN_GUARD_END(set_err, MN_NOTHING, -1)
 
 // A sharded search all-gathers every shard's overflow count next to its top-k (mn_hnsw_search_sharded_dev): every rank sees
@@ -882,7 +910,7 @@ static int search_small(mn_index *x, const float *queries, int64_t nq, int k, in
     const size_t qb = (size_t)nq * x->dim * sizeof(float), ib = (size_t)nq * k * sizeof(int64_t), db = (size_t)nq * k * sizeof(float);
     const size_t cb = ((size_t)nq * sizeof(int) + 7) & ~(size_t)7;
     const size_t o_ids = (qb + 15) & ~(size_t)15, o_d = o_ids + ib, o_c = (o_d + db + 7) & ~(size_t)7, o_cnt = o_c + cb;
-    const size_t need = o_cnt + 4 * sizeof(unsigned long long);
+    const size_t need = o_cnt + (size_t)nq * 4 * sizeof(unsigned long long);
     if (push_links(x) || sync_meta(x)) // (before the block is written: a pending single-slot upload stages through it too)
         return -1;
     if (!pin_reserve(x, need)) {
@@ -891,18 +919,25 @@ static int search_small(mn_index *x, const float *queries, int64_t nq, int k, in
     }
     HIPCHK(hipStreamSynchronize(st));
     memcpy(x->pin, queries, qb);
-    if (mn_hnsw_search_batch_dev(x, (const float *)x->pin, nq, k, ef, (int64_t *)(x->pin + o_ids), (float *)(x->pin + o_d),
-                                 (int *)(x->pin + o_c)))
+    unsigned long long *qc = reinterpret_cast<unsigned long long *>(x->pin + o_cnt);
+    if (search_batch_dev_impl(x, (const float *)x->pin, nq, k, ef, (int64_t *)(x->pin + o_ids), (float *)(x->pin + o_d),
+                              (int *)(x->pin + o_c), qc))
         return -1;
     const bool launched = x->entry_id != -1 && x->node_count > 0;
-    if (launched)
-        HIPCHK(hipMemcpyAsync(x->pin + o_cnt, x->ws_counters.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipStreamSynchronize(st)); // the one wait of a lone query: the kernel has answered into the block, counters included
     memcpy(out_ids, x->pin + o_ids, ib);
     memcpy(out_dists, x->pin + o_d, db);
     memcpy(out_counts, x->pin + o_c, (size_t)nq * sizeof(int));
     if (launched) {
-        counters_from(x, (const unsigned long long *)(x->pin + o_cnt));
+        unsigned long long tot[4] = {0, 0, 0, 0};
+        for (int64_t q = 0; q < nq; q++)
+            for (int i = 0; i < 3; i++)
+                tot[i] += qc[q * 4 + i];
+        x->last.last_n_dist = (int64_t)tot[0];
+        x->last.last_n_expanded = (int64_t)tot[1];
+        x->last.last_n_overflow = (int64_t)tot[2];
+        x->last.last_kernel_ms = 0.0f; // (not timed: no event records on this path)
+        x->last_on_host = true;
         if (x->last.last_n_overflow) {
             set_err("mn_hnsw_search: %lld queries exceeded heap workspace", (long long)x->last.last_n_overflow);
             return -1;
@@ -999,7 +1034,7 @@ static int build_search(mn_index *x, const int *slots, int nq, MnSearchArgs &a, 
     a.nsel = x->ws_nsel.p;
     a.nlev = nlev;
     if (log_cap > 0) {
-        if (x->ws_readlog.reserve((size_t)nq * log_cap, false, st)) return -1;
+        if (x->ws_readlog.reserve((size_t)nq * log_cap * MN_RLOG_INTS, false, st)) return -1;
         if (x->ws_nread.reserve((size_t)nq, false, st)) return -1;
         a.readlog = x->ws_readlog.p;
         a.readcap = log_cap;
@@ -1007,6 +1042,7 @@ static int build_search(mn_index *x, const int *slots, int nq, MnSearchArgs &a, 
     }
     MnDevIndex v = dev_view(x);
     HIPCHK(hipEventRecord(x->ev0, st));
+    x->last_on_host = false;
     mn_launch_search(v, a, true, st);
     HIPCHK(hipEventRecord(x->ev1, st));
     return 0;
@@ -1157,6 +1193,7 @@ static int run_sequential(mn_index *x, const std::vector<int> &slots) {
     }
     MnSearchArgs a;
     memset(&a, 0, sizeof(a));
+    x->last_on_host = false;
     if (prepare_search_ws(x, 1, x->efc, a))
         return -1;
     long long bmu_words = ((int64_t)std::max(1, x->n_pool_rows) + 31) / 32;
@@ -1238,6 +1275,9 @@ static int run_speculative(mn_index *x, const std::vector<int> &slots) {
     const int LOG_CAP = 2048;
     if (x->d_stamp0.reserve((size_t)x->d_ids.cap, true, st, 0)) return -1;
     if (x->d_stampU.reserve((size_t)std::max(1, x->n_pool_rows) + 1, true, st, 0)) return -1;
+    if (x->d_sidx0.reserve((size_t)x->d_ids.cap, false, st)) return -1; // (read only where the stamp is this window's)
+    if (x->d_sidxU.reserve((size_t)std::max(1, x->n_pool_rows) + 1, false, st)) return -1;
+    if (x->d_saved_rows.reserve((size_t)MN_SPEC_SAVE_CAP * 64, false, st)) return -1;
     if (x->ws_ncommit.reserve(1, false, st)) return -1;
     int window = 16, poor = 0;
     long long searched = 0, rounds = 0, plain = 0;
@@ -1271,7 +1311,8 @@ static int run_speculative(mn_index *x, const std::vector<int> &slots) {
         }
         MnDevIndex v = dev_view(x);
         mn_launch_spec_commit(v, x->ws_qslots.p, W, a.nlev, x->ws_sel.p, x->ws_nsel.p, x->ws_readlog.p, LOG_CAP, x->ws_nread.p,
-                              x->d_stamp0.p, x->d_stampU.p, x->spec_epoch, x->ws_ncommit.p, st);
+                              x->d_stamp0.p, x->d_stampU.p, x->d_sidx0.p, x->d_sidxU.p, x->d_saved_rows.p, x->spec_epoch,
+                              x->ws_ncommit.p, st);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(x->ev2, st));
         int done = 0;
@@ -2207,7 +2248,7 @@ extern "C" int mn_hnsw_build_stats(mn_index *x, mn_build_stats *out, int reset) 
 extern "C" int mn_hnsw_last_launch(mn_index *x, mn_launch_stats *out) try {
     if (use_device(x))
         return -1;
-    if (fetch_counters(x))
+    if (!x->last_on_host && fetch_counters(x)) // (a lone query's counters came back with its answer)
         return -1;
     *out = x->last;
     return 0;

@@ -187,7 +187,7 @@ DEVI void beam_query(const MnDevIndex &ix, const MnSearchArgs &a, const long lon
             *coop->qnorm = w.qnorm;
     }
     if (BUILD && a.readlog) {
-        w.rlog = a.readlog + (size_t)qi * a.readcap;
+        w.rlog = a.readlog + (size_t)qi * a.readcap * MN_RLOG_INTS;
         w.rcap = a.readcap;
     }
 
@@ -267,10 +267,16 @@ DEVI void beam_query(const MnDevIndex &ix, const MnSearchArgs &a, const long lon
     if (lane == 0) {
         if (BUILD && a.readlog)
             a.nread[qi] = w.nr; // > readcap: the log is incomplete and the commit step must not trust it
-        atomicAdd(&a.counters[0], w.n_dist);
-        atomicAdd(&a.counters[1], w.n_exp);
-        if (cand.ovf || res.ovf)
-            atomicAdd(&a.counters[2], 1ull);
+        if (a.q_counters) {
+            a.q_counters[(size_t)qi * 4 + 0] = w.n_dist;
+            a.q_counters[(size_t)qi * 4 + 1] = w.n_exp;
+            a.q_counters[(size_t)qi * 4 + 2] = (cand.ovf || res.ovf) ? 1ull : 0ull;
+        } else {
+            atomicAdd(&a.counters[0], w.n_dist);
+            atomicAdd(&a.counters[1], w.n_exp);
+            if (cand.ovf || res.ovf)
+                atomicAdd(&a.counters[2], 1ull);
+        }
     }
 }
 
@@ -576,3 +582,10 @@ extern "C" int mn_debug_phase_kernels(unsigned long long *out, int reset) { // p
     return 0;
 }
 #endif
+
+// HIP loads a translation unit's code object on the first use of one of its kernels (several milliseconds for these units): an
+// index asks for all of them when it is created (mn_index.hip), so that the first query or insert of a process does not pay.
+void mn_module_touch_kernels() {
+    hipFuncAttributes fa;
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_merge_topk));
+}

@@ -498,3 +498,10 @@ extern "C" int mn_debug_phase_seq(unsigned long long *out, int reset) { // probe
     return 0;
 }
 #endif
+
+// HIP loads a translation unit's code object on the first use of one of its kernels (several milliseconds for these units): an
+// index asks for all of them when it is created (mn_index.hip), so that the first query or insert of a process does not pay.
+void mn_module_touch_seq() {
+    hipFuncAttributes fa;
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_insert_seq<MN_ORDER_SSE_V, 0, false>));
+}

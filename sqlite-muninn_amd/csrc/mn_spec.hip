@@ -4,8 +4,9 @@
 // honours that with a single wavefront.  Here a WINDOW of consecutive inserts has its searches run at once against
 // the graph as it stands (k_beam<BUILD>, one wavefront each, every link row read is logged), and one workgroup then
 // commits the window in order:
-//   insert j is valid  ⇔  none of the link rows its search read was rewritten by inserts 0..j-1 of the window
+//   insert j is valid  ⇐  none of the link rows its search read was rewritten by inserts 0..j-1 of the window
 //                          (rows carry the epoch of their last rewrite; the first insert of a window is always valid)
+//                      or (round 4) every such rewrite provably leaves the search as it was: see spec_rewrite_is_harmless
 // A valid insert's search result is exactly what the sequential algorithm would have computed, so its links are
 // applied to the live rows exactly as hnsw_insert applies them (targets in list order; MN-RU prune, :601-646).  At the
 // first invalid insert the window stops: the host restarts from there, so the prefix property — and with it the
@@ -31,6 +32,9 @@ struct MnSpecArgs {
     const int *nread; // [W]
     int *stamp0;      // [n_slots]     epoch of the last rewrite of the node's layer-0 row
     int *stampU;      // [n_pool_rows] same for upper-layer rows
+    int *sidx0;       // [n_slots]     valid while stamp == epoch: where in saved_rows the row's list of the window's start is kept
+    int *sidxU;       // [n_pool_rows] (-1: not kept, the save buffer was full)
+    int *saved_rows;  // [MN_SPEC_SAVE_CAP][64]
     int epoch;
     int *ncommit;     // out: inserts committed (>= 1)
     size_t wave_bytes; // LDS per wavefront
@@ -42,19 +46,93 @@ DEVI int *spec_row(const MnDevIndex &ix, int node, int level) {
     return ix.links_up + ((size_t)ix.up_off[node] + (level - 1)) * ix.WU;
 }
 
-DEVI void spec_stamp(const MnDevIndex &ix, const MnSpecArgs &a, int node, int level) {
-    int *p = level == 0 ? a.stamp0 + node : a.stampU + (ix.up_off[node] + level - 1);
-    __hip_atomic_store(p, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// A row is about to be rewritten (one wavefront; v = its list as it stands, lane < W): the first time in a window its list
+// — the one every search of the window read — is kept, then the row is stamped.
+DEVI void spec_stamp(const MnDevIndex &ix, const MnSpecArgs &a, int node, int level, int v, int W, int *nsaved, int lane) {
+    const size_t r = level == 0 ? (size_t)node : (size_t)(ix.up_off[node] + level - 1);
+    int *p = (level == 0 ? a.stamp0 : a.stampU) + r;
+    int *q = (level == 0 ? a.sidx0 : a.sidxU) + r;
+    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.epoch)
+        return; // (uniform) rewritten before in this window: the kept list is the older one
+    int k = 0;
+    if (lane == 0)
+        k = W <= 64 ? atomicAdd(nsaved, 1) : MN_SPEC_SAVE_CAP;
+    k = __builtin_amdgcn_readfirstlane(k);
+    if (k < MN_SPEC_SAVE_CAP) {
+        if (lane < 64)
+            a.saved_rows[(size_t)k * 64 + lane] = lane < W ? v : -1;
+    } else {
+        k = -1;
+    }
+    if (lane == 0) {
+        __hip_atomic_store(q, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Round 4.  One log entry of insert jj's search names a row that an earlier insert of the window has rewritten since.  The
+// search ran on the row's OLD list; the sequential algorithm would have run on the new one.  With distinct keys a beam search is
+// a computation on sets (mn_beam.hpp, beam_layer_regs), and by induction over its expansions the two runs stay identical if at
+// this row
+//   * no neighbour that was REMOVED from the list could have been pushed when the search opened it (the log entry carries the
+//     positions that were new and nearer than the worst result of that moment): a neighbour that was already visited, or was
+//     evaluated and rejected, leaves no trace — if it turns up again in another row the worst result has only come nearer;
+//   * every neighbour that was ADDED (one of the window's new nodes: nothing else is ever added) would have been rejected: its
+//     distance to this insert's vector, computed here by the search's own code, is not below that worst result.
+// Anything else — a greedy descent's row, a search that met equal keys and went back to the heaps, a row of more than 64 links,
+// a list that was not kept — carries the log's defaults (-inf / all positions) and invalidates the insert as before.
+// One wavefront; qv = the insert's vector (LDS), qnorm as its search had it.  tmp: LDS, 64 ints.
+template <int ORDER, int NCH>
+DEVI bool spec_rewrite_is_harmless(const MnDevIndex &ix, const MnSpecArgs &a, const int *e, const float *qv, float qnorm, int *tmp,
+                                   int lane) {
+    const int r = e[0];
+    const float worst = __int_as_float(e[1]);
+    const unsigned long long could = (unsigned long long)(unsigned)e[2] | ((unsigned long long)(unsigned)e[3] << 32);
+    if (!(worst > -__builtin_inff())) // the defaults (or a NaN)
+        return false;
+    const int k = __hip_atomic_load((r >= 0 ? a.sidx0 + r : a.sidxU + (-r - 2)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k < 0)
+        return false;
+    const int W = r >= 0 ? ix.W0 : ix.WU;
+    if (W > 64)
+        return false;
+    const int *cur_row = r >= 0 ? ix.links0 + (size_t)r * ix.W0 : ix.links_up + (size_t)(-r - 2) * ix.WU;
+    const int o = lane < W ? a.saved_rows[(size_t)k * 64 + lane] : -1;
+    const int c = lane < W ? ld_link<true>(cur_row + lane) : -1;
+    bool o_stays = false, c_was = false;
+    for (int p = 0; p < W; p++) { // (lists of ≤ 64: all pairs)
+        const int cp = __builtin_amdgcn_readlane(c, p), op = __builtin_amdgcn_readlane(o, p);
+        o_stays |= o == cp;
+        c_was |= c == op;
+    }
+    const unsigned long long removed = __ballot(o >= 0 && !o_stays);
+    if (removed & could)
+        return false;
+    const bool added = c >= 0 && !c_was;
+    const unsigned long long am = __ballot(added);
+    const int na = __popcll(am);
+    if (na == 0)
+        return true;
+    const int rank = __popcll(am & ((1ull << lane) - 1ull));
+    __builtin_amdgcn_wave_barrier();
+    if (added)
+        tmp[rank] = c;
+    __builtin_amdgcn_wave_barrier();
+    const int myslot = lane < na ? tmp[lane] : 0;
+    __builtin_amdgcn_wave_barrier();
+    const float d = rows_distance<ORDER, NCH>(ix, qv, qnorm, myslot, na, lane);
+    return __ballot(lane < na && !(d >= worst)) == 0; // (a NaN distance fails too)
 }
 
 template <int ORDER, int NCH>
 __global__ void __launch_bounds__(MN_SPEC_MAX_WAVES * 64) k_spec_commit(MnDevIndex ix, MnSpecArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, NW = blockDim.x >> 6;
-    int *flag = reinterpret_cast<int *>(smem); // [0] invalid insert  [1] tie in this (insert, layer)
+    int *flag = reinterpret_cast<int *>(smem); // [0] invalid insert  [1] tie in this (insert, layer)  [2] rewritten rows read  [3] rows kept
     int *act = flag + 16;                      // [64] per target: 0 nothing, 1 append, 2 pruned row
     int *cntA = act + 64;                      // [64] append position
-    int *newrow = cntA + 64;                   // [64][64]
+    int *hot = cntA + 64;                      // [64] log entries of the insert under test whose row has been rewritten
+    int *newrow = hot + 64;                    // [64][64]
     unsigned char *pw = reinterpret_cast<unsigned char *>(newrow + 64 * 64) + (size_t)wv * a.wave_bytes;
     int *list = reinterpret_cast<int *>(pw);            // [128]
     float *nd = reinterpret_cast<float *>(list + 128);  // [128]
@@ -62,11 +140,17 @@ __global__ void __launch_bounds__(MN_SPEC_MAX_WAVES * 64) k_spec_commit(MnDevInd
     float *tv = reinterpret_cast<float *>(mn + 128);    // [ld]
 
     int done = a.W;
+    if (tid == 0)
+        flag[3] = 0;
+    __syncthreads();
     for (int jj = 0; jj < a.W; jj++) {
         const int s = a.slots[jj];
         // ── did an earlier insert of this window rewrite a row this search read? ──
         if (tid == 0)
             flag[0] = 0;
+        __syncthreads();
+        if (tid == 0)
+            flag[2] = 0; // rewritten rows among those the search read
         __syncthreads();
         if (jj > 0) {
             const int nr = a.nread[jj];
@@ -74,16 +158,40 @@ __global__ void __launch_bounds__(MN_SPEC_MAX_WAVES * 64) k_spec_commit(MnDevInd
                 if (tid == 0)
                     flag[0] = 1; // incomplete log: cannot be trusted
             } else {
-                const int *log = a.readlog + (size_t)jj * a.readcap;
+                const int *log = a.readlog + (size_t)jj * a.readcap * MN_RLOG_INTS;
                 for (int i = tid; i < nr; i += blockDim.x) {
-                    const int r = log[i];
+                    const int r = log[(size_t)i * MN_RLOG_INTS];
                     const int *p = r >= 0 ? a.stamp0 + r : a.stampU + (-r - 2);
-                    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.epoch)
-                        flag[0] = 1;
+                    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.epoch) {
+                        const int h = atomicAdd(&flag[2], 1);
+                        if (h < 64)
+                            hot[h] = i;
+                        else
+                            flag[0] = 1; // (more than the check looks at)
+                    }
                 }
             }
         }
         __syncthreads();
+        if (!flag[0] && flag[2] > 0) { // (uniform) would those rewrites have changed this search?
+            const int nh = flag[2];
+            const int *log = a.readlog + (size_t)jj * a.readcap * MN_RLOG_INTS;
+            if (wv < nh) {
+                const float *src = ix.vectors + (size_t)s * ix.ld;
+                for (int e = lane; e < ix.ld; e += 64)
+                    tv[e] = src[e];
+                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_wave_barrier();
+                const float qnorm = ix.metric == 1 ? ix.norms[s] : 0.0f;
+                for (int h = wv; h < nh; h += NW)
+                    if (!spec_rewrite_is_harmless<ORDER, NCH>(ix, a, log + (size_t)hot[h] * MN_RLOG_INTS, tv, qnorm, list, lane)) {
+                        if (lane == 0)
+                            flag[0] = 1;
+                        break;
+                    }
+            }
+            __syncthreads();
+        }
         if (flag[0]) { // uniform over the workgroup
             done = jj;
             break;
@@ -150,14 +258,13 @@ __global__ void __launch_bounds__(MN_SPEC_MAX_WAVES * 64) k_spec_commit(MnDevInd
                     if (act[i] == 0)
                         continue;
                     int *trow = spec_row(ix, t, l);
+                    spec_stamp(ix, a, t, l, lane < W ? ld_link<true>(trow + lane) : -1, W, &flag[3], lane);
                     if (act[i] == 1) {
                         if (lane == 0)
                             st_link(trow + cntA[i], s);
                     } else if (lane < W) {
                         st_link(trow + lane, newrow[i * 64 + lane]);
                     }
-                    if (lane == 0)
-                        spec_stamp(ix, a, t, l);
                 }
             } else if (wv == 0) {
                 // the layer in list order by one wavefront, as k_insert_seq does it
@@ -175,10 +282,9 @@ __global__ void __launch_bounds__(MN_SPEC_MAX_WAVES * 64) k_spec_commit(MnDevInd
                     if (__ballot(v == s))
                         continue;
                     if (cnt < W) {
-                        if (lane == 0) {
+                        spec_stamp(ix, a, t, l, v, W, &flag[3], lane);
+                        if (lane == 0)
                             st_link(trow + cnt, s);
-                            spec_stamp(ix, a, t, l);
-                        }
                         continue;
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -193,10 +299,9 @@ __global__ void __launch_bounds__(MN_SPEC_MAX_WAVES * 64) k_spec_commit(MnDevInd
                     __builtin_amdgcn_wave_barrier();
                     const float tnorm = ix.metric == 1 ? ix.norms[t] : 0.0f;
                     prune_row<ORDER, NCH, true, true>(ix, tv, tnorm, list, nd, mn, W + 1, W, l, lane);
+                    spec_stamp(ix, a, t, l, v, W, &flag[3], lane);
                     if (lane < W)
                         st_link(trow + lane, list[lane]);
-                    if (lane == 0)
-                        spec_stamp(ix, a, t, l);
                     __builtin_amdgcn_s_waitcnt(0);
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -222,8 +327,8 @@ static int pick_nch_p(int ld) {
 
 // one workgroup; as many wavefronts as 60 KB of LDS allow (≤ 8)
 void mn_launch_spec_commit(const MnDevIndex &ix, const int *d_slots, int W, int nlev, const int *sel, const int *nsel,
-                           const int *readlog, int readcap, const int *nread, int *stamp0, int *stampU, int epoch, int *d_ncommit,
-                           hipStream_t st) {
+                           const int *readlog, int readcap, const int *nread, int *stamp0, int *stampU, int *sidx0, int *sidxU,
+                           int *saved_rows, int epoch, int *d_ncommit, hipStream_t st) {
     MnSpecArgs a;
     a.slots = d_slots;
     a.W = W;
@@ -235,10 +340,13 @@ void mn_launch_spec_commit(const MnDevIndex &ix, const int *d_slots, int W, int 
     a.nread = nread;
     a.stamp0 = stamp0;
     a.stampU = stampU;
+    a.sidx0 = sidx0;
+    a.sidxU = sidxU;
+    a.saved_rows = saved_rows;
     a.epoch = epoch;
     a.ncommit = d_ncommit;
     a.wave_bytes = (3 * 128 * sizeof(int) + (size_t)ix.ld * sizeof(float) + 15) & ~(size_t)15;
-    const size_t shared = (16 + 64 + 64 + 64 * 64) * sizeof(int);
+    const size_t shared = (16 + 64 + 64 + 64 + 64 * 64) * sizeof(int);
     int nw = (int)((60 * 1024 - shared) / a.wave_bytes);
     nw = nw < 1 ? 1 : (nw > MN_SPEC_MAX_WAVES ? MN_SPEC_MAX_WAVES : nw);
     const size_t lds = shared + (size_t)nw * a.wave_bytes;
@@ -257,4 +365,11 @@ void mn_launch_spec_commit(const MnDevIndex &ix, const int *d_slots, int W, int 
     default: MN_SP(MN_ORDER_WAVE_V, 0); break;
     }
 #undef MN_SP
+}
+
+// HIP loads a translation unit's code object on the first use of one of its kernels (several milliseconds for these units): an
+// index asks for all of them when it is created (mn_index.hip), so that the first query or insert of a process does not pay.
+void mn_module_touch_spec() {
+    hipFuncAttributes fa;
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_spec_commit<MN_ORDER_SSE_V, 0>));
 }

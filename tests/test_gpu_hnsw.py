@@ -729,11 +729,19 @@ def test_lone_search_kernel_equals_the_batch_kernel(gpu, n, dim, metric):
     Q = np.concatenate([rng.standard_normal((150, dim)).astype(np.float32), X[:30], np.zeros((2, dim), np.float32)])
     for ef in (10, 64, 200, 256, 300):
         bi, bd, bc = g.search_batch(Q, 10, ef)  # 182 queries: k_beam
+        bst = g.last_launch()
+        nd = nx = 0
         for qi in range(len(Q)):
             si, sd = g.search(Q[qi], 10, ef)    # one query: k_beam_coop
             assert len(si) == bc[qi], (ef, qi)
             assert np.array_equal(si, bi[qi, :bc[qi]]), (ef, qi)
             assert same_bits(sd, bd[qi, :bc[qi]]), (ef, qi)
+            st = g.last_launch()                # (the lone path's counters come back in its pinned block, per query)
+            assert st["last_n_overflow"] == 0
+            nd += st["last_n_dist"]
+            nx += st["last_n_expanded"]
+        # the same searches: the same number of distances and expansions, whichever kernel and queue ran them
+        assert (nd, nx) == (bst["last_n_dist"], bst["last_n_expanded"]), ef
     g.close()
 
 
