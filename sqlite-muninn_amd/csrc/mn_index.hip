@@ -155,7 +155,7 @@ struct mn_index {
     DevBuf<int> er_slot, er_level, er_nbr;
     DevBuf<float> er_dist;
     // speculative exact build: read logs of a window's searches, per-row rewrite epochs
-    DevBuf<int> ws_readlog, ws_nread, ws_ncommit, d_stamp0, d_stampU, d_sidx0, d_sidxU, d_saved_rows;
+    DevBuf<int> ws_readlog, ws_nread, ws_ncommit, d_stamp0, d_stampU, d_sidx0, d_sidxU, d_saved_rows, d_pre_act, d_pre_cnt, d_pre_row;
     int spec_epoch = 0;
     std::vector<int> staged; // mn_hnsw_batch_stage: slots added but not yet searched / linked
     DevBuf<int> d_staged;
@@ -700,6 +700,7 @@ extern "C" void mn_hnsw_destroy(mn_index *x) {
     x->sh_lids.release(); x->sh_gd.release(); x->sh_ld.release();
     x->ws_readlog.release(); x->ws_nread.release(); x->ws_ncommit.release(); x->d_stamp0.release(); x->d_stampU.release();
     x->d_sidx0.release(); x->d_sidxU.release(); x->d_saved_rows.release();
+    x->d_pre_act.release(); x->d_pre_cnt.release(); x->d_pre_row.release();
     if (x->ev0) (void)hipEventDestroy(x->ev0);
     if (x->ev1) (void)hipEventDestroy(x->ev1);
     if (x->ev2) (void)hipEventDestroy(x->ev2);
@@ -1310,9 +1311,17 @@ static int run_speculative(mn_index *x, const std::vector<int> &slots) {
             x->spec_epoch = 1;
         }
         MnDevIndex v = dev_view(x);
+        // the link decisions of the whole window ahead of its commit (k_spec_prepare; MN_SPEC_AHEAD=0: decided inside the commit)
+        const bool ahead = !(getenv("MN_SPEC_AHEAD") && atoi(getenv("MN_SPEC_AHEAD")) == 0) && v.W0 <= 64;
+        if (ahead) {
+            const size_t cells = (size_t)W * a.nlev * v.W0;
+            if (x->d_pre_act.reserve(cells, false, st) || x->d_pre_cnt.reserve(cells, false, st) ||
+                x->d_pre_row.reserve(cells * 64, false, st))
+                return -1;
+        }
         mn_launch_spec_commit(v, x->ws_qslots.p, W, a.nlev, x->ws_sel.p, x->ws_nsel.p, x->ws_readlog.p, LOG_CAP, x->ws_nread.p,
-                              x->d_stamp0.p, x->d_stampU.p, x->d_sidx0.p, x->d_sidxU.p, x->d_saved_rows.p, x->spec_epoch,
-                              x->ws_ncommit.p, st);
+                              x->d_stamp0.p, x->d_stampU.p, x->d_sidx0.p, x->d_sidxU.p, x->d_saved_rows.p,
+                              ahead ? x->d_pre_act.p : nullptr, x->d_pre_cnt.p, x->d_pre_row.p, x->spec_epoch, x->ws_ncommit.p, st);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(x->ev2, st));
         int done = 0;

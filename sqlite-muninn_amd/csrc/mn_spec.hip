@@ -36,6 +36,11 @@ struct MnSpecArgs {
     int *sidxU;       // [n_pool_rows] (-1: not kept, the save buffer was full)
     int *saved_rows;  // [MN_SPEC_SAVE_CAP][64]
     int epoch;
+    // decisions taken ahead for every (insert, layer, target) by k_spec_prepare against the rows of the window's start — good for
+    // as long as the target's row has not been rewritten in this window; index ((jj * nlev + l) * W0 + i)
+    int *pre_act;     // 0 nothing, 1 append, 2 pruned row, 3 a tie came up
+    int *pre_cnt;     // append position
+    int *pre_row;     // [..][64] the pruned row
     int *ncommit;     // out: inserts committed (>= 1)
     size_t wave_bytes; // LDS per wavefront
 };
@@ -124,6 +129,74 @@ DEVI bool spec_rewrite_is_harmless(const MnDevIndex &ix, const MnSpecArgs &a, co
     return __ballot(lane < na && !(d >= worst)) == 0; // (a NaN distance fails too)
 }
 
+// What adding node s to target t's layer-l list does (src/hnsw_algo.c:590-646), decided by one wavefront from the row as it stands,
+// nothing written: 0 nothing (t has no such layer, or s is in the list), 1 append at *where, 2 the list is full and the MN-RU
+// prune's choice is in out_row[0..W), 3 the prune met a distance tie (it would have to look at other rows: list order decides).
+template <int ORDER, int NCH>
+DEVI int spec_decide(const MnDevIndex &ix, int s, int t, int l, int W, int *list, float *nd, int *mn, float *tv, int lane,
+                     int *where, int *out_row) {
+    if (ix.levels[t] < l) // :590
+        return 0;
+    int *trow = spec_row(ix, t, l);
+    const int v = lane < W ? ld_link<true>(trow + lane) : -1;
+    const int cnt = __popcll(__ballot(v >= 0));
+    if (__ballot(v == s)) // already a neighbour (:147-150)
+        return 0;
+    if (cnt < W) {
+        *where = cnt;
+        return 1;
+    }
+    // over-full: MN-RU prune of t's list (:601-646)
+    __builtin_amdgcn_wave_barrier();
+    if (lane < W)
+        list[lane] = v;
+    if (lane == 0)
+        list[W] = s;
+    const float *tsrc = ix.vectors + (size_t)t * ix.ld;
+    for (int e = lane; e < ix.ld; e += 64)
+        tv[e] = tsrc[e];
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    const float tnorm = ix.metric == 1 ? ix.norms[t] : 0.0f;
+    if (prune_row<ORDER, NCH, true, false>(ix, tv, tnorm, list, nd, mn, W + 1, W, l, lane))
+        return 3;
+    if (lane < W)
+        out_row[lane] = list[lane];
+    return 2;
+}
+
+// Round 4: the decisions of a whole window at once, one workgroup per insert — the prunes are most of a commit's time, the
+// inserts of a window mostly touch different rows, and a decision depends on nothing but the target's row and the vectors.  The
+// commit kernel takes a decision from here when the target's row still is what it was, and decides itself when it is not.
+template <int ORDER, int NCH>
+__global__ void __launch_bounds__(MN_SPEC_MAX_WAVES * 64) k_spec_prepare(MnDevIndex ix, MnSpecArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, NW = blockDim.x >> 6;
+    unsigned char *pw = smem + (size_t)wv * a.wave_bytes;
+    int *list = reinterpret_cast<int *>(pw);
+    float *nd = reinterpret_cast<float *>(list + 128);
+    int *mn = reinterpret_cast<int *>(nd + 128);
+    float *tv = reinterpret_cast<float *>(mn + 128);
+    const int jj = blockIdx.x;
+    const int s = a.slots[jj];
+    const int level = ix.levels[s];
+    const int start = level < a.nlev - 1 ? level : a.nlev - 1;
+    for (int l = start; l >= 0; l--) {
+        const int W = l == 0 ? ix.W0 : ix.WU;
+        const int ns = a.nsel[jj * a.nlev + l];
+        const size_t base = ((size_t)jj * a.nlev + l) * ix.W0;
+        const int *sel = a.sel + base;
+        for (int i = wv; i < ns; i += NW) {
+            int where = 0;
+            const int what = spec_decide<ORDER, NCH>(ix, s, sel[i], l, W, list, nd, mn, tv, lane, &where, a.pre_row + (base + i) * 64);
+            if (lane == 0) {
+                a.pre_act[base + i] = what;
+                a.pre_cnt[base + i] = where;
+            }
+        }
+    }
+}
+
 template <int ORDER, int NCH>
 __global__ void __launch_bounds__(MN_SPEC_MAX_WAVES * 64) k_spec_commit(MnDevIndex ix, MnSpecArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -206,40 +279,29 @@ __global__ void __launch_bounds__(MN_SPEC_MAX_WAVES * 64) k_spec_commit(MnDevInd
             if (tid == 0)
                 flag[1] = 0;
             __syncthreads();
-            // pass 1: decide every target's new row, write nothing
+            // pass 1: every target's new row — taken from k_spec_prepare while the target's row is the one it saw, decided here
+            // otherwise; nothing is written yet
             for (int i = wv; i < ns; i += NW) {
                 const int t = sel[i];
                 int what = 0, where = 0;
-                if (ix.levels[t] >= l) { // :590
-                    int *trow = spec_row(ix, t, l);
-                    const int v = lane < W ? ld_link<true>(trow + lane) : -1;
-                    const int cnt = __popcll(__ballot(v >= 0));
-                    if (__ballot(v == s)) { // already a neighbour (:147-150)
-                        what = 0;
-                    } else if (cnt < W) {
-                        what = 1;
-                        where = cnt;
-                    } else { // over-full: MN-RU prune of t's list (:601-646)
-                        __builtin_amdgcn_wave_barrier();
-                        if (lane < W)
-                            list[lane] = v;
-                        if (lane == 0)
-                            list[W] = s;
-                        const float *tsrc = ix.vectors + (size_t)t * ix.ld;
-                        for (int e = lane; e < ix.ld; e += 64)
-                            tv[e] = tsrc[e];
-                        __builtin_amdgcn_s_waitcnt(0);
-                        __builtin_amdgcn_wave_barrier();
-                        const float tnorm = ix.metric == 1 ? ix.norms[t] : 0.0f;
-                        if (prune_row<ORDER, NCH, true, false>(ix, tv, tnorm, list, nd, mn, W + 1, W, l, lane)) {
-                            if (lane == 0)
-                                flag[1] = 1; // a tie: this layer is redone in list order below
-                        } else {
-                            what = 2;
-                            if (lane < W)
-                                newrow[i * 64 + lane] = list[lane];
-                        }
+                bool taken = false;
+                if (a.pre_act && ix.levels[t] >= l) {
+                    const size_t r = l == 0 ? (size_t)t : (size_t)(ix.up_off[t] + l - 1);
+                    if (__hip_atomic_load((l == 0 ? a.stamp0 : a.stampU) + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
+                        const size_t idx = ((size_t)jj * a.nlev + l) * ix.W0 + i;
+                        what = a.pre_act[idx];
+                        where = a.pre_cnt[idx];
+                        if (what == 2 && lane < W)
+                            newrow[i * 64 + lane] = a.pre_row[idx * 64 + lane];
+                        taken = true;
                     }
+                }
+                if (!taken)
+                    what = spec_decide<ORDER, NCH>(ix, s, t, l, W, list, nd, mn, tv, lane, &where, newrow + i * 64);
+                if (what == 3) {
+                    what = 0;
+                    if (lane == 0)
+                        flag[1] = 1; // a tie: this layer is redone in list order below
                 }
                 if (lane == 0) {
                     act[i] = what;
@@ -328,7 +390,7 @@ static int pick_nch_p(int ld) {
 // one workgroup; as many wavefronts as 60 KB of LDS allow (≤ 8)
 void mn_launch_spec_commit(const MnDevIndex &ix, const int *d_slots, int W, int nlev, const int *sel, const int *nsel,
                            const int *readlog, int readcap, const int *nread, int *stamp0, int *stampU, int *sidx0, int *sidxU,
-                           int *saved_rows, int epoch, int *d_ncommit, hipStream_t st) {
+                           int *saved_rows, int *pre_act, int *pre_cnt, int *pre_row, int epoch, int *d_ncommit, hipStream_t st) {
     MnSpecArgs a;
     a.slots = d_slots;
     a.W = W;
@@ -343,6 +405,9 @@ void mn_launch_spec_commit(const MnDevIndex &ix, const int *d_slots, int W, int 
     a.sidx0 = sidx0;
     a.sidxU = sidxU;
     a.saved_rows = saved_rows;
+    a.pre_act = pre_act;
+    a.pre_cnt = pre_cnt;
+    a.pre_row = pre_row;
     a.epoch = epoch;
     a.ncommit = d_ncommit;
     a.wave_bytes = (3 * 128 * sizeof(int) + (size_t)ix.ld * sizeof(float) + 15) & ~(size_t)15;
@@ -350,7 +415,13 @@ void mn_launch_spec_commit(const MnDevIndex &ix, const int *d_slots, int W, int 
     int nw = (int)((60 * 1024 - shared) / a.wave_bytes);
     nw = nw < 1 ? 1 : (nw > MN_SPEC_MAX_WAVES ? MN_SPEC_MAX_WAVES : nw);
     const size_t lds = shared + (size_t)nw * a.wave_bytes;
-#define MN_SP(O, N) hipLaunchKernelGGL((k_spec_commit<O, N>), dim3(1), dim3(nw * 64), lds, st, ix, a)
+    const size_t lds_pre = (size_t)nw * a.wave_bytes;
+#define MN_SP(O, N)                                                                                                              \
+    do {                                                                                                                         \
+        if (a.pre_act)                                                                                                           \
+            hipLaunchKernelGGL((k_spec_prepare<O, N>), dim3(W), dim3(nw * 64), lds_pre, st, ix, a);                              \
+        hipLaunchKernelGGL((k_spec_commit<O, N>), dim3(1), dim3(nw * 64), lds, st, ix, a);                                       \
+    } while (0)
     if (ix.order == MN_ORDER_SSE_V) {
         MN_SP(MN_ORDER_SSE_V, 0);
         return;

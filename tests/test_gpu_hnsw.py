@@ -357,6 +357,40 @@ def test_speculative_exact_inserts_equal_the_single_wavefront_kernel(gpu, monkey
     assert graphs[0][2:] == graphs[1][2:]
 
 
+@pytest.mark.parametrize("metric,dim", [("l2", 24), ("cosine", 40)])
+def test_speculative_windows_with_colliding_inserts_equal_the_single_wavefront_kernel(gpu, monkeypatch, metric, dim):
+    """Round 4: a window's insert stays valid when the rows its search read were rewritten in ways that cannot have changed the
+    search (mn_spec.hip spec_rewrite_is_harmless).  The dangerous cases are rewrites that DO matter: consecutive inserts that
+    are each other's nearest neighbours (the node an earlier insert appended to a row is one the later search would have
+    pushed), runs from one small cluster (pruned rows drop neighbours the later search did push), exact duplicates (ties:
+    the log's defaults), a small index (every window collides) and deleted nodes in the lists.  Same graph as the
+    one-wavefront kernel, links, levels, entry point — with the windows on and off."""
+    rng = np.random.default_rng(171)
+    n0, M, efc = 4000, 8, 80
+    centres = rng.standard_normal((12, dim)).astype(np.float32) * 3
+    base = (centres[rng.integers(0, 12, n0)] + rng.standard_normal((n0, dim)).astype(np.float32) * 0.3).astype(np.float32)
+    chain = np.cumsum(rng.standard_normal((400, dim)).astype(np.float32) * 0.01, axis=0) + centres[3]   # each next to the last
+    burst = (centres[5] + rng.standard_normal((400, dim)).astype(np.float32) * 0.05).astype(np.float32)  # one tight cluster
+    dups = base[rng.integers(0, n0, 200)]                                                                # ties
+    far = rng.standard_normal((400, dim)).astype(np.float32) * 3                                         # harmless collisions
+    new = np.concatenate([chain, far, burst, dups, chain[::-1] + np.float32(0.001), far[:100] * np.float32(1.001)]).astype(np.float32)
+    X = np.concatenate([base, new])
+    ids = np.arange(1, len(X) + 1, dtype=np.int64)
+    graphs = []
+    for spec in ("0", "1"):
+        monkeypatch.setenv("MN_SPECULATE", spec)
+        g = gpu.HnswIndex(dim, metric, M, efc)
+        assert g.build(ids[:n0], X[:n0], 16, 1024) == 0
+        for i in range(100, 160):  # deleted nodes stay in their neighbours' lists
+            assert g.delete(int(ids[i])) == 0
+        assert g.insert_batch(ids[n0:], X[n0:], gpu.BUILD_SEQUENTIAL) == 0
+        graphs.append((g.export_links(0), g.export_links(1), g.export_nodes()[1], g.entry_point, g.max_level))
+        g.close()
+    for a, b in zip(graphs[0][:3], graphs[1][:3]):
+        assert np.array_equal(a, b)
+    assert graphs[0][3:] == graphs[1][3:]
+
+
 def test_two_host_threads_two_indexes(gpu, orc):
     """SURVEY §8b threading contract: one host thread per connection, several connections per process.  Each index has
     its own HIP stream and the device is selected per call; two threads building and searching their own indexes at
