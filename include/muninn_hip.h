@@ -73,7 +73,8 @@ int mn_vec_dist_batch(int metric, int order, const float *query, const float *ro
 /* hnsw_create (src/hnsw_algo.c:181-208).  M_max0 = 2M, rng seed 42.  device = HIP ordinal.
  * 2 <= M <= 512 (the reference has no upper bound; here a list of 2M + 1 entries is pruned inside one workgroup's LDS;
  * rows of more than 64 links are walked 64 at a time); NULL + mn_last_error() otherwise, or when no gfx950 device is
- * available (there is no CPU fallback). */
+ * available (there is no CPU fallback).  The first index a process creates on a device also has HIP load the library's kernels
+ * there (tens of milliseconds, once), so that no later query or insert pays for it. */
 mn_index *mn_hnsw_create(int dim, int metric, int M, int ef_construction);
 mn_index *mn_hnsw_create_on(int dim, int metric, int M, int ef_construction, int device);
 /* hnsw_destroy (:210-220) */
@@ -197,7 +198,8 @@ int64_t mn_hnsw_edges_of(mn_index *idx, const int64_t *ids, int n, int64_t *out_
 
 /* ---- measurement hooks (bench.py) ---- */
 typedef struct {
-    double last_kernel_ms;   /* HIP-event time of the last dominant kernel launch on the index's stream */
+    double last_kernel_ms;   /* HIP-event time of the last dominant kernel launch on the index's stream (0 after a search of a few
+                              * host-resident queries, mn_hnsw_search: that path records no events) */
     int64_t last_n_dist;     /* distance evaluations performed by that launch (device counter) */
     int64_t last_n_expanded; /* neighbour rows read by that launch */
     int64_t last_n_overflow; /* queries whose heaps exceeded workspace (must be 0) */

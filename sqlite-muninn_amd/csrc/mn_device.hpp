@@ -166,7 +166,8 @@ void mn_launch_insert_seq(const MnDevIndex &ix, const int *d_slots, int n, int e
 #define MN_SPEC_SAVE_CAP 4096 // rows a speculative window may rewrite with their old lists kept (more: those rows invalidate as before)
 void mn_launch_spec_commit(const MnDevIndex &ix, const int *d_slots, int W, int nlev, const int *sel, const int *nsel,
                            const int *readlog, int readcap, const int *nread, int *stamp0, int *stampU, int *sidx0, int *sidxU,
-                           int *saved_rows, int *pre_act, int *pre_cnt, int *pre_row, int epoch, int *d_ncommit, hipStream_t st);
+                           int *saved_rows, int *pre_act, int *pre_cnt, int *pre_row, int *why, int epoch, int *d_ncommit,
+                           hipStream_t st);
 
 // rows[r] = (slot, level): writes the row's neighbour slots and dist(slot, neighbour) (mn_kernels.hip)
 void mn_launch_edge_rows(const MnDevIndex &ix, const int *d_row_slot, const int *d_row_level, int n_rows, int *d_out_nbr,

@@ -155,7 +155,7 @@ struct mn_index {
     DevBuf<int> er_slot, er_level, er_nbr;
     DevBuf<float> er_dist;
     // speculative exact build: read logs of a window's searches, per-row rewrite epochs
-    DevBuf<int> ws_readlog, ws_nread, ws_ncommit, d_stamp0, d_stampU, d_sidx0, d_sidxU, d_saved_rows, d_pre_act, d_pre_cnt, d_pre_row;
+    DevBuf<int> ws_readlog, ws_nread, ws_ncommit, d_stamp0, d_stampU, d_sidx0, d_sidxU, d_saved_rows, d_pre_act, d_pre_cnt, d_pre_row, d_spec_why;
     int spec_epoch = 0;
     std::vector<int> staged; // mn_hnsw_batch_stage: slots added but not yet searched / linked
     DevBuf<int> d_staged;
@@ -700,7 +700,7 @@ extern "C" void mn_hnsw_destroy(mn_index *x) {
     x->sh_lids.release(); x->sh_gd.release(); x->sh_ld.release();
     x->ws_readlog.release(); x->ws_nread.release(); x->ws_ncommit.release(); x->d_stamp0.release(); x->d_stampU.release();
     x->d_sidx0.release(); x->d_sidxU.release(); x->d_saved_rows.release();
-    x->d_pre_act.release(); x->d_pre_cnt.release(); x->d_pre_row.release();
+    x->d_pre_act.release(); x->d_pre_cnt.release(); x->d_pre_row.release(); x->d_spec_why.release();
     if (x->ev0) (void)hipEventDestroy(x->ev0);
     if (x->ev1) (void)hipEventDestroy(x->ev1);
     if (x->ev2) (void)hipEventDestroy(x->ev2);
@@ -1280,6 +1280,11 @@ static int run_speculative(mn_index *x, const std::vector<int> &slots) {
     if (x->d_sidxU.reserve((size_t)std::max(1, x->n_pool_rows) + 1, false, st)) return -1;
     if (x->d_saved_rows.reserve((size_t)MN_SPEC_SAVE_CAP * 64, false, st)) return -1;
     if (x->ws_ncommit.reserve(1, false, st)) return -1;
+    const bool trace = getenv("MN_SPEC_TRACE") != nullptr;
+    if (trace) {
+        if (x->d_spec_why.reserve(8, false, st)) return -1;
+        HIPCHK(hipMemsetAsync(x->d_spec_why.p, 0, 8 * sizeof(int), st));
+    }
     int window = 16, poor = 0;
     long long searched = 0, rounds = 0, plain = 0;
     double t_search = 0, t_commit = 0; // device ms (HIP events), reported under MN_SPEC_TRACE
@@ -1321,7 +1326,8 @@ static int run_speculative(mn_index *x, const std::vector<int> &slots) {
         }
         mn_launch_spec_commit(v, x->ws_qslots.p, W, a.nlev, x->ws_sel.p, x->ws_nsel.p, x->ws_readlog.p, LOG_CAP, x->ws_nread.p,
                               x->d_stamp0.p, x->d_stampU.p, x->d_sidx0.p, x->d_sidxU.p, x->d_saved_rows.p,
-                              ahead ? x->d_pre_act.p : nullptr, x->d_pre_cnt.p, x->d_pre_row.p, x->spec_epoch, x->ws_ncommit.p, st);
+                              ahead ? x->d_pre_act.p : nullptr, x->d_pre_cnt.p, x->d_pre_row.p, trace ? x->d_spec_why.p : nullptr,
+                              x->spec_epoch, x->ws_ncommit.p, st);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(x->ev2, st));
         int done = 0;
@@ -1359,7 +1365,14 @@ static int run_speculative(mn_index *x, const std::vector<int> &slots) {
     }
     x->host_links_valid = false;
     x->last_spec_searched = searched;
-    if (getenv("MN_SPEC_TRACE"))
+    if (trace) {
+        int why[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        HIPCHK(hipMemcpy(why, x->d_spec_why.p, sizeof(why), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[mn_spec] windows ended by: log overflow %d, > 64 rewritten rows %d, a row with the log's defaults %d, an old list "
+                        "not kept %d, a removed neighbour the search could have pushed %d, an added node it would have pushed %d; "
+                        "committed whole %d\n", why[1], why[2], why[3], why[4], why[5], why[6], why[7]);
+    }
+    if (trace)
         fprintf(stderr, "[mn_spec] %d inserts: %lld rounds (%.1f committed per round), %lld searches, %lld by k_insert_seq; device ms "
                         "per round: search %.2f commit %.2f\n", n, rounds, rounds ? (double)(n - plain) / rounds : 0.0, searched, plain,
                 rounds ? t_search / rounds : 0.0, rounds ? t_commit / rounds : 0.0);

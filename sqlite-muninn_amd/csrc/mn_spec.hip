@@ -41,6 +41,8 @@ struct MnSpecArgs {
     int *pre_act;     // 0 nothing, 1 append, 2 pruned row, 3 a tie came up
     int *pre_cnt;     // append position
     int *pre_row;     // [..][64] the pruned row
+    int *why;         // [8] or null (MN_SPEC_TRACE): why inserts were judged stale — [1] log overflow, [2] more than 64 rewritten rows
+                      // read, [3..6] see spec_rewrite_is_harmless; [7] windows that committed whole
     int *ncommit;     // out: inserts committed (>= 1)
     size_t wave_bytes; // LDS per wavefront
 };
@@ -87,20 +89,22 @@ DEVI void spec_stamp(const MnDevIndex &ix, const MnSpecArgs &a, int node, int le
 // Anything else — a greedy descent's row, a search that met equal keys and went back to the heaps, a row of more than 64 links,
 // a list that was not kept — carries the log's defaults (-inf / all positions) and invalidates the insert as before.
 // One wavefront; qv = the insert's vector (LDS), qnorm as its search had it.  tmp: LDS, 64 ints.
+// Returns 0 = harmless, else why not (MN_SPEC_TRACE counts them): 3 the log's defaults, 4 the old list was not kept or the row is
+// wider than 64, 5 a removed neighbour could have been pushed, 6 an added node would have been pushed.
 template <int ORDER, int NCH>
-DEVI bool spec_rewrite_is_harmless(const MnDevIndex &ix, const MnSpecArgs &a, const int *e, const float *qv, float qnorm, int *tmp,
-                                   int lane) {
+DEVI int spec_rewrite_is_harmless(const MnDevIndex &ix, const MnSpecArgs &a, const int *e, const float *qv, float qnorm, int *tmp,
+                                  int lane) {
     const int r = e[0];
     const float worst = __int_as_float(e[1]);
     const unsigned long long could = (unsigned long long)(unsigned)e[2] | ((unsigned long long)(unsigned)e[3] << 32);
     if (!(worst > -__builtin_inff())) // the defaults (or a NaN)
-        return false;
+        return 3;
     const int k = __hip_atomic_load((r >= 0 ? a.sidx0 + r : a.sidxU + (-r - 2)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (k < 0)
-        return false;
+        return 4;
     const int W = r >= 0 ? ix.W0 : ix.WU;
     if (W > 64)
-        return false;
+        return 4;
     const int *cur_row = r >= 0 ? ix.links0 + (size_t)r * ix.W0 : ix.links_up + (size_t)(-r - 2) * ix.WU;
     const int o = lane < W ? a.saved_rows[(size_t)k * 64 + lane] : -1;
     const int c = lane < W ? ld_link<true>(cur_row + lane) : -1;
@@ -112,12 +116,12 @@ DEVI bool spec_rewrite_is_harmless(const MnDevIndex &ix, const MnSpecArgs &a, co
     }
     const unsigned long long removed = __ballot(o >= 0 && !o_stays);
     if (removed & could)
-        return false;
+        return 5;
     const bool added = c >= 0 && !c_was;
     const unsigned long long am = __ballot(added);
     const int na = __popcll(am);
     if (na == 0)
-        return true;
+        return 0;
     const int rank = __popcll(am & ((1ull << lane) - 1ull));
     __builtin_amdgcn_wave_barrier();
     if (added)
@@ -126,7 +130,7 @@ DEVI bool spec_rewrite_is_harmless(const MnDevIndex &ix, const MnSpecArgs &a, co
     const int myslot = lane < na ? tmp[lane] : 0;
     __builtin_amdgcn_wave_barrier();
     const float d = rows_distance<ORDER, NCH>(ix, qv, qnorm, myslot, na, lane);
-    return __ballot(lane < na && !(d >= worst)) == 0; // (a NaN distance fails too)
+    return __ballot(lane < na && !(d >= worst)) == 0 ? 0 : 6; // (a NaN distance fails too)
 }
 
 // What adding node s to target t's layer-l list does (src/hnsw_algo.c:590-646), decided by one wavefront from the row as it stands,
@@ -228,8 +232,11 @@ __global__ void __launch_bounds__(MN_SPEC_MAX_WAVES * 64) k_spec_commit(MnDevInd
         if (jj > 0) {
             const int nr = a.nread[jj];
             if (nr > a.readcap) {
-                if (tid == 0)
+                if (tid == 0) {
                     flag[0] = 1; // incomplete log: cannot be trusted
+                    if (a.why)
+                        atomicAdd(&a.why[1], 1);
+                }
             } else {
                 const int *log = a.readlog + (size_t)jj * a.readcap * MN_RLOG_INTS;
                 for (int i = tid; i < nr; i += blockDim.x) {
@@ -239,8 +246,11 @@ __global__ void __launch_bounds__(MN_SPEC_MAX_WAVES * 64) k_spec_commit(MnDevInd
                         const int h = atomicAdd(&flag[2], 1);
                         if (h < 64)
                             hot[h] = i;
-                        else
+                        else {
                             flag[0] = 1; // (more than the check looks at)
+                            if (a.why && h == 64)
+                                atomicAdd(&a.why[2], 1);
+                        }
                     }
                 }
             }
@@ -256,12 +266,17 @@ __global__ void __launch_bounds__(MN_SPEC_MAX_WAVES * 64) k_spec_commit(MnDevInd
                 __builtin_amdgcn_s_waitcnt(0);
                 __builtin_amdgcn_wave_barrier();
                 const float qnorm = ix.metric == 1 ? ix.norms[s] : 0.0f;
-                for (int h = wv; h < nh; h += NW)
-                    if (!spec_rewrite_is_harmless<ORDER, NCH>(ix, a, log + (size_t)hot[h] * MN_RLOG_INTS, tv, qnorm, list, lane)) {
-                        if (lane == 0)
+                for (int h = wv; h < nh; h += NW) {
+                    const int why = spec_rewrite_is_harmless<ORDER, NCH>(ix, a, log + (size_t)hot[h] * MN_RLOG_INTS, tv, qnorm, list, lane);
+                    if (why) {
+                        if (lane == 0) {
                             flag[0] = 1;
+                            if (a.why)
+                                atomicAdd(&a.why[why], 1);
+                        }
                         break;
                     }
+                }
             }
             __syncthreads();
         }
@@ -372,8 +387,11 @@ __global__ void __launch_bounds__(MN_SPEC_MAX_WAVES * 64) k_spec_commit(MnDevInd
             __syncthreads();
         }
     }
-    if (tid == 0)
+    if (tid == 0) {
         *a.ncommit = done;
+        if (a.why && done == a.W)
+            atomicAdd(&a.why[7], 1);
+    }
 }
 
 static int pick_nch_p(int ld) {
@@ -390,7 +408,8 @@ static int pick_nch_p(int ld) {
 // one workgroup; as many wavefronts as 60 KB of LDS allow (≤ 8)
 void mn_launch_spec_commit(const MnDevIndex &ix, const int *d_slots, int W, int nlev, const int *sel, const int *nsel,
                            const int *readlog, int readcap, const int *nread, int *stamp0, int *stampU, int *sidx0, int *sidxU,
-                           int *saved_rows, int *pre_act, int *pre_cnt, int *pre_row, int epoch, int *d_ncommit, hipStream_t st) {
+                           int *saved_rows, int *pre_act, int *pre_cnt, int *pre_row, int *why, int epoch, int *d_ncommit,
+                           hipStream_t st) {
     MnSpecArgs a;
     a.slots = d_slots;
     a.W = W;
@@ -408,6 +427,7 @@ void mn_launch_spec_commit(const MnDevIndex &ix, const int *d_slots, int W, int 
     a.pre_act = pre_act;
     a.pre_cnt = pre_cnt;
     a.pre_row = pre_row;
+    a.why = why;
     a.epoch = epoch;
     a.ncommit = d_ncommit;
     a.wave_bytes = (3 * 128 * sizeof(int) + (size_t)ix.ld * sizeof(float) + 15) & ~(size_t)15;
