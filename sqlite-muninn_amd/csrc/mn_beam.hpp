@@ -173,12 +173,15 @@ struct WaveCtx {
 };
 DEVI bool getenv_spec_off(const WaveCtx &w) { return (w.no_spec_rows & 1) != 0; }
 
-// A log entry is MN_RLOG_INTS ints: [0] the row (level 0: the node's slot, upper: -(pool row) - 2); [1] the worst result's
-// distance when the row was opened (float bits: what a neighbour had to beat to be pushed; +inf while the results had room);
-// [2..3] the positions of the row whose neighbour was new AND nearer than that — everything that could have been pushed.
-// The commit step of a speculative window (mn_spec.hip) uses [1..3] to decide whether a rewrite of the row by an earlier insert
-// of the window would have changed this search at all.  The defaults written here say "anything would have" (-inf, all
-// positions): greedy descents, rows of more than 64 links and searches that fell back to the heaps keep them.
+// A log entry is MN_RLOG_INTS ints: [0] the row (level 0: the node's slot, upper: -(pool row) - 2); [4] what read it.
+// [4] = 0, a beam search: [1] the worst result's distance when the row was opened (float bits: what a neighbour had to beat to be
+// pushed; +inf while the results had room); [2..3] the positions of the row whose neighbour was new AND nearer than that —
+// everything that could have been pushed.  [4] = 2: the same from the search with the reference's heaps (beam_layer: equal keys
+// are about — the ORDER of the pushes counts as well).  [4] = 1, a greedy descent (greedy_layer): [1] the distance to beat, [2] the position
+// the scan started from, [3] the position of the neighbour it moved to, -1 if none improved.
+// The commit step of a speculative window (mn_spec.hip) uses them to decide whether a rewrite of the row by an earlier insert of
+// the window would have changed this search at all.  The defaults written here say "anything would have" (-inf, all positions):
+// rows of more than 64 links keep them.
 DEVI void log_row_read(const MnDevIndex &ix, WaveCtx &w, int node, int level, int lane) {
     if (!w.rlog)
         return;
@@ -187,11 +190,24 @@ DEVI void log_row_read(const MnDevIndex &ix, WaveCtx &w, int node, int level, in
         e[0] = level == 0 ? node : -(ix.up_off[node] + level - 1) - 2;
         e[1] = (int)0xff800000u; // -inf
         e[2] = e[3] = -1;
+        e[4] = 0;
     }
     w.nr++;
 }
+// ... and of a greedy step
+DEVI void log_greedy_detail(WaveCtx &w, float to_beat, int from, int moved_to, int lane) {
+    if (!w.rlog)
+        return;
+    if (lane == 0 && w.nr >= 1 && w.nr <= w.rcap) {
+        int *e = w.rlog + (size_t)(w.nr - 1) * MN_RLOG_INTS;
+        e[1] = __float_as_int(to_beat);
+        e[2] = from;
+        e[3] = moved_to;
+        e[4] = 1;
+    }
+}
 // the detail of the entry log_row_read has just written (beam_layer_regs, a row of one chunk)
-DEVI void log_row_detail(WaveCtx &w, float worst, unsigned long long could_push, int lane) {
+DEVI void log_row_detail(WaveCtx &w, float worst, unsigned long long could_push, int lane, int kind = 0) {
     if (!w.rlog)
         return;
     if (lane == 0 && w.nr >= 1 && w.nr <= w.rcap) {
@@ -199,6 +215,7 @@ DEVI void log_row_detail(WaveCtx &w, float worst, unsigned long long could_push,
         e[1] = __float_as_int(worst);
         e[2] = (int)(unsigned)(could_push & 0xffffffffull);
         e[3] = (int)(unsigned)(could_push >> 32);
+        e[4] = kind;
     }
 }
 
@@ -259,7 +276,8 @@ DEVI const int *link_row(const MnDevIndex &ix, int node, int level, int &W) {
 // index i+1 of the NEW node's list.
 // WIDE: rows may hold more than 64 links (M > 32) and are walked in 64-link chunks; with WIDE = false the chunk
 // logic folds away at compile time and the code is the single-pass one the throughput kernels were tuned with.
-template <int ORDER, int NCH, bool COH = false, bool WIDE = false>
+// LOG: the search feeds the read log of a speculative window (only k_beam_coop<BUILD>: every other kernel compiles the log away)
+template <int ORDER, int NCH, bool COH = false, bool WIDE = false, bool LOG = false>
 DEVI int greedy_layer(const MnDevIndex &ix, WaveCtx &w, int entry, int level, int lane) {
     int cur = entry;
     float cur_d = ctx_distance<ORDER, NCH>(ix, w, cur, 1, lane);
@@ -278,7 +296,8 @@ DEVI int greedy_layer(const MnDevIndex &ix, WaveCtx &w, int entry, int level, in
             const int c0 = WIDE ? (i0 & ~63) : 0;
             if (fresh) {
                 w.n_exp++;
-                log_row_read(ix, w, cur, level, lane);
+                if (LOG)
+                    log_row_read(ix, w, cur, level, lane);
             }
             const int pos = c0 + lane;
             int nb = (pos < W) ? ld_link<COH>(row + pos) : -1;
@@ -291,6 +310,8 @@ DEVI int greedy_layer(const MnDevIndex &ix, WaveCtx &w, int entry, int level, in
                     fresh = false;
                     continue;
                 }
+                if (LOG && !WIDE)
+                    log_greedy_detail(w, cur_d, i0, -1, lane);
                 break;
             }
             int rank = __popcll(m & ((1ull << lane) - 1ull));
@@ -308,9 +329,13 @@ DEVI int greedy_layer(const MnDevIndex &ix, WaveCtx &w, int entry, int level, in
                     fresh = false;
                     continue;
                 }
+                if (LOG && !WIDE)
+                    log_greedy_detail(w, cur_d, i0, -1, lane);
                 break;
             }
             int c = __ffsll((long long)better) - 1; // first compact index that improves
+            const float beaten = cur_d;
+            const int from = i0;
             cur_d = __shfl(d, c);
             cur = __shfl(myslot, c);
             // list position of compact index c = position of the (c+1)-th set bit of m
@@ -322,6 +347,8 @@ DEVI int greedy_layer(const MnDevIndex &ix, WaveCtx &w, int entry, int level, in
             i0 = w.scratch[c] + 1;
             i0 = rfl(i0);
             cur = rfl(cur);
+            if (LOG && !WIDE)
+                log_greedy_detail(w, beaten, from, i0 - 1, lane);
             changed = 1;
             fresh = true;
         }
@@ -330,7 +357,7 @@ DEVI int greedy_layer(const MnDevIndex &ix, WaveCtx &w, int entry, int level, in
 }
 
 // src/hnsw_algo.c:347-448.  Results are left in the result heap; the caller drains it.
-template <int ORDER, int NCH, bool COH = false, bool WIDE = false>
+template <int ORDER, int NCH, bool COH = false, bool WIDE = false, bool LOG = false>
 DEVI void beam_layer(const MnDevIndex &ix, WaveCtx &w, WHeap &cand, WHeap &res, unsigned *bitmap, int entry, int level,
                      int ef, int lane) {
     cand.size = 0;
@@ -367,7 +394,8 @@ DEVI void beam_layer(const MnDevIndex &ix, WaveCtx &w, WHeap &cand, WHeap &res, 
         int W;
         const int *row = link_row(ix, node, level, W);
         w.n_exp++;
-        log_row_read(ix, w, node, level, lane);
+        if (LOG)
+            log_row_read(ix, w, node, level, lane);
         PH_ADD(w, 0);
         PH_CNT(w, 5, 1);
         int improved = 0;
@@ -398,12 +426,16 @@ DEVI void beam_layer(const MnDevIndex &ix, WaveCtx &w, WHeap &cand, WHeap &res, 
             // :413-425, in list order.  Once the result set is full an element can only be accepted
             // if it beats the worst AT THAT MOMENT, which never exceeds the worst now: pre-filter.
             unsigned long long am;
+            float worst_log = __builtin_inff();
             if (res.size >= ef) {
                 float worst0 = -u2f(rflu(hget(res, 1).x));
                 am = __ballot(lane < n && d < worst0);
+                worst_log = worst0;
             } else {
                 am = __ballot(lane < n);
             }
+            if (LOG && !WIDE && w.rlog) // (speculative windows: what this row's expansion depended on, by list position)
+                log_row_detail(w, worst_log, __ballot(todo && ((am >> rank) & 1ull)), lane, 2);
             PH_CNT(w, 4, __popcll(am));
             while (am) {
                 int i = __ffsll((long long)am) - 1;
@@ -427,6 +459,8 @@ DEVI void beam_layer(const MnDevIndex &ix, WaveCtx &w, WHeap &cand, WHeap &res, 
                 }
             }
             PH_ADD(w, 3);
+        } else if (LOG && !WIDE && w.rlog) {
+            log_row_detail(w, res.size >= ef ? -u2f(rflu(hget(res, 1).x)) : __builtin_inff(), 0ull, lane, 2);
         }
         } // chunks of the row
         stale = improved ? 0 : stale + 1; // :428-432
@@ -603,7 +637,7 @@ template <bool COH> DEVI bool probe_new(const MnDevIndex &ix, unsigned *bitmap, 
 // res.sorted = 1: position i is the (size - i)-th nearest).  false: a tie (or something else the array cannot decide) came
 // up; nothing but the bitmap, the read log and the counters has been touched, and the caller redoes the layer with
 // beam_layer.  `perm`: LDS, MN_SA_CAP items (the unused candidate heap).
-template <int ORDER, int NCH, bool COH, bool WIDE>
+template <int ORDER, int NCH, bool COH, bool WIDE, bool LOG = false>
 DEVI bool beam_layer_regs(const MnDevIndex &ix, WaveCtx &w, WHeap &res, uint2 *perm, unsigned *bitmap, int entry, int level,
                           int ef, int lane) {
     SQueue s;
@@ -647,7 +681,8 @@ DEVI bool beam_layer_regs(const MnDevIndex &ix, WaveCtx &w, WHeap &res, uint2 *p
         if (stale >= patience_max && s.rn >= ef) // :391
             break;
         w.n_exp++;
-        log_row_read(ix, w, node, level, lane);
+        if (LOG)
+            log_row_read(ix, w, node, level, lane);
         int improved = 0;
         int W;
         const int *row = link_row(ix, node, level, W);
@@ -722,13 +757,13 @@ DEVI bool beam_layer_regs(const MnDevIndex &ix, WaveCtx &w, WHeap &res, uint2 *p
                 const float worst0 = s.rn >= ef ? s.wk : __builtin_inff();
                 unsigned long long entering;
                 ok = sq_merge(s, perm, d, myslot, todo, ef, lane, improved, entering);
-                if (!WIDE && w.rlog) { // (speculative windows) what this row's expansion depended on
+                if (LOG && !WIDE && w.rlog) { // (speculative windows) what this row's expansion depended on
                     // lanes → positions of the row: the compacted path numbered the new neighbours in list order
                     const bool e_here = compacted ? (nb_todo && ((entering >> nb_rank) & 1ull)) : ((entering >> lane) & 1ull) != 0;
                     log_row_detail(w, worst0, __ballot(e_here), lane);
                 }
                 PH_ADD(w, 3);
-            } else if (!WIDE && w.rlog) {
+            } else if (LOG && !WIDE && w.rlog) {
                 log_row_detail(w, s.rn >= ef ? s.wk : __builtin_inff(), 0ull, lane); // nothing new in the row: nothing could be pushed
             }
         }
@@ -759,13 +794,13 @@ DEVI bool beam_layer_regs(const MnDevIndex &ix, WaveCtx &w, WHeap &res, uint2 *p
 }
 
 // the layer search of the latency-bound paths: registers first, the reference's heaps when a tie has to be decided
-template <int ORDER, int NCH, bool COH, bool WIDE>
+template <int ORDER, int NCH, bool COH, bool WIDE, bool LOG = false>
 DEVI void beam_layer_auto(const MnDevIndex &ix, WaveCtx &w, WHeap &cand, WHeap &res, unsigned *bitmap, long long bm_words,
                           int entry, int level, int ef, int lane) {
     if (ef <= MN_SA_CAP && ef >= 1 && ef + 1 < res.lcap + res.gcap && cand.lcap >= MN_SA_CAP) {
         const unsigned long long nd0 = w.n_dist, ne0 = w.n_exp;
         const int nr0 = w.nr;
-        if (beam_layer_regs<ORDER, NCH, COH, WIDE>(ix, w, res, cand.l, bitmap, entry, level, ef, lane))
+        if (beam_layer_regs<ORDER, NCH, COH, WIDE, LOG>(ix, w, res, cand.l, bitmap, entry, level, ef, lane))
             return;
         w.n_dist = nd0;
         w.n_exp = ne0;
@@ -777,7 +812,7 @@ DEVI void beam_layer_auto(const MnDevIndex &ix, WaveCtx &w, WHeap &cand, WHeap &
         __builtin_amdgcn_wave_barrier();
     }
     res.sorted = 0;
-    beam_layer<ORDER, NCH, COH, WIDE>(ix, w, cand, res, bitmap, entry, level, ef, lane);
+    beam_layer<ORDER, NCH, COH, WIDE, LOG>(ix, w, cand, res, bitmap, entry, level, ef, lane);
 }
 
 // the callers' drain (:436-441): entry i of the results in ascending distance, i counted down from size - 1 to 0 — a pop of

@@ -162,8 +162,8 @@ void mn_launch_insert_seq(const MnDevIndex &ix, const int *d_slots, int n, int e
 #define MN_CHLOG_INTS 5
 
 // speculative exact inserts (mn_spec.hip): commit a window of searched inserts in order, stop at the first stale one
-#define MN_RLOG_INTS 4      // ints per entry of a search's read log (mn_beam.hpp log_row_read)
-#define MN_SPEC_SAVE_CAP 4096 // rows a speculative window may rewrite with their old lists kept (more: those rows invalidate as before)
+#define MN_RLOG_INTS 5      // ints per entry of a search's read log (mn_beam.hpp log_row_read)
+#define MN_SPEC_SAVE_CAP 8192 // rows a speculative window may rewrite with their old lists kept (more: those rows invalidate as before)
 void mn_launch_spec_commit(const MnDevIndex &ix, const int *d_slots, int W, int nlev, const int *sel, const int *nsel,
                            const int *readlog, int readcap, const int *nread, int *stamp0, int *stampU, int *sidx0, int *sidxU,
                            int *saved_rows, int *pre_act, int *pre_cnt, int *pre_row, int *why, int epoch, int *d_ncommit,

@@ -1361,7 +1361,7 @@ static int run_speculative(mn_index *x, const std::vector<int> &slots) {
         poor = done <= 1 && W > 1 ? poor + 1 : 0;
         // A window's searches run side by side and a search is one latency-bound wavefront, so a wider window costs
         // bandwidth, not time; searches beyond the committed prefix are simply repeated.  Keep it a few times the prefix.
-        window = done == W ? std::min(64, window * 2) : std::max(16, std::min(64, 3 * done));
+        window = done == W ? std::min(128, window * 2) : std::max(16, std::min(128, 3 * done)); // (≤ 128: one workgroup each, k_beam_coop)
     }
     x->host_links_valid = false;
     x->last_spec_searched = searched;
@@ -1369,8 +1369,9 @@ static int run_speculative(mn_index *x, const std::vector<int> &slots) {
         int why[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         HIPCHK(hipMemcpy(why, x->d_spec_why.p, sizeof(why), hipMemcpyDeviceToHost));
         fprintf(stderr, "[mn_spec] windows ended by: log overflow %d, > 64 rewritten rows %d, a row with the log's defaults %d, an old list "
-                        "not kept %d, a removed neighbour the search could have pushed %d, an added node it would have pushed %d; "
-                        "committed whole %d\n", why[1], why[2], why[3], why[4], why[5], why[6], why[7]);
+                        "not kept %d, a removed neighbour the search could have pushed %d, an added node it would have pushed %d, a "
+                        "greedy step that would have gone elsewhere %d; committed whole %d\n", why[1], why[2], why[3], why[4], why[5],
+                why[6], why[0], why[7]);
     }
     if (trace)
         fprintf(stderr, "[mn_spec] %d inserts: %lld rounds (%.1f committed per round), %lld searches, %lld by k_insert_seq; device ms "

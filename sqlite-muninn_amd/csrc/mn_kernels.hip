@@ -236,14 +236,14 @@ DEVI void beam_query(const MnDevIndex &ix, const MnSearchArgs &a, const long lon
         // search half of hnsw_insert, src/hnsw_algo.c:550-579,:650-652, against the frozen graph
         const int level = ix.levels[qslot];
         for (int l = a.max_level; l > level; l--)
-            cur = greedy_layer<ORDER, NCH, false, WIDE>(ix, w, cur, l, lane);
+            cur = greedy_layer<ORDER, NCH, false, WIDE, LAT>(ix, w, cur, l, lane); // (LAT && BUILD: a window's search, logged)
         int start = level < a.max_level ? level : a.max_level;
         for (int l = start; l >= 0; l--) {
             unsigned *bm = bm0;
             if (l > 0)
                 bm = a.bitmap_up + ((size_t)a.up_bm_index[qi] * a.max_level + (l - 1)) * a.bmu_words;
             if (LAT)
-                beam_layer_auto<ORDER, NCH, false, WIDE>(ix, w, cand, res, bm, l > 0 ? a.bmu_words : a.bm0_words, cur, l, a.ef, lane);
+                beam_layer_auto<ORDER, NCH, false, WIDE, true>(ix, w, cand, res, bm, l > 0 ? a.bmu_words : a.bm0_words, cur, l, a.ef, lane);
             else
                 beam_layer<ORDER, NCH, false, WIDE>(ix, w, cand, res, bm, cur, l, a.ef, lane);
             const int M_max = (l == 0) ? ix.M0 : ix.MU;
@@ -266,7 +266,8 @@ DEVI void beam_query(const MnDevIndex &ix, const MnSearchArgs &a, const long lon
     }
     if (lane == 0) {
         if (BUILD && a.readlog)
-            a.nread[qi] = w.nr; // > readcap: the log is incomplete and the commit step must not trust it
+            a.nread[qi] = LAT ? w.nr : a.readcap + 1; // > readcap: the log is incomplete and the commit step must not trust it
+                                                      // (only the latency kernel's searches keep a log)
         if (a.q_counters) {
             a.q_counters[(size_t)qi * 4 + 0] = w.n_dist;
             a.q_counters[(size_t)qi * 4 + 1] = w.n_exp;

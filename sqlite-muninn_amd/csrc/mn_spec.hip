@@ -86,15 +86,53 @@ DEVI void spec_stamp(const MnDevIndex &ix, const MnSpecArgs &a, int node, int le
 //     evaluated and rejected, leaves no trace — if it turns up again in another row the worst result has only come nearer;
 //   * every neighbour that was ADDED (one of the window's new nodes: nothing else is ever added) would have been rejected: its
 //     distance to this insert's vector, computed here by the search's own code, is not below that worst result.
-// Anything else — a greedy descent's row, a search that met equal keys and went back to the heaps, a row of more than 64 links,
-// a list that was not kept — carries the log's defaults (-inf / all positions) and invalidates the insert as before.
+// A greedy descent's step (src/hnsw_algo.c:257-282) is simply taken again on the new list: from the same place, against the same
+// distance to beat, it must move to the same neighbour at the same position (the scan of the next row starts after it), or
+// nowhere as before.  Anything else — a search that met equal keys and went back to the heaps, a row of more than 64 links, a
+// list that was not kept — carries the log's defaults (-inf / all positions) and invalidates the insert as before.
 // One wavefront; qv = the insert's vector (LDS), qnorm as its search had it.  tmp: LDS, 64 ints.
 // Returns 0 = harmless, else why not (MN_SPEC_TRACE counts them): 3 the log's defaults, 4 the old list was not kept or the row is
-// wider than 64, 5 a removed neighbour could have been pushed, 6 an added node would have been pushed.
+// wider than 64, 5 a removed neighbour could have been pushed, 6 an added node would have been pushed, 7 a greedy step would
+// have gone elsewhere.
 template <int ORDER, int NCH>
 DEVI int spec_rewrite_is_harmless(const MnDevIndex &ix, const MnSpecArgs &a, const int *e, const float *qv, float qnorm, int *tmp,
                                   int lane) {
     const int r = e[0];
+    if (e[4] == 1) { // a greedy step: take it again on the row as it is now — it must move to the same neighbour at the same place
+        const int k = __hip_atomic_load((r >= 0 ? a.sidx0 + r : a.sidxU + (-r - 2)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int W = r >= 0 ? ix.W0 : ix.WU;
+        if (k < 0 || W > 64)
+            return 4;
+        const float to_beat = __int_as_float(e[1]);
+        const int from = e[2], moved_to = e[3];
+        const int *cur_row = r >= 0 ? ix.links0 + (size_t)r * ix.W0 : ix.links_up + (size_t)(-r - 2) * ix.WU;
+        const int c = lane < W ? ld_link<true>(cur_row + lane) : -1;
+        const bool valid = lane >= from && c >= 0 && !(ix.has_deleted && ix.deleted[c >= 0 ? c : 0]);
+        const unsigned long long m = __ballot(valid);
+        const int n = __popcll(m);
+        int now = -1;
+        if (n > 0) {
+            const int rank = __popcll(m & ((1ull << lane) - 1ull));
+            __builtin_amdgcn_wave_barrier();
+            if (valid) {
+                tmp[rank] = c;
+                tmp[64 + rank] = lane;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int myslot = lane < n ? tmp[lane] : 0;
+            const int mypos = lane < n ? tmp[64 + lane] : 0;
+            __builtin_amdgcn_wave_barrier();
+            const float d = rows_distance<ORDER, NCH>(ix, qv, qnorm, myslot, n, lane);
+            const unsigned long long better = __ballot(lane < n && d < to_beat);
+            if (better)
+                now = __builtin_amdgcn_readlane(mypos, __ffsll((long long)better) - 1);
+        }
+        if (now != moved_to)
+            return 7;
+        if (now >= 0 && a.saved_rows[(size_t)k * 64 + now] != __builtin_amdgcn_readlane(c, now))
+            return 7;
+        return 0;
+    }
     const float worst = __int_as_float(e[1]);
     const unsigned long long could = (unsigned long long)(unsigned)e[2] | ((unsigned long long)(unsigned)e[3] << 32);
     if (!(worst > -__builtin_inff())) // the defaults (or a NaN)
@@ -109,14 +147,30 @@ DEVI int spec_rewrite_is_harmless(const MnDevIndex &ix, const MnSpecArgs &a, con
     const int o = lane < W ? a.saved_rows[(size_t)k * 64 + lane] : -1;
     const int c = lane < W ? ld_link<true>(cur_row + lane) : -1;
     bool o_stays = false, c_was = false;
+    int o_now = 0; // where this lane's old neighbour sits in the list now
     for (int p = 0; p < W; p++) { // (lists of ≤ 64: all pairs)
         const int cp = __builtin_amdgcn_readlane(c, p), op = __builtin_amdgcn_readlane(o, p);
-        o_stays |= o == cp;
+        if (o == cp) {
+            o_stays = true;
+            o_now = p;
+        }
         c_was |= c == op;
     }
     const unsigned long long removed = __ballot(o >= 0 && !o_stays);
     if (removed & could)
         return 5;
+    if (e[4] == 2) { // the heaps' search: the neighbours that could be pushed must still come in the order they came in
+        const bool mine = (could >> lane) & 1ull;
+        const int rk = __popcll(could & ((1ull << lane) - 1ull));
+        __builtin_amdgcn_wave_barrier();
+        if (mine)
+            tmp[rk] = o_now;
+        __builtin_amdgcn_wave_barrier();
+        const bool bad = mine && rk > 0 && tmp[rk - 1] >= o_now;
+        __builtin_amdgcn_wave_barrier();
+        if (__ballot(bad))
+            return 5;
+    }
     const bool added = c >= 0 && !c_was;
     const unsigned long long am = __ballot(added);
     const int na = __popcll(am);
@@ -272,7 +326,7 @@ __global__ void __launch_bounds__(MN_SPEC_MAX_WAVES * 64) k_spec_commit(MnDevInd
                         if (lane == 0) {
                             flag[0] = 1;
                             if (a.why)
-                                atomicAdd(&a.why[why], 1);
+                                atomicAdd(&a.why[why == 7 ? 0 : why], 1); // ([7] counts the windows that committed whole)
                         }
                         break;
                     }
