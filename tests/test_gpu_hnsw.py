@@ -391,6 +391,44 @@ def test_speculative_windows_with_colliding_inserts_equal_the_single_wavefront_k
     assert graphs[0][3:] == graphs[1][3:]
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_speculative_windows_random_configurations_equal_the_single_wavefront_kernel(gpu, monkeypatch, seed):
+    """The window rules of mn_spec.hip on random small configurations where they bite hardest: small ef_construction (the
+    results are full after a few rows, so the "could have been pushed" masks and bounds decide, not the +inf of a filling queue),
+    small M (every row is full: every link is a prune that reorders the list), few dimensions and coarse coordinates (equal
+    distances: the heaps' searches and their order rule), clusters, several upper layers (greedy steps over rewritten rows)."""
+    rng = np.random.default_rng(1000 + seed)
+    dim = int(rng.integers(2, 12))
+    M = int(rng.choice([2, 3, 4, 6, 8]))
+    efc = int(rng.choice([4, 8, 16, 40]))
+    metric = ["l2", "cosine", "inner_product"][seed % 3]
+    n0, n1 = int(rng.integers(600, 3000)), 1200
+    k = int(rng.integers(3, 40))
+    centres = rng.standard_normal((k, dim)) * 2
+    X = centres[rng.integers(0, k, n0 + n1)] + rng.standard_normal((n0 + n1, dim)) * rng.choice([0.05, 0.3, 1.0])
+    if seed % 2 == 0:
+        X = np.round(X * 4) / 4  # coarse coordinates: many equal distances
+    X = X.astype(np.float32)
+    if metric != "l2":
+        X[np.abs(X).sum(1) == 0] += 1.0
+    ids = np.arange(1, n0 + n1 + 1, dtype=np.int64)
+    graphs = []
+    for spec in ("0", "1"):
+        monkeypatch.setenv("MN_SPECULATE", spec)
+        g = gpu.HnswIndex(dim, metric, M, efc)
+        assert g.insert_batch(ids[:n0], X[:n0], gpu.BUILD_SEQUENTIAL) == 0
+        for i in range(50, 50 + n0 // 20):
+            assert g.delete(int(ids[i])) == 0
+        assert g.insert_batch(ids[n0:], X[n0:], gpu.BUILD_SEQUENTIAL) == 0
+        lv = g.export_nodes()[1]
+        graphs.append(([g.export_links(l) for l in range(int(lv.max()) + 1)], lv, g.entry_point, g.max_level))
+        g.close()
+    assert graphs[0][2:] == graphs[1][2:] and np.array_equal(graphs[0][1], graphs[1][1])
+    assert len(graphs[0][0]) == len(graphs[1][0])
+    for a, b in zip(graphs[0][0], graphs[1][0]):
+        assert np.array_equal(a, b)
+
+
 def test_two_host_threads_two_indexes(gpu, orc):
     """SURVEY §8b threading contract: one host thread per connection, several connections per process.  Each index has
     its own HIP stream and the device is selected per call; two threads building and searching their own indexes at
