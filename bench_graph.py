@@ -505,7 +505,8 @@ def bench_tvf(pkg, args, what):
             "this_extension_ms": ours_ms, "compiled_reference_ms_on_this_host": ref_ms, "host": host_cpu(),
             "reference_published_ms": PUBLISHED_MS[what].get(n_pub), "rows_equal_to_reference": same},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel_ms": dev_ms, "algorithmic_bytes_per_launch": alg},
+                     "traffic": _traffic(f"tvf_{what}_er_{big['nodes']}_nodes_avg_degree_20"), "kernel_ms": dev_ms,
+                     "algorithmic_bytes_per_launch": alg},
         "cpu_baseline": None if ref_ms is None else {
             "value": ref_ms, "unit": "ms per query (lower is better)", "cores": 1, "kind": "reference", "host": host_cpu(),
             "sample": f"the compiled reference's own TVF through SQL at the published size ({n_pub} nodes): {ref_ms:.0f} ms; this "

@@ -2131,7 +2131,11 @@ extern "C" int mn_graph_betweenness(mn_graph *g, int direction, int auto_approx,
     const long long heap_cap = g->weighted ? e_trav + 2 : 1;
     // chunk of sources that fits the scratch budget
     const size_t per_src = (size_t)N * (3 * sizeof(double) + 3 * sizeof(int)) + (size_t)P * sizeof(int) + (size_t)heap_cap * sizeof(BrDpq);
-    size_t budget = (size_t)8 << 30;
+    // Half of what the device has free (round 4): the lanes of a launch are the only parallelism there is, and at the 8 GB of
+    // rounds 2-3 a 20 000-node graph went through in six launches of 58 wavefronts each on a chip of 1 024 SIMDs.
+    size_t budget = (size_t)8 << 30, free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+        budget = std::max<size_t>((size_t)256 << 20, free_b / 2);
     if (const char *e = getenv("MN_BRANDES_SCRATCH_MB"))
         budget = (size_t)atoll(e) << 20;
     int chunk = (int)std::max<size_t>(1, std::min<size_t>(sources.size(), budget / per_src));
@@ -2185,7 +2189,17 @@ extern "C" int mn_graph_betweenness(mn_graph *g, int direction, int auto_approx,
     for (size_t s0 = 0; s0 < sources.size(); s0 += (size_t)chunk) {
         a.n_src = (int)std::min<size_t>((size_t)chunk, sources.size() - s0);
         GCHK(hipMemcpyAsync(d_sources, sources.data() + s0, (size_t)a.n_src * sizeof(int), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_brandes_sources, dim3((a.n_src + 63) / 64), dim3(64), 0, st, a);
+        // One lane per source, and every lane a chain of dependent accesses to its own rows: what hides the latency is the
+        // number of wavefronts, not their width.  Narrow workgroups (4 to 64 lanes) until the launch has some 4 096 of them —
+        // 20 000 sources are 5 000 four-lane wavefronts, five per SIMD, instead of 313 full ones on a third of the SIMDs; a
+        // divergent memory instruction also costs one address cycle per distinct line, so narrow wavefronts lose nothing.
+        int lanes = 64;
+        if (const char *e = getenv("MN_BRANDES_LANES"))
+            lanes = std::max(1, std::min(64, atoi(e)));
+        else
+            while (lanes > 4 && (a.n_src + lanes - 1) / lanes < 4096)
+                lanes >>= 1;
+        hipLaunchKernelGGL(k_brandes_sources, dim3((a.n_src + lanes - 1) / lanes), dim3(lanes), 0, st, a);
         hipLaunchKernelGGL(k_brandes_accumulate, dim3((N + 255) / 256), dim3(256), 0, st, a, d_cb, d_eb);
         GCHK(hipStreamSynchronize(st)); // (the host vector `sources` chunk must outlive the copy; also bounds the queue)
     }
