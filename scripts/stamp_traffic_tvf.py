@@ -2,7 +2,7 @@
 """profiles/traffic.json entries for the three f-4 workloads of bench_graph.py (--workload tvf --no-ref-sql) from the raw
 rocprofv3 counter files of scripts/prof_tvf.sh: FETCH_SIZE (doubled: gfx950, MI355X_MICROARCH.md) + WRITE_SIZE, summed over the
 launches of ONE timed run at the C-ABI size (the warm-up run and the 10 000-node SQL run are told apart by grid size and order).
-usage: stamp_traffic_tvf.py <fetch counter csv> <write counter csv> <commit>"""
+usage: stamp_traffic_tvf.py <fetch counter csv> <write counter csv> <commit> [<summary tag> [key substring ...]]"""
 import csv
 import json
 import os
@@ -29,7 +29,7 @@ def one_run(rs, names, runs_at_big_size, iters_of_timed_run=None):
     mine = [r for r in rs if r[1] in names]
     if not mine:
         return None, 0
-    lead = names[0]
+    lead = next(nme for nme in names if any(r[1] == nme for r in mine))
     big = max(r[2] for r in mine if r[1] == lead)
     # a launch belongs to the big case when the lead kernel launched last before or at it had the big grid
     total, n, cur_big = 0.0, 0, False
@@ -39,10 +39,12 @@ def one_run(rs, names, runs_at_big_size, iters_of_timed_run=None):
             cur_big = r[2] == big
         if cur_big:
             picked.append(r)
-    if iters_of_timed_run is not None:  # pagerank: 2 warm-up iterations, then the timed 100 — keep the last 100 of each kernel
+    if iters_of_timed_run is not None:  # pagerank: 2 warm-up iterations, then the timed 100 — keep the last 100/102 of each kernel
         keep = []
         for nme in names:
-            keep += [r for r in picked if r[1] == nme][-iters_of_timed_run:]
+            mine_k = [r for r in picked if r[1] == nme]
+            if mine_k:
+                keep += mine_k[-max(1, round(len(mine_k) * iters_of_timed_run / (iters_of_timed_run + 2))):]
         picked, runs_at_big_size = keep, 1
     for r in picked:
         total += r[3]
@@ -52,15 +54,19 @@ def one_run(rs, names, runs_at_big_size, iters_of_timed_run=None):
 
 def main():
     fpath, wpath, commit = sys.argv[1:4]
+    tag = sys.argv[4] if len(sys.argv) > 4 else "r04_tvf_1M_20M"
+    only = sys.argv[5:]
     f, w = rows(fpath, "FETCH_SIZE"), rows(wpath, "WRITE_SIZE")
     tj_path = os.path.join(ROOT, "profiles", "traffic.json")
     tj = json.load(open(tj_path))
     spec = {
-        "tvf_pagerank_er_1000000_nodes_avg_degree_20": (["k_pr_pull", "k_pr_share"], 1, 100, ["mn_graph_algo.hip"]),
+        "tvf_pagerank_er_1000000_nodes_avg_degree_20": (["k_pr_pull_tile", "k_pr_pull", "k_pr_share"], 1, 100, ["mn_graph_algo.hip"]),
         "tvf_components_er_1000000_nodes_avg_degree_20": (["k_cc_hook", "k_cc_root", "k_cc_out", "k_uf_init"], 2, None, ["mn_graph_algo.hip"]),
         "tvf_betweenness_er_20000_nodes_avg_degree_20": (["k_brandes_accumulate", "k_brandes_sources"], 2, None, ["mn_graph.hip"]),
     }
     for key, (names, runs, iters, srcs) in spec.items():
+        if only and not any(o in key for o in only):
+            continue
         if key.startswith("tvf_betweenness"):
             # sources launches precede their accumulate launch: classify by the accumulate grid that FOLLOWS → walk backwards
             f2, w2 = [(-t, k, g, v) for t, k, g, v in f], [(-t, k, g, v) for t, k, g, v in w]
@@ -76,7 +82,7 @@ def main():
             continue
         tj[key] = {"kernel": " + ".join(names) + f", the {nf} launches of one timed run (bench_graph.py --workload tvf --no-ref-sql)",
                    "fetch_size_kb": fk, "write_size_kb": wk, "traffic_bytes": int((2 * fk + wk) * 1024),
-                   "source": "profiles/r04_tvf_1M_20M_pmc_summary.csv (round 4, scripts/prof_tvf.sh: separate --pmc passes; FETCH_SIZE doubled); "
+                   "source": f"profiles/{tag}_pmc_summary.csv (round 4, scripts/prof_tvf.sh: separate --pmc passes; FETCH_SIZE doubled); "
                              "per-run sums taken from the raw counter files by scripts/stamp_traffic_tvf.py",
                    "kernel_sources": srcs, "kernel_sources_sha256": kernel_sources_sha(srcs), "measured_in_round": 4,
                    "measured_at_commit": commit}

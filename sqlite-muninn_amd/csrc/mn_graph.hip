@@ -1886,6 +1886,10 @@ struct BrDpq {
     int node;
     double dist;
 };
+struct BrCell {
+    double dist, sigma, delta;
+    int pcnt, pad;
+};
 struct BrArgs {
     DevGraph g;
     int use_out, use_in, weighted;
@@ -1894,8 +1898,8 @@ struct BrArgs {
     const int *poff;     // [N+1] predecessor-list slots per node (static: one per incident traversed edge)
     long long P;         // poff[N]
     long long heap_cap;  // Dijkstra: entries per source
-    double *dist, *sigma, *delta; // [n_src][N]
-    int *stack, *queue, *pcnt;    // [n_src][N]   (queue doubles as Dijkstra's settled flags)
+    BrCell *cell;        // [n_src][N]   what a pass keeps per node, side by side (one line per touch of a node instead of three)
+    int *stack, *queue;  // [n_src][N]   (queue doubles as Dijkstra's settled flags)
     int *pitems;                  // [n_src][P]
     BrDpq *heap;                  // [n_src][heap_cap]
     int *overflow;
@@ -1908,17 +1912,16 @@ __global__ void __launch_bounds__(64) k_brandes_sources(BrArgs a) {
     if (si >= a.n_src)
         return;
     const int N = a.g.n, src = a.sources[si];
-    double *dist = a.dist + (size_t)si * N, *sigma = a.sigma + (size_t)si * N, *delta = a.delta + (size_t)si * N;
-    int *stack = a.stack + (size_t)si * N, *queue = a.queue + (size_t)si * N, *pcnt = a.pcnt + (size_t)si * N;
+    BrCell *c = a.cell + (size_t)si * N;
+    int *stack = a.stack + (size_t)si * N, *queue = a.queue + (size_t)si * N;
     int *pitems = a.pitems + (size_t)si * a.P;
     for (int i = 0; i < N; i++) {
-        dist[i] = -1.0;
-        sigma[i] = 0.0;
-        pcnt[i] = 0;
-        queue[i] = 0;
+        c[i] = BrCell{-1.0, 0.0, 0.0, 0, 0};
+        if (a.weighted)
+            queue[i] = 0; // (Dijkstra's settled flags; the BFS writes a queue position before it reads it)
     }
-    dist[src] = 0.0;
-    sigma[src] = 1.0;
+    c[src].dist = 0.0;
+    c[src].sigma = 1.0;
     int ss = 0;
     if (!a.weighted) { // sssp_bfs, :263-315
         int qh = 0, qt = 0;
@@ -1932,16 +1935,16 @@ __global__ void __launch_bounds__(64) k_brandes_sources(BrArgs a) {
                 const int *off = pass ? a.g.off_in : a.g.off_out, *tgt = pass ? a.g.tgt_in : a.g.tgt_out;
                 for (int e = off[v]; e < off[v + 1]; e++) {
                     const int w = tgt[e];
-                    if (dist[w] < 0) {
-                        dist[w] = dist[v] + 1.0;
+                    if (c[w].dist < 0) {
+                        c[w].dist = c[v].dist + 1.0;
                         queue[qt++] = w;
                     }
-                    if (br_double_eq(dist[w], dist[v] + 1.0)) {
-                        const int pc = pcnt[w];
+                    if (br_double_eq(c[w].dist, c[v].dist + 1.0)) {
+                        const int pc = c[w].pcnt;
                         if (pc == 0 || pitems[a.poff[w] + pc - 1] != v) {
-                            sigma[w] += sigma[v];
+                            c[w].sigma += c[v].sigma;
                             pitems[a.poff[w] + pc] = v;
-                            pcnt[w] = pc + 1;
+                            c[w].pcnt = pc + 1;
                         }
                     }
                 }
@@ -1987,12 +1990,12 @@ __global__ void __launch_bounds__(64) k_brandes_sources(BrArgs a) {
                 const double *wt = pass ? a.g.w_in : a.g.w_out;
                 for (int e = off[v]; e < off[v + 1]; e++) {
                     const int w = tgt[e];
-                    const double nd = dist[v] + (wt ? wt[e] : 1.0);
-                    if (dist[w] < 0 || nd < dist[w] - 1e-10) {
-                        dist[w] = nd;
-                        sigma[w] = sigma[v];
+                    const double nd = c[v].dist + (wt ? wt[e] : 1.0);
+                    if (c[w].dist < 0 || nd < c[w].dist - 1e-10) {
+                        c[w].dist = nd;
+                        c[w].sigma = c[v].sigma;
                         pitems[a.poff[w]] = v;
-                        pcnt[w] = 1;
+                        c[w].pcnt = 1;
                         if (hs >= a.heap_cap) {
                             *a.overflow = 1;
                             return;
@@ -2009,16 +2012,16 @@ __global__ void __launch_bounds__(64) k_brandes_sources(BrArgs a) {
                             h[i] = t;
                             i = parent;
                         }
-                    } else if (br_double_eq(nd, dist[w])) {
-                        const int pc = pcnt[w];
+                    } else if (br_double_eq(nd, c[w].dist)) {
+                        const int pc = c[w].pcnt;
                         if (pc == 0 || pitems[a.poff[w] + pc - 1] != v) {
                             if (pc >= a.poff[w + 1] - a.poff[w]) { // (cannot happen: one slot per incident edge)
                                 *a.overflow = 1;
                                 return;
                             }
-                            sigma[w] += sigma[v];
+                            c[w].sigma += c[v].sigma;
                             pitems[a.poff[w] + pc] = v;
-                            pcnt[w] = pc + 1;
+                            c[w].pcnt = pc + 1;
                         }
                     }
                 }
@@ -2026,16 +2029,14 @@ __global__ void __launch_bounds__(64) k_brandes_sources(BrArgs a) {
         }
     }
     // dependency accumulation in reverse stack order (:448-462)
-    for (int i = 0; i < N; i++)
-        delta[i] = 0.0;
-    while (ss > 0) {
+    while (ss > 0) { // (delta is zero from the start: the passes above never touch it)
         const int w = stack[--ss];
-        const int pc = pcnt[w];
+        const int pc = c[w].pcnt;
         for (int pi = 0; pi < pc; pi++) {
             const int v = pitems[a.poff[w] + pi];
-            if (sigma[w] > 0) {
-                const double flow = (sigma[v] / sigma[w]) * (1.0 + delta[w]);
-                delta[v] += flow;
+            if (c[w].sigma > 0) {
+                const double flow = (c[v].sigma / c[w].sigma) * (1.0 + c[w].delta);
+                c[v].delta += flow;
             }
         }
     }
@@ -2049,16 +2050,16 @@ __global__ void k_brandes_accumulate(BrArgs a, double *CB, double *EB) {
         return;
     double cb = CB[w];
     for (int si = 0; si < a.n_src; si++) {
-        const double *sigma = a.sigma + (size_t)si * N, *delta = a.delta + (size_t)si * N;
-        const double dw = delta[w];
+        const BrCell *c = a.cell + (size_t)si * N;
+        const double dw = c[w].delta;
         if (EB) {
-            const int pc = a.pcnt[(size_t)si * N + w];
+            const int pc = c[w].pcnt;
             const int *items = a.pitems + (size_t)si * a.P + a.poff[w];
-            const double sw = sigma[w];
+            const double sw = c[w].sigma;
             for (int pi = 0; pi < pc; pi++) {
                 const int v = items[pi];
                 if (sw > 0)
-                    EB[(size_t)v * N + w] += (sigma[v] / sw) * (1.0 + dw);
+                    EB[(size_t)v * N + w] += (c[v].sigma / sw) * (1.0 + dw);
             }
         }
         if (w != a.sources[si])
@@ -2130,7 +2131,7 @@ extern "C" int mn_graph_betweenness(mn_graph *g, int direction, int auto_approx,
     const long long P = poff[(size_t)N] > 0 ? poff[(size_t)N] : 1;
     const long long heap_cap = g->weighted ? e_trav + 2 : 1;
     // chunk of sources that fits the scratch budget
-    const size_t per_src = (size_t)N * (3 * sizeof(double) + 3 * sizeof(int)) + (size_t)P * sizeof(int) + (size_t)heap_cap * sizeof(BrDpq);
+    const size_t per_src = (size_t)N * (sizeof(BrCell) + 2 * sizeof(int)) + (size_t)P * sizeof(int) + (size_t)heap_cap * sizeof(BrDpq);
     // Half of what the device has free (round 4): the lanes of a launch are the only parallelism there is, and at the 8 GB of
     // rounds 2-3 a 20 000-node graph went through in six launches of 58 wavefronts each on a chip of 1 024 SIMDs.
     size_t budget = (size_t)8 << 30, free_b = 0, total_b = 0;
@@ -2162,18 +2163,15 @@ extern "C" int mn_graph_betweenness(mn_graph *g, int direction, int auto_approx,
     a.P = P;
     a.heap_cap = heap_cap;
     int *d_sources = (int *)scr.get((size_t)chunk * sizeof(int)), *d_poff = (int *)scr.get(((size_t)N + 1) * sizeof(int));
-    a.dist = (double *)scr.get((size_t)chunk * N * sizeof(double));
-    a.sigma = (double *)scr.get((size_t)chunk * N * sizeof(double));
-    a.delta = (double *)scr.get((size_t)chunk * N * sizeof(double));
+    a.cell = (BrCell *)scr.get((size_t)chunk * N * sizeof(BrCell));
     a.stack = (int *)scr.get((size_t)chunk * N * sizeof(int));
     a.queue = (int *)scr.get((size_t)chunk * N * sizeof(int));
-    a.pcnt = (int *)scr.get((size_t)chunk * N * sizeof(int));
     a.pitems = (int *)scr.get((size_t)chunk * P * sizeof(int));
     a.heap = (BrDpq *)scr.get((size_t)chunk * heap_cap * sizeof(BrDpq));
     a.overflow = (int *)scr.get(sizeof(int));
     double *d_cb = (double *)scr.get((size_t)N * sizeof(double));
     double *d_eb = eb_out ? (double *)scr.get((size_t)N * N * sizeof(double)) : nullptr;
-    if (!d_sources || !d_poff || !a.dist || !a.sigma || !a.delta || !a.stack || !a.queue || !a.pcnt || !a.pitems || !a.heap ||
+    if (!d_sources || !d_poff || !a.cell || !a.stack || !a.queue || !a.pitems || !a.heap ||
         !a.overflow || !d_cb || (eb_out && !d_eb)) {
         gset_err("mn_graph_betweenness: out of device memory (N = %d%s)", N, eb_out ? ", dense N x N edge matrix as in the reference" : "");
         return -1;

@@ -77,6 +77,7 @@ __global__ void k_pr_share(const double *rank, const int *outc, int n, double da
 }
 
 #define PR_CHUNK 256
+#define DEVI_PR __device__ __forceinline__
 __global__ void __launch_bounds__(PR_CHUNK)
     k_pr_pull(const int *in_off, const int *in_src, const double *share, const int *dang, int n_dang, int n, double teleport,
               double *rank_new) {
@@ -133,6 +134,50 @@ __global__ void __launch_bounds__(PR_CHUNK)
         rank_new[j] = acc;
 }
 
+// Round 4, graphs without dangling nodes whose share[] outgrows one XCD's L2 (4 MB): the in-list of a target is ascending by
+// source, so cutting the SOURCES into ranges of 2^PR_TILE_LOG2 nodes cuts every list into consecutive pieces — one launch per range adds
+// a target's piece to its running sum, in list order, and parks the sum in rank_new[] for the next range (an f64 through memory
+// keeps its bits).  Every gather of a launch then falls into the same 2 MB of share[], which stays in each XCD's L2 instead of
+// coming over the fabric a 128-byte line per 8-byte gather.
+#define PR_TILE_LOG2 18
+template <bool NT> DEVI_PR int pr_ld(const int *p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT>
+__global__ void __launch_bounds__(PR_CHUNK)
+    k_pr_pull_tile(const int *lo, const int *hi, const int *in_src, const double *share, int n, double teleport, int first,
+                   double *rank_new) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n)
+        return;
+    // NT (MN_PR_NT=1, off): the streamed operands loaded non-temporal so that they leave share[] in the L2 — measured 40 % SLOWER
+    // (profiles/r04_ab_pagerank_source_ranges.txt); smaller ranges lose too: every launch re-reads the cuts and the running sums
+    int p = pr_ld<NT>(lo + j);
+    const int pe = pr_ld<NT>(hi + j);
+    double acc = first ? teleport : rank_new[j]; // :1689
+    for (; p + 4 <= pe; p += 4) {
+        int sidx[4];
+        double sv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            sidx[u] = pr_ld<NT>(in_src + p + u);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            sv[u] = share[sidx[u]];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            acc += sv[u];
+    }
+    if (p < pe) { // up to three left: requested together, added in order
+        const int s0 = pr_ld<NT>(in_src + p), s1 = p + 1 < pe ? pr_ld<NT>(in_src + p + 1) : s0, s2 = p + 2 < pe ? pr_ld<NT>(in_src + p + 2) : s0;
+        const double v0 = share[s0], v1 = share[s1], v2 = share[s2];
+        acc += v0;
+        if (p + 1 < pe)
+            acc += v1;
+        if (p + 2 < pe)
+            acc += v2;
+    }
+    rank_new[j] = acc;
+}
+
 extern "C" int mn_graph_pagerank(int n, int64_t n_edges, const int *src, const int *dst, double damping, int iterations,
                                  int device, double *rank_out, mn_graph_algo_stats *stats) try {
     if (stats)
@@ -179,7 +224,38 @@ extern "C" int mn_graph_pagerank(int n, int64_t n_edges, const int *src, const i
     for (int i = 0; i < n; i++)
         if (outc[i] == 0)
             dang.push_back(i);
+    // source ranges (see k_pr_pull_tile): cut[t][j] = first position of j's list whose source is >= t * PR_TILE
+    int tile_log2 = PR_TILE_LOG2, nt = 0;
+    if (const char *e = getenv("MN_PR_TILE_LOG2"))
+        tile_log2 = std::max(10, std::min(30, atoi(e)));
+    if (const char *e = getenv("MN_PR_NT"))
+        nt = atoi(e) != 0;
+    const long long PR_TILE = 1LL << tile_log2;
+    int tiles = dang.empty() && n > PR_TILE ? (int)((n + PR_TILE - 1) / PR_TILE) : 1;
+    if (const char *e = getenv("MN_PR_TILES"))
+        if (atoi(e) == 0)
+            tiles = 1;
+    std::vector<int> cut;
+    if (tiles > 1) {
+        cut.resize((size_t)(tiles + 1) * n);
+        for (int j = 0; j < n; j++) {
+            int p = in_off[j];
+            for (int t = 0; t <= tiles; t++) {
+                const long long bound = (long long)t * PR_TILE;
+                while (p < in_off[j + 1] && in_src[p] < bound)
+                    p++;
+                cut[(size_t)t * n + j] = t == tiles ? in_off[j + 1] : p;
+            }
+        }
+    }
     Bufs b;
+    int *d_cut = tiles > 1 ? b.alloc<int>(cut.size()) : nullptr;
+    if (tiles > 1 && !d_cut) {
+        aset_err("mn_graph_pagerank: out of device memory");
+        return -1;
+    }
+    if (tiles > 1)
+        ACHK(hipMemcpy(d_cut, cut.data(), cut.size() * sizeof(int), hipMemcpyHostToDevice));
     int *d_outc = b.alloc<int>(n), *d_inoff = b.alloc<int>((size_t)n + 1), *d_insrc = b.alloc<int>(E), *d_dang = b.alloc<int>(dang.size());
     double *d_r0 = b.alloc<double>(n), *d_r1 = b.alloc<double>(n), *d_share = b.alloc<double>(n);
     if (!d_outc || !d_inoff || !d_insrc || !d_dang || !d_r0 || !d_r1 || !d_share) {
@@ -203,8 +279,13 @@ extern "C" int mn_graph_pagerank(int n, int64_t n_edges, const int *src, const i
     double *cur = d_r0, *nxt = d_r1;
     for (int it = 0; it < iterations; it++) {
         hipLaunchKernelGGL(k_pr_share, dim3(nb), dim3(PR_CHUNK), 0, nullptr, cur, d_outc, n, damping, d_share);
-        hipLaunchKernelGGL(k_pr_pull, dim3(nb), dim3(PR_CHUNK), 0, nullptr, d_inoff, d_insrc, d_share, d_dang, (int)dang.size(), n,
-                           teleport, nxt);
+        if (tiles > 1)
+            for (int t = 0; t < tiles; t++)
+                hipLaunchKernelGGL(nt ? k_pr_pull_tile<true> : k_pr_pull_tile<false>, dim3(nb), dim3(PR_CHUNK), 0, nullptr, d_cut + (size_t)t * n,
+                                   d_cut + (size_t)(t + 1) * n, d_insrc, d_share, n, teleport, t == 0, nxt);
+        else
+            hipLaunchKernelGGL(k_pr_pull, dim3(nb), dim3(PR_CHUNK), 0, nullptr, d_inoff, d_insrc, d_share, d_dang, (int)dang.size(), n,
+                               teleport, nxt);
         std::swap(cur, nxt);
     }
     ACHK(hipEventRecord(e1, nullptr));
@@ -392,13 +473,25 @@ __global__ void k_cc_hook(const int *src, const int *dst, long long n_edges, int
     }
 }
 
+// One atomic per distinct root of a wavefront (round 4): a graph that is one giant component sent a million atomicAdds to one
+// address — 5.7 ms of the 14 ms of a 1M-node run.  Counts are integers: the order they arrive in does not matter.
 __global__ void k_cc_root(const int *parent, int n, int *root, int *size) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n)
-        return;
-    const int r = uf_root(parent, i);
-    root[i] = r;
-    atomicAdd(size + r, 1);
+    const bool live = i < n;
+    int r = -1;
+    if (live) {
+        r = uf_root(parent, i);
+        root[i] = r;
+    }
+    unsigned long long todo = __ballot(live); // (wave-uniform: every lane takes every turn of the loop)
+    while (todo) {
+        const int lead = __ffsll((long long)todo) - 1;
+        const int r0 = __shfl(r, lead);
+        const unsigned long long same = __ballot(live && r == r0);
+        if ((int)(threadIdx.x & 63) == lead)
+            atomicAdd(size + r0, __popcll(same));
+        todo &= ~same;
+    }
 }
 
 __global__ void k_cc_out(const int *root, const int *size, int n, int *comp_size) {

@@ -132,6 +132,30 @@ def test_sql_table_valued_functions_equal_the_reference(gpu, ext_conn):
     assert c.execute("SELECT * FROM graph_pagerank WHERE edge_table='empty_e' AND src_col='s' AND dst_col='d'").fetchall() == []
 
 
+@pytest.mark.gpu
+def test_pagerank_by_source_ranges_equals_the_oracle_and_the_one_launch_pull(gpu, monkeypatch):
+    """Graphs without dangling nodes and more than 2^18 nodes are pulled one source range per launch (k_pr_pull_tile: share[]
+    stays in the L2): 700k nodes (three ranges, the last one short), 4.2M rows with multi-edges, self loops, nodes with an empty
+    in-list and lists that skip a whole range — rank bits against the oracle and against the one-launch kernel."""
+    rng = np.random.default_rng(21)
+    n, m = 700_000, 3_500_000
+    s = np.concatenate([np.arange(n, dtype=np.int64), rng.integers(0, n, m)]).astype(np.int32)  # every node has an out-edge
+    d = rng.integers(0, n - 5000, n + m).astype(np.int32)  # the last 5 000 nodes have no in-edge
+    d[rng.integers(0, n + m, 50_000)] = 7  # one long in-list crossing every range
+    lowhalf = rng.integers(0, n + m, 200_000)
+    d[lowhalf] = 11  # a second hub whose sources are then cut to the first range only
+    s[lowhalf] = rng.integers(0, 1 << 18, len(lowhalf)).astype(np.int32)
+    s[:n] = np.arange(n, dtype=np.int32)  # (keep the out-edge of every node)
+    d[:n][d[:n] == 11] = 12
+    want = og.pagerank(n, s, d, 0.85, 6)
+    got, st = gpu.graph.pagerank(n, s, d, 0.85, 6)
+    assert st["dangling"] == 0
+    assert np.array_equal(got.view(np.int64), want.view(np.int64))
+    monkeypatch.setenv("MN_PR_TILES", "0")
+    one, _ = gpu.graph.pagerank(n, s, d, 0.85, 6)
+    assert np.array_equal(one.view(np.int64), want.view(np.int64))
+
+
 # ───────────── f-2: csr_apply_delta (the merge step of graph_adjacency's incremental rebuild) ─────────────
 
 def _same_csr(a, b):
