@@ -276,9 +276,15 @@ def test_betweenness_device_vs_oracle_larger(gpu, weighted):
     os.environ["MN_BRANDES_SCRATCH_MB"] = "256"  # several chunks of sources: the source-order accumulation crosses chunks
     try:
         got, _, ms = g.betweenness("both", 0, 1)
+        os.environ["MN_BRANDES_LANES"] = "64"  # full wavefronts (the default narrows them until a launch has thousands)
+        wide, _, _ = g.betweenness("both", 0, 1)
     finally:
         os.environ.pop("MN_BRANDES_SCRATCH_MB")
+        os.environ.pop("MN_BRANDES_LANES", None)
     assert np.array_equal(got.view(np.int64), want.view(np.int64))
+    assert np.array_equal(wide.view(np.int64), want.view(np.int64))
+    one, _, _ = g.betweenness("both", 0, 1)  # the default budget: every source in one launch
+    assert np.array_equal(one.view(np.int64), want.view(np.int64))
     g.close()
 
 
