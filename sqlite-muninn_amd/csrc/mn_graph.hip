@@ -2135,8 +2135,9 @@ extern "C" int mn_graph_betweenness(mn_graph *g, int direction, int auto_approx,
     // Half of what the device has free (round 4): the lanes of a launch are the only parallelism there is, and at the 8 GB of
     // rounds 2-3 a 20 000-node graph went through in six launches of 58 wavefronts each on a chip of 1 024 SIMDs.
     size_t budget = (size_t)8 << 30, free_b = 0, total_b = 0;
+    const size_t eb_bytes = eb_out ? (size_t)N * N * sizeof(double) : 0; // (allocated after the scratch: leave it its room)
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-        budget = std::max<size_t>((size_t)256 << 20, free_b / 2);
+        budget = std::max<size_t>((size_t)256 << 20, (free_b > eb_bytes ? free_b - eb_bytes : 0) / 2);
     if (const char *e = getenv("MN_BRANDES_SCRATCH_MB"))
         budget = (size_t)atoll(e) << 20;
     int chunk = (int)std::max<size_t>(1, std::min<size_t>(sources.size(), budget / per_src));
