@@ -178,6 +178,56 @@ __global__ void __launch_bounds__(PR_CHUNK)
     rank_new[j] = acc;
 }
 
+// Balanced gathers (round 4, last): with one lane per target a wavefront issues as many gather instructions as its LONGEST piece has
+// entries (≈ 12 where the mean is 5), and the kernel's time follows the gather instructions issued.  The pieces of a range are
+// therefore stored range-major (tsrc / toff, built with the in-lists on the host), so that the pieces of a wavefront's 64 targets are
+// one contiguous run: its lanes request entry base + k·64 + lane — coalesced sources, every lane busy — park the shares in LDS, and
+// each lane then adds ITS piece from LDS in list order.  The additions and their order are unchanged.
+#define PR_FLAT_CAP 512
+__global__ void __launch_bounds__(PR_CHUNK)
+    k_pr_pull_flat(const int *toff, const int *tsrc, const double *share, int n, double teleport, int first, double *rank_new) {
+    __shared__ double val[PR_CHUNK / 64][PR_FLAT_CAP];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j0 = blockIdx.x * blockDim.x + (wv << 6); // first target of this wavefront
+    if (j0 >= n)
+        return; // (the whole wavefront)
+    const int j = j0 + lane;
+    const bool live = j < n;
+    int p = toff[live ? j : n];
+    const int pe = toff[live ? j + 1 : n];
+    double acc = live ? (first ? teleport : rank_new[j]) : 0.0; // :1689
+    const int wbeg = __shfl(p, 0), wend = toff[j0 + 64 < n ? j0 + 64 : n];
+    double *v = val[wv];
+    for (int base = wbeg; base < wend; base += PR_FLAT_CAP) {
+        const int cnt = wend - base < PR_FLAT_CAP ? wend - base : PR_FLAT_CAP;
+        for (int k0 = 0; k0 < cnt; k0 += 256) {
+            int sidx[4];
+            double sv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = k0 + u * 64 + lane;
+                sidx[u] = i < cnt ? tsrc[base + i] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                sv[u] = sidx[u] >= 0 ? share[sidx[u]] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = k0 + u * 64 + lane;
+                if (i < cnt)
+                    v[i] = sv[u];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int hi = pe < base + cnt ? pe : base + cnt;
+        for (; p < hi; p++)
+            acc += v[p - base];
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (live)
+        rank_new[j] = acc;
+}
+
 extern "C" int mn_graph_pagerank(int n, int64_t n_edges, const int *src, const int *dst, double damping, int iterations,
                                  int device, double *rank_out, mn_graph_algo_stats *stats) try {
     if (stats)
@@ -248,6 +298,27 @@ extern "C" int mn_graph_pagerank(int n, int64_t n_edges, const int *src, const i
             }
         }
     }
+    int flat = 1;
+    if (const char *e = getenv("MN_PR_FLAT"))
+        flat = atoi(e) != 0;
+    std::vector<int> toff;
+    if (tiles > 1 && flat) { // range-major pieces (k_pr_pull_flat); in_src is then only needed in this order
+        toff.resize((size_t)tiles * ((size_t)n + 1));
+        std::vector<int> tsrc((size_t)(E ? E : 1));
+        int run = 0;
+        for (int t = 0; t < tiles; t++) {
+            for (int j = 0; j < n; j++) {
+                toff[(size_t)t * (n + 1) + j] = run;
+                for (int x = cut[(size_t)t * n + j]; x < cut[(size_t)(t + 1) * n + j]; x++)
+                    tsrc[run++] = in_src[x];
+            }
+            toff[(size_t)t * (n + 1) + n] = run;
+        }
+        in_src.swap(tsrc);
+        cut.swap(toff); // (uploaded through d_cut below)
+        toff.assign(1, 0);
+    }
+    const bool use_flat = tiles > 1 && flat;
     Bufs b;
     int *d_cut = tiles > 1 ? b.alloc<int>(cut.size()) : nullptr;
     if (tiles > 1 && !d_cut) {
@@ -279,7 +350,11 @@ extern "C" int mn_graph_pagerank(int n, int64_t n_edges, const int *src, const i
     double *cur = d_r0, *nxt = d_r1;
     for (int it = 0; it < iterations; it++) {
         hipLaunchKernelGGL(k_pr_share, dim3(nb), dim3(PR_CHUNK), 0, nullptr, cur, d_outc, n, damping, d_share);
-        if (tiles > 1)
+        if (use_flat)
+            for (int t = 0; t < tiles; t++)
+                hipLaunchKernelGGL(k_pr_pull_flat, dim3(nb), dim3(PR_CHUNK), 0, nullptr, d_cut + (size_t)t * (n + 1), d_insrc, d_share, n, teleport,
+                                   t == 0, nxt);
+        else if (tiles > 1)
             for (int t = 0; t < tiles; t++)
                 hipLaunchKernelGGL(nt ? k_pr_pull_tile<true> : k_pr_pull_tile<false>, dim3(nb), dim3(PR_CHUNK), 0, nullptr, d_cut + (size_t)t * n,
                                    d_cut + (size_t)(t + 1) * n, d_insrc, d_share, n, teleport, t == 0, nxt);
