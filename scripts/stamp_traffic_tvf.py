@@ -60,7 +60,7 @@ def main():
     tj_path = os.path.join(ROOT, "profiles", "traffic.json")
     tj = json.load(open(tj_path))
     spec = {
-        "tvf_pagerank_er_1000000_nodes_avg_degree_20": (["k_pr_pull_tile", "k_pr_pull", "k_pr_share"], 1, 100, ["mn_graph_algo.hip"]),
+        "tvf_pagerank_er_1000000_nodes_avg_degree_20": (["k_pr_pull_flat", "k_pr_pull_tile", "k_pr_pull", "k_pr_share"], 1, 100, ["mn_graph_algo.hip"]),
         "tvf_components_er_1000000_nodes_avg_degree_20": (["k_cc_hook", "k_cc_root", "k_cc_out", "k_uf_init"], 2, None, ["mn_graph_algo.hip"]),
         "tvf_betweenness_er_20000_nodes_avg_degree_20": (["k_brandes_accumulate", "k_brandes_sources"], 2, None, ["mn_graph.hip"]),
     }
